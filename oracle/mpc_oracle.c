@@ -1,0 +1,829 @@
+/*
+ * mpc_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).  See mpc_oracle.h.
+ *
+ * PARITY UNPINNED for solve outputs (acados/HPIPM are absent; see header).
+ *
+ * Deliberately written as a dense, generic, residual-form ("delta form") primal-dual interior
+ * point method with explicit costates and explicit KKT residuals, i.e. NOT the way the HIP
+ * kernel is organised (which uses the structure-exploiting "absolute form" without costates).
+ * Agreement of the two is therefore a real check.  The QP of one RTI step is strictly convex
+ * (Gauss-Newton Hessian + LM*I, robot_ocp_problem.py:127-128) so its solution is unique.
+ *
+ * All paths cited are relative to /root/reference.
+ */
+#include "mpc_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NX ORC_NX
+#define NU ORC_NU
+#define NZ ORC_NZ
+#define TL_MIN 1e-13
+
+static const int IDXBX[4] = {0, 1, 3, 4}; /* robot_ocp_problem.py:93 */
+
+/* Gauss-Legendre 4-point rule on [0,1] (acados IRK default: GL, 4 stages) */
+static const double GLC[4] = {0.069431844202973712388, 0.330009478207571867599,
+                              0.669990521792428132401, 0.930568155797026287612};
+static const double GLB[4] = {0.173927422568726928687, 0.326072577431273071313,
+                              0.326072577431273071313, 0.173927422568726928687};
+
+void orc_default_config(orc_config *c, int N, int n_obst, double Tf)
+{
+    memset(c, 0, sizeof(*c));
+    c->N = N; c->n_obst = n_obst; c->Tf = Tf;
+    /* robot_ocp_problem.py:24-27: R = 0.15 I2, Q = 2 I4, Q_e = 5 I4 */
+    for (int k = 0; k < 4; k++) { c->W[k] = 2.0; c->We[k] = 5.0; }
+    c->W[4] = c->W[5] = 0.15;
+    c->lm = 2.0;                                      /* :128 */
+    c->bx_lo[0] = c->bx_lo[1] = -7.0; c->bx_hi[0] = c->bx_hi[1] = 7.0;    /* :91-92 */
+    c->bx_lo[2] = c->bx_lo[3] = -10.0; c->bx_hi[2] = c->bx_hi[3] = 10.0;  /* V_MAX_ROBOT */
+    c->bu_lo[0] = c->bu_lo[1] = -8.0; c->bu_hi[0] = c->bu_hi[1] = 8.0;    /* C_MAX :95-96 */
+    c->r_safe = 1.0 + 0.2 + 1.2;                      /* robot_model.py:62 */
+    c->slack_a = 1e4; c->slack_b = 50.0;              /* :146 */
+    c->qp_iter_max = 50;                              /* world_specification.py:48 */
+    c->qp_tol = 1e-8;
+    c->cost_scale_dt = 1; c->slack_scale_dt = 1; c->lm_scaled = 0; c->bx_terminal = 0; c->soft_h = 1;
+    c->arena[0] = -8.0; c->arena[1] = 8.0; c->arena[2] = -8.0; c->arena[3] = 8.0;
+    c->bug_compat_predict = 1;
+    c->mu0 = 1e4; c->thr0 = 1e-1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Model: robot_model.py:39-43                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+void orc_ode(const double *x, const double *u, double *xdot)
+{
+    xdot[0] = x[3] * cos(x[2]);
+    xdot[1] = x[3] * sin(x[2]);
+    xdot[2] = x[4];
+    xdot[3] = u[0];
+    xdot[4] = u[1];
+}
+
+static void ode_jac(const double *x, double *fx /*5x5*/, double *fu /*5x2*/)
+{
+    memset(fx, 0, 25 * sizeof(double));
+    memset(fu, 0, 10 * sizeof(double));
+    double c = cos(x[2]), s = sin(x[2]);
+    fx[0 * 5 + 2] = -x[3] * s; fx[0 * 5 + 3] = c;
+    fx[1 * 5 + 2] = x[3] * c;  fx[1 * 5 + 3] = s;
+    fx[2 * 5 + 4] = 1.0;
+    fu[3 * 2 + 0] = 1.0;
+    fu[4 * 2 + 1] = 1.0;
+}
+
+/*
+ * Closed form of one IRK-GL4 step for this ODE: psi, v, omega are polynomial
+ * in t, and x,y are a 4-point Gauss-Legendre quadrature of v(t)cos(psi(t)), v(t)sin(psi(t)).
+ * Plant integrator (robot_ocp_problem.py:136,207-212) and OCP integrator (:129) are the same map.
+ */
+void orc_dynamics(const double *x, const double *u, double dt, double *xn, double *A, double *B)
+{
+    double psi = x[2], v = x[3], om = x[4], a = u[0], al = u[1];
+    double sx = 0, sy = 0;
+    double dx_dpsi = 0, dx_dv = 0, dx_dom = 0, dx_da = 0, dx_dal = 0;
+    double dy_dpsi = 0, dy_dv = 0, dy_dom = 0, dy_da = 0, dy_dal = 0;
+    for (int j = 0; j < 4; j++) {
+        double tau = GLC[j] * dt, w = GLB[j] * dt;
+        double vj = v + a * tau;
+        double pj = psi + om * tau + 0.5 * al * tau * tau;
+        double cj = cos(pj), sj = sin(pj);
+        sx += w * vj * cj;
+        sy += w * vj * sj;
+        dx_dpsi += -w * vj * sj;          dy_dpsi += w * vj * cj;
+        dx_dv += w * cj;                  dy_dv += w * sj;
+        dx_dom += -w * vj * sj * tau;     dy_dom += w * vj * cj * tau;
+        dx_da += w * tau * cj;            dy_da += w * tau * sj;
+        dx_dal += -w * vj * sj * 0.5 * tau * tau;
+        dy_dal += w * vj * cj * 0.5 * tau * tau;
+    }
+    xn[0] = x[0] + sx;
+    xn[1] = x[1] + sy;
+    xn[2] = psi + om * dt + 0.5 * al * dt * dt;
+    xn[3] = v + a * dt;
+    xn[4] = om + al * dt;
+    if (A) {
+        memset(A, 0, 25 * sizeof(double));
+        for (int k = 0; k < 5; k++) A[k * 5 + k] = 1.0;
+        A[0 * 5 + 2] = dx_dpsi; A[0 * 5 + 3] = dx_dv; A[0 * 5 + 4] = dx_dom;
+        A[1 * 5 + 2] = dy_dpsi; A[1 * 5 + 3] = dy_dv; A[1 * 5 + 4] = dy_dom;
+        A[2 * 5 + 4] = dt;
+    }
+    if (B) {
+        memset(B, 0, 10 * sizeof(double));
+        B[0 * 2 + 0] = dx_da; B[0 * 2 + 1] = dx_dal;
+        B[1 * 2 + 0] = dy_da; B[1 * 2 + 1] = dy_dal;
+        B[2 * 2 + 1] = 0.5 * dt * dt;
+        B[3 * 2 + 0] = dt;
+        B[4 * 2 + 1] = dt;
+    }
+}
+
+/* dense Gaussian elimination with partial pivoting: solves M X = R in place (M n x n, R n x m) */
+static int gauss_solve(int n, int m, double *M, double *R)
+{
+    for (int k = 0; k < n; k++) {
+        int p = k; double best = fabs(M[k * n + k]);
+        for (int r = k + 1; r < n; r++) if (fabs(M[r * n + k]) > best) { best = fabs(M[r * n + k]); p = r; }
+        if (best == 0.0) return -1;
+        if (p != k) {
+            for (int cidx = 0; cidx < n; cidx++) { double t = M[k * n + cidx]; M[k * n + cidx] = M[p * n + cidx]; M[p * n + cidx] = t; }
+            for (int cidx = 0; cidx < m; cidx++) { double t = R[k * m + cidx]; R[k * m + cidx] = R[p * m + cidx]; R[p * m + cidx] = t; }
+        }
+        double inv = 1.0 / M[k * n + k];
+        for (int r = k + 1; r < n; r++) {
+            double f = M[r * n + k] * inv;
+            if (f == 0.0) continue;
+            for (int cidx = k; cidx < n; cidx++) M[r * n + cidx] -= f * M[k * n + cidx];
+            for (int cidx = 0; cidx < m; cidx++) R[r * m + cidx] -= f * R[k * m + cidx];
+        }
+    }
+    for (int k = n - 1; k >= 0; k--) {
+        double inv = 1.0 / M[k * n + k];
+        for (int cidx = 0; cidx < m; cidx++) {
+            double s = R[k * m + cidx];
+            for (int j = k + 1; j < n; j++) s -= M[k * n + j] * R[j * m + cidx];
+            R[k * m + cidx] = s * inv;
+        }
+    }
+    return 0;
+}
+
+/* Butcher matrix of the s=4 Gauss-Legendre collocation method: a_ij = int_0^{c_i} l_j(t) dt */
+static void gl4_butcher(double a[4][4])
+{
+    for (int j = 0; j < 4; j++) {
+        /* l_j(t) = prod_{m != j} (t - c_m)/(c_j - c_m): cubic with coefficients p[0..3] */
+        double p[4] = {1, 0, 0, 0}; int deg = 0; double den = 1.0;
+        for (int m = 0; m < 4; m++) {
+            if (m == j) continue;
+            double np_[4] = {0, 0, 0, 0};
+            for (int d = 0; d <= deg; d++) { np_[d + 1] += p[d]; np_[d] += -GLC[m] * p[d]; }
+            deg++;
+            for (int d = 0; d < 4; d++) p[d] = np_[d];
+            den *= (GLC[j] - GLC[m]);
+        }
+        for (int i = 0; i < 4; i++) {
+            double t = GLC[i], acc = 0, tp = t;
+            for (int d = 0; d < 4; d++) { acc += p[d] * tp / (d + 1); tp *= t; }
+            a[i][j] = acc / den;
+        }
+    }
+}
+
+/*
+ * General IRK Gauss-Legendre collocation (4 stages, 1 step) with `newton_iter` Newton iterations
+ * from K = 0 and forward sensitivities by the implicit function theorem -- what acados'
+ * integrator_type='IRK' (robot_ocp_problem.py:129) does with its defaults [acados-knowledge].
+ * Used only to check the closed form above.
+ */
+void orc_dynamics_collocation(const double *x, const double *u, double dt, int newton_iter,
+                              double *xn, double *A, double *B)
+{
+    double a[4][4]; gl4_butcher(a);
+    double K[20]; memset(K, 0, sizeof(K));
+    double J[400], R[20 * 8], fx[25], fu[10];
+    for (int it = 0; it <= newton_iter; it++) {
+        /* residual G = K - f(x + dt a K, u) and Jacobian dG/dK */
+        memset(J, 0, sizeof(J));
+        for (int s = 0; s < 4; s++) {
+            double xs[5], f[5];
+            for (int k = 0; k < 5; k++) { xs[k] = x[k]; for (int l = 0; l < 4; l++) xs[k] += dt * a[s][l] * K[l * 5 + k]; }
+            orc_ode(xs, u, f); ode_jac(xs, fx, fu);
+            for (int k = 0; k < 5; k++) {
+                R[(s * 5 + k) * 8 + 0] = -(K[s * 5 + k] - f[k]);
+                for (int m = 0; m < 5; m++) R[(s * 5 + k) * 8 + 1 + m] = fx[k * 5 + m];  /* rhs for dK/dx */
+                for (int m = 0; m < 2; m++) R[(s * 5 + k) * 8 + 6 + m] = fu[k * 2 + m];  /* rhs for dK/du */
+                J[(s * 5 + k) * 20 + (s * 5 + k)] += 1.0;
+                for (int l = 0; l < 4; l++) for (int m = 0; m < 5; m++)
+                    J[(s * 5 + k) * 20 + (l * 5 + m)] -= dt * a[s][l] * fx[k * 5 + m];
+            }
+        }
+        gauss_solve(20, 8, J, R);
+        if (it < newton_iter) { for (int i = 0; i < 20; i++) K[i] += R[i * 8 + 0]; }
+        /* after the last Newton update, one more pass (it == newton_iter) evaluates sensitivities at the final K */
+    }
+    for (int k = 0; k < 5; k++) { xn[k] = x[k]; for (int s = 0; s < 4; s++) xn[k] += dt * GLB[s] * K[s * 5 + k]; }
+    if (A) for (int k = 0; k < 5; k++) for (int m = 0; m < 5; m++) {
+        double acc = (k == m) ? 1.0 : 0.0;
+        for (int s = 0; s < 4; s++) acc += dt * GLB[s] * R[(s * 5 + k) * 8 + 1 + m];
+        A[k * 5 + m] = acc;
+    }
+    if (B) for (int k = 0; k < 5; k++) for (int m = 0; m < 2; m++) {
+        double acc = 0.0;
+        for (int s = 0; s < 4; s++) acc += dt * GLB[s] * R[(s * 5 + k) * 8 + 6 + m];
+        B[k * 2 + m] = acc;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Obstacles: utils/visualization.py:25-79                                                     */
+/* ------------------------------------------------------------------------------------------ */
+static double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* visualization.py:25-60 (predict_step).  state = {x, y, vx, vy}. */
+void orc_obstacle_step(const orc_config *c, double *st, double dt, const double *noise, double randomness, double vmax)
+{
+    double x = st[0], y = st[1], vx = st[2], vy = st[3];
+    if (noise) { /* :28-33 */
+        vx = clampd((1.0 + randomness * noise[0]) * vx, -vmax, vmax);
+        vy = clampd((1.0 + randomness * noise[1]) * vy, -vmax, vmax);
+    }
+    double t_hit;
+    if (vx < 0) t_hit = (x - c->arena[0]) / fabs(vx);        /* :35-40 */
+    else if (vx > 0) t_hit = (c->arena[1] - x) / fabs(vx);
+    else t_hit = INFINITY;
+    if (t_hit <= dt) { x += (vx * t_hit - vx * (dt - t_hit)); vx = -vx; } else x += vx * dt;  /* :42-46 */
+    if (vy < 0) t_hit = (y - c->arena[2]) / fabs(vy);        /* :48-53 */
+    else if (vy > 0) t_hit = (c->arena[3] - y) / fabs(vy);
+    else t_hit = INFINITY;
+    if (t_hit <= dt) { y += (vy * t_hit - vy * (dt - t_hit)); vy = -vy; } else y += vy * dt;  /* :55-59 */
+    st[0] = x; st[1] = y; st[2] = vx; st[3] = vy;
+}
+
+/* visualization.py:62-79: note :69 `vx = self.vy` (reference defect D1), reproduced when bug_compat_predict */
+void orc_predict_trajectory(const orc_config *c, const double *state, int n, double dt, double *traj)
+{
+    double st[4] = {state[0], state[1], c->bug_compat_predict ? state[3] : state[2], state[3]};
+    traj[0] = st[0]; traj[1] = st[1];
+    for (int i = 0; i < n; i++) {
+        orc_obstacle_step(c, st, dt, NULL, 0.0, 0.0);
+        traj[2 * (i + 1)] = st[0]; traj[2 * (i + 1) + 1] = st[1];
+    }
+}
+
+/* robot_ocp_problem.py:154-166: P[i] = [o0x,o0y,o1x,o1y,...] */
+void orc_predict_params(const orc_config *c, const double *obst, double *P)
+{
+    int N = c->N, no = c->n_obst; double dt = c->Tf / N;
+    double *traj = (double *)malloc(sizeof(double) * 2 * (N + 1));
+    for (int j = 0; j < no; j++) {
+        orc_predict_trajectory(c, obst + 4 * j, N, dt, traj);
+        for (int i = 0; i <= N; i++) { P[(i * no + j) * 2] = traj[2 * i]; P[(i * no + j) * 2 + 1] = traj[2 * i + 1]; }
+    }
+    free(traj);
+}
+
+/* robot_ocp_problem.py:145-152 */
+void orc_slack_alpha(const orc_config *c, const double *x0, const double *goal, double *alpha)
+{
+    double d0 = x0[0] - goal[0], d1 = x0[1] - goal[1];
+    double scale = c->slack_a * (d0 * d0 + d1 * d1 + x0[3] * x0[3] + x0[4] * x0[4] + c->slack_b);
+    for (int i = 0; i <= c->N; i++) alpha[i] = scale * (double)(c->N - i) / (double)c->N;
+}
+
+/* robot_ocp_problem.py:286-306: X[i] = [x0_x, x0_y, x0_psi, 0, 0], U = 0 (the aliasing of :301-302 is the caller's) */
+void orc_initial_guess(const orc_config *c, const double *x0, double *X, double *U)
+{
+    for (int i = 0; i <= c->N; i++) { X[i * 5] = x0[0]; X[i * 5 + 1] = x0[1]; X[i * 5 + 2] = x0[2]; X[i * 5 + 3] = 0; X[i * 5 + 4] = 0; }
+    for (int i = 0; i < c->N * 2; i++) U[i] = 0;
+}
+
+/* robot_ocp_problem.py:253-258 */
+void orc_shift(const orc_config *c, double *X, double *U)
+{
+    int N = c->N;
+    for (int j = 0; j < N - 1; j++) {
+        for (int k = 0; k < 5; k++) X[j * 5 + k] = X[(j + 1) * 5 + k];
+        for (int k = 0; k < 2; k++) U[j * 2 + k] = U[(j + 1) * 2 + k];
+    }
+    for (int k = 0; k < 5; k++) X[(N - 1) * 5 + k] = X[N * 5 + k];
+    U[(N - 1) * 2] = 0; U[(N - 1) * 2 + 1] = 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* OCP pieces                                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+/* robot_model.py:60-65 */
+static void obstacle_h(const orc_config *c, const double *x, const double *p, double *h, double *dh)
+{
+    for (int j = 0; j < c->n_obst; j++) {
+        double ex = x[0] - p[2 * j], ey = x[1] - p[2 * j + 1];
+        h[j] = ex * ex + ey * ey - c->r_safe * c->r_safe;
+        if (dh) { dh[2 * j] = 2 * ex; dh[2 * j + 1] = 2 * ey; }
+    }
+}
+
+static double stage_cs(const orc_config *c) { return c->cost_scale_dt ? c->Tf / c->N : 1.0; }
+static double stage_ss(const orc_config *c) { return c->slack_scale_dt ? c->Tf / c->N : 1.0; }
+static double stage_lm(const orc_config *c) { return c->lm_scaled ? c->lm * c->Tf / c->N : c->lm; }
+
+/*
+ * Gauss-Newton QP blocks: y = [x,y,v,w,ua,ual], W diag -> H diagonal.
+ * z order is [u(2); x(5)].  Hd[7] diagonal of H, q[7] gradient.   robot_ocp_problem.py:59-83
+ */
+static void stage_cost_blocks(const orc_config *c, int i, const double *x, const double *u, const double *goal,
+                              double *Hd, double *q)
+{
+    if (i < c->N) {
+        double cs = stage_cs(c), lm = stage_lm(c);
+        Hd[0] = cs * c->W[4] + lm; Hd[1] = cs * c->W[5] + lm;
+        Hd[2] = cs * c->W[0] + lm; Hd[3] = cs * c->W[1] + lm; Hd[4] = lm; Hd[5] = cs * c->W[2] + lm; Hd[6] = cs * c->W[3] + lm;
+        q[0] = cs * c->W[4] * u[0]; q[1] = cs * c->W[5] * u[1];
+        q[2] = cs * c->W[0] * (x[0] - goal[0]); q[3] = cs * c->W[1] * (x[1] - goal[1]); q[4] = 0.0;
+        q[5] = cs * c->W[2] * x[3]; q[6] = cs * c->W[3] * x[4];
+    } else {
+        double lm = c->lm; /* terminal: unscaled */
+        Hd[0] = Hd[1] = 0; q[0] = q[1] = 0;
+        Hd[2] = c->We[0] + lm; Hd[3] = c->We[1] + lm; Hd[4] = lm; Hd[5] = c->We[2] + lm; Hd[6] = c->We[3] + lm;
+        q[2] = c->We[0] * (x[0] - goal[0]); q[3] = c->We[1] * (x[1] - goal[1]); q[4] = 0.0;
+        q[5] = c->We[2] * x[3]; q[6] = c->We[3] * x[4];
+    }
+}
+
+void orc_linearize(const orc_config *c, const double *x0, const double *P, const double *goal,
+                   const double *X, const double *U,
+                   double *A, double *B, double *b, double *q, double *h, double *dh)
+{
+    (void)x0;
+    int N = c->N, no = c->n_obst; double dt = c->Tf / N; double Hd[7];
+    for (int i = 0; i < N; i++) {
+        double xn[5];
+        orc_dynamics(X + 5 * i, U + 2 * i, dt, xn, A + 25 * i, B + 10 * i);
+        for (int k = 0; k < 5; k++) b[5 * i + k] = xn[k] - X[5 * (i + 1) + k];
+    }
+    for (int i = 0; i <= N; i++) {
+        stage_cost_blocks(c, i, X + 5 * i, i < N ? U + 2 * i : NULL, goal, Hd, q + 7 * i);
+        obstacle_h(c, X + 5 * i, P + 2 * no * i, h + no * i, dh + 2 * no * i);
+    }
+}
+
+double orc_cost(const orc_config *c, const double *x0, const double *P, const double *goal,
+                const double *X, const double *U)
+{
+    int N = c->N, no = c->n_obst; double cs = stage_cs(c), ss = stage_ss(c);
+    double *alpha = (double *)malloc(sizeof(double) * (N + 1));
+    double *h = (double *)malloc(sizeof(double) * no);
+    orc_slack_alpha(c, x0, goal, alpha);
+    double J = 0;
+    for (int i = 0; i <= N; i++) {
+        const double *x = X + 5 * i;
+        double ex = x[0] - goal[0], ey = x[1] - goal[1];
+        if (i < N) {
+            const double *u = U + 2 * i;
+            J += 0.5 * cs * (c->W[0] * ex * ex + c->W[1] * ey * ey + c->W[2] * x[3] * x[3] + c->W[3] * x[4] * x[4]
+                             + c->W[4] * u[0] * u[0] + c->W[5] * u[1] * u[1]);
+        } else {
+            J += 0.5 * (c->We[0] * ex * ex + c->We[1] * ey * ey + c->We[2] * x[3] * x[3] + c->We[3] * x[4] * x[4]);
+        }
+        obstacle_h(c, x, P + 2 * no * i, h, NULL);
+        double sc = (i < N) ? ss : 1.0;
+        for (int j = 0; j < no; j++) {
+            double v = h[j] < 0 ? -h[j] : 0.0;
+            J += sc * alpha[i] * (v + 0.5 * v * v);
+        }
+    }
+    free(alpha); free(h);
+    return J;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Generic OCP-QP + interior point                                                              */
+/* ------------------------------------------------------------------------------------------ */
+/*
+ * Inequality "items".  Every item is rho = c0 + cz' z_i (+ s_j) >= 0 with slack t and multiplier lam.
+ * kind 0: plain row (box or hard obstacle row); kind 1: soft row (has +s_j); kind 2: s_j >= 0.
+ */
+typedef struct {
+    int stage, kind, sidx;   /* sidx: index of the slack variable for kinds 1,2 */
+    double c0, cz[NZ];
+    double lam, t, dlam, dt_, dlam_aff, dt_aff;
+} item_t;
+
+typedef struct {
+    int N, n_items, n_s;
+    double (*Hd)[NZ];      /* diagonal Hessian per stage (z = [u;x]); stage N uses x part */
+    double (*q)[NZ];
+    double (*A)[25], (*B)[10], (*b)[NX];
+    double d0[NX];         /* required dx_0 */
+    item_t *it;
+    double *zs, *Zs;       /* slack penalties per slack variable */
+    int *s_stage;
+} qp_t;
+
+static void qp_free(qp_t *Q)
+{
+    free(Q->Hd); free(Q->q); free(Q->A); free(Q->B); free(Q->b); free(Q->it); free(Q->zs); free(Q->Zs); free(Q->s_stage);
+}
+
+static void add_box(qp_t *Q, int stage, int zidx, double val, double lo, double hi)
+{
+    item_t *e = &Q->it[Q->n_items++];
+    memset(e, 0, sizeof(*e)); e->stage = stage; e->kind = 0; e->cz[zidx] = 1.0; e->c0 = val - lo;
+    e = &Q->it[Q->n_items++];
+    memset(e, 0, sizeof(*e)); e->stage = stage; e->kind = 0; e->cz[zidx] = -1.0; e->c0 = hi - val;
+}
+
+/* Build the QP of one RTI step */
+static void build_qp(const orc_config *c, const double *x0, const double *P, const double *goal,
+                     const double *X, const double *U, qp_t *Q)
+{
+    int N = c->N, no = c->n_obst; double dt = c->Tf / N;
+    Q->N = N;
+    Q->Hd = malloc(sizeof(double[NZ]) * (N + 1)); Q->q = malloc(sizeof(double[NZ]) * (N + 1));
+    Q->A = malloc(sizeof(double[25]) * N); Q->B = malloc(sizeof(double[10]) * N); Q->b = malloc(sizeof(double[NX]) * N);
+    int max_items = (N + 1) * (4 + 8 + 2 * no);
+    Q->it = malloc(sizeof(item_t) * max_items); Q->n_items = 0;
+    Q->zs = malloc(sizeof(double) * (N + 1) * no); Q->Zs = malloc(sizeof(double) * (N + 1) * no);
+    Q->s_stage = malloc(sizeof(int) * (N + 1) * no); Q->n_s = 0;
+    double *alpha = malloc(sizeof(double) * (N + 1));
+    double *h = malloc(sizeof(double) * no), *dh = malloc(sizeof(double) * 2 * no);
+    orc_slack_alpha(c, x0, goal, alpha);
+    for (int k = 0; k < 5; k++) Q->d0[k] = x0[k] - X[k];    /* lbx_0 = ubx_0 = x0, robot_ocp_problem.py:191-192 */
+    for (int i = 0; i < N; i++) {
+        double xn[5];
+        orc_dynamics(X + 5 * i, U + 2 * i, dt, xn, Q->A[i], Q->B[i]);
+        for (int k = 0; k < 5; k++) Q->b[i][k] = xn[k] - X[5 * (i + 1) + k];
+    }
+    for (int i = 0; i <= N; i++) {
+        stage_cost_blocks(c, i, X + 5 * i, i < N ? U + 2 * i : NULL, goal, Q->Hd[i], Q->q[i]);
+        if (i < N) for (int k = 0; k < 2; k++) add_box(Q, i, k, U[2 * i + k], c->bu_lo[k], c->bu_hi[k]);   /* :95-97 */
+        if (i >= 1 && (i < N || c->bx_terminal))                                                         /* :91-93 */
+            for (int k = 0; k < 4; k++) add_box(Q, i, 2 + IDXBX[k], X[5 * i + IDXBX[k]], c->bx_lo[k], c->bx_hi[k]);
+        if (i >= 1) { /* stage 0: x_0 is fixed so its rows are decoupled */
+            obstacle_h(c, X + 5 * i, P + 2 * no * i, h, dh);
+            double sc = (i < N) ? stage_ss(c) : 1.0;
+            for (int j = 0; j < no; j++) {
+                if (c->soft_h) {
+                    double z = sc * alpha[i];
+                    if (!(z > 0.0)) continue;   /* zero penalty: the slack is free, the row is vacuous */
+                    int si = Q->n_s++;
+                    Q->zs[si] = z; Q->Zs[si] = z; Q->s_stage[si] = i;   /* zl = Zl = alpha_i, :149-152 */
+                    item_t *e = &Q->it[Q->n_items++];
+                    memset(e, 0, sizeof(*e)); e->stage = i; e->kind = 1; e->sidx = si; e->c0 = h[j]; e->cz[2] = dh[2 * j]; e->cz[3] = dh[2 * j + 1];
+                    e = &Q->it[Q->n_items++];
+                    memset(e, 0, sizeof(*e)); e->stage = i; e->kind = 2; e->sidx = si; e->c0 = 0.0;
+                } else {
+                    item_t *e = &Q->it[Q->n_items++];
+                    memset(e, 0, sizeof(*e)); e->stage = i; e->kind = 0; e->c0 = h[j]; e->cz[2] = dh[2 * j]; e->cz[3] = dh[2 * j + 1];
+                }
+            }
+        }
+    }
+    free(alpha); free(h); free(dh);
+}
+
+/* dense helpers, row-major */
+static void mat_mul(int m, int k, int n, const double *Aa, const double *Bb, double *C) /* C = A(mxk) B(kxn) */
+{
+    for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) {
+        double s = 0; for (int l = 0; l < k; l++) s += Aa[i * k + l] * Bb[l * n + j];
+        C[i * n + j] = s;
+    }
+}
+
+typedef struct {
+    double (*P)[25];   /* cost-to-go Hessians */
+    double (*p)[NX];
+    double (*K)[10];   /* 2x5 */
+    double (*k)[NU];
+    double (*L)[4];    /* chol of Muu, lower 2x2 */
+    double (*Mxu)[10]; /* 5x2 */
+} ricc_t;
+
+/*
+ * Riccati solve of  min sum 0.5 z'Ht z + g'z  s.t. dx_{i+1} = A dx_i + B du_i + r_i,  dx_0 = e0.
+ * Ht_i = diag(Hd) + Haug_i (7x7 dense), factorised when `factor`; returns z (7 per stage) and
+ * costates pi_i (multiplier of the equation defining x_{i+1}; pi index i+1, pi[0] for the initial condition).
+ */
+static void riccati(const qp_t *Q, double (*Ht)[49], double (*g)[NZ], double (*r)[NX], const double *e0,
+                    ricc_t *R, int factor, double (*z)[NZ], double (*pi)[NX])
+{
+    int N = Q->N;
+    /* terminal */
+    if (factor) for (int a = 0; a < 5; a++) for (int bq = 0; bq < 5; bq++) R->P[N][a * 5 + bq] = Ht[N][(2 + a) * 7 + (2 + bq)];
+    for (int a = 0; a < 5; a++) R->p[N][a] = g[N][2 + a];
+    for (int i = N - 1; i >= 0; i--) {
+        double Wm[35]; /* 5x7: [B A] */
+        for (int a = 0; a < 5; a++) { Wm[a * 7 + 0] = Q->B[i][a * 2]; Wm[a * 7 + 1] = Q->B[i][a * 2 + 1]; for (int bq = 0; bq < 5; bq++) Wm[a * 7 + 2 + bq] = Q->A[i][a * 5 + bq]; }
+        double PW[35], M[49], m[7], Pr[5];
+        mat_mul(5, 5, 7, R->P[i + 1], Wm, PW);
+        if (factor) {
+            for (int a = 0; a < 7; a++) for (int bq = 0; bq < 7; bq++) {
+                double s = Ht[i][a * 7 + bq];
+                for (int l = 0; l < 5; l++) s += Wm[l * 7 + a] * PW[l * 7 + bq];
+                M[a * 7 + bq] = s;
+            }
+            /* Cholesky of Muu */
+            double l00 = sqrt(M[0]), l10 = M[7] / l00, l11 = sqrt(M[8] - l10 * l10);
+            R->L[i][0] = l00; R->L[i][1] = 0; R->L[i][2] = l10; R->L[i][3] = l11;
+            for (int a = 0; a < 5; a++) { R->Mxu[i][a * 2] = M[(2 + a) * 7 + 0]; R->Mxu[i][a * 2 + 1] = M[(2 + a) * 7 + 1]; }
+            /* K = -Muu^{-1} Mux */
+            for (int a = 0; a < 5; a++) {
+                double r0 = M[0 * 7 + 2 + a], r1 = M[1 * 7 + 2 + a];
+                double y0 = r0 / l00, y1 = (r1 - l10 * y0) / l11;
+                double x1 = y1 / l11, x0_ = (y0 - l10 * x1) / l00;
+                R->K[i][0 * 5 + a] = -x0_; R->K[i][1 * 5 + a] = -x1;
+            }
+            /* P_i = Mxx + Mxu K */
+            for (int a = 0; a < 5; a++) for (int bq = 0; bq < 5; bq++)
+                R->P[i][a * 5 + bq] = M[(2 + a) * 7 + 2 + bq] + R->Mxu[i][a * 2] * R->K[i][0 * 5 + bq] + R->Mxu[i][a * 2 + 1] * R->K[i][1 * 5 + bq];
+            /* symmetrise */
+            for (int a = 0; a < 5; a++) for (int bq = a + 1; bq < 5; bq++) { double s = 0.5 * (R->P[i][a * 5 + bq] + R->P[i][bq * 5 + a]); R->P[i][a * 5 + bq] = R->P[i][bq * 5 + a] = s; }
+        }
+        /* m = g_i + W'(P r + p) */
+        for (int a = 0; a < 5; a++) { double s = R->p[i + 1][a]; for (int l = 0; l < 5; l++) s += R->P[i + 1][a * 5 + l] * r[i][l]; Pr[a] = s; }
+        for (int a = 0; a < 7; a++) { double s = g[i][a]; for (int l = 0; l < 5; l++) s += Wm[l * 7 + a] * Pr[l]; m[a] = s; }
+        {
+            double l00 = R->L[i][0], l10 = R->L[i][2], l11 = R->L[i][3];
+            double y0 = m[0] / l00, y1 = (m[1] - l10 * y0) / l11;
+            double x1 = y1 / l11, x0_ = (y0 - l10 * x1) / l00;
+            R->k[i][0] = -x0_; R->k[i][1] = -x1;
+        }
+        for (int a = 0; a < 5; a++) R->p[i][a] = m[2 + a] + R->Mxu[i][a * 2] * R->k[i][0] + R->Mxu[i][a * 2 + 1] * R->k[i][1];
+    }
+    /* forward */
+    double xc[5]; for (int a = 0; a < 5; a++) xc[a] = e0[a];
+    for (int a = 0; a < 5; a++) { double s = R->p[0][a]; for (int l = 0; l < 5; l++) s += R->P[0][a * 5 + l] * xc[l]; pi[0][a] = s; }
+    for (int i = 0; i < N; i++) {
+        double u[2];
+        for (int a = 0; a < 2; a++) { double s = R->k[i][a]; for (int l = 0; l < 5; l++) s += R->K[i][a * 5 + l] * xc[l]; u[a] = s; }
+        z[i][0] = u[0]; z[i][1] = u[1]; for (int a = 0; a < 5; a++) z[i][2 + a] = xc[a];
+        double xn[5];
+        for (int a = 0; a < 5; a++) {
+            double s = r[i][a];
+            for (int l = 0; l < 5; l++) s += Q->A[i][a * 5 + l] * xc[l];
+            s += Q->B[i][a * 2] * u[0] + Q->B[i][a * 2 + 1] * u[1];
+            xn[a] = s;
+        }
+        for (int a = 0; a < 5; a++) xc[a] = xn[a];
+        for (int a = 0; a < 5; a++) { double s = R->p[i + 1][a]; for (int l = 0; l < 5; l++) s += R->P[i + 1][a * 5 + l] * xc[l]; pi[i + 1][a] = s; }
+    }
+    z[N][0] = z[N][1] = 0; for (int a = 0; a < 5; a++) z[N][2 + a] = xc[a];
+}
+
+typedef struct {
+    double (*z)[NZ];   /* primal per stage */
+    double *s;         /* slacks */
+    double (*pi)[NX];  /* pi[0]: initial condition; pi[i+1]: dynamics i */
+} iter_t;
+
+/* explicit KKT residuals; returns inf-norms in res[4] = {stationarity, equality, inequality, complementarity(max lam*t)} */
+static void residuals(const qp_t *Q, iter_t *I, double (*rg)[NZ], double *rs, double (*rb)[NX], double *re0, double *res)
+{
+    int N = Q->N;
+    /* Costates by the adjoint recursion pi_i = (H z + q - C'lam)_x + A_i' pi_{i+1}: any costate is a valid
+     * linearisation point (the Newton target does not depend on it), this choice zeroes the x-blocks of the
+     * stationarity residual exactly and avoids the ill-conditioned products P_i x_i late in the iteration. */
+    for (int i = N; i >= 0; i--) {
+        double acc[5];
+        for (int a = 0; a < 5; a++) acc[a] = Q->Hd[i][2 + a] * I->z[i][2 + a] + Q->q[i][2 + a];
+        for (int e = 0; e < Q->n_items; e++) { const item_t *it = &Q->it[e]; if (it->stage != i) continue; for (int a = 0; a < 5; a++) acc[a] -= it->cz[2 + a] * it->lam; }
+        if (i < N) for (int a = 0; a < 5; a++) { double sacc = 0; for (int l = 0; l < 5; l++) sacc += Q->A[i][l * 5 + a] * I->pi[i + 1][l]; acc[a] += sacc; }
+        for (int a = 0; a < 5; a++) I->pi[i][a] = acc[a];
+    }
+    for (int i = 0; i <= N; i++) {
+        for (int a = 0; a < 7; a++) rg[i][a] = Q->Hd[i][a] * I->z[i][a] + Q->q[i][a];
+        if (i == N) { rg[i][0] = rg[i][1] = 0; }
+        /* + [B' ; A'] pi_{i+1} - [0; pi_i] */
+        if (i < N) {
+            for (int a = 0; a < 2; a++) { double sacc = 0; for (int l = 0; l < 5; l++) sacc += Q->B[i][l * 2 + a] * I->pi[i + 1][l]; rg[i][a] += sacc; }
+            for (int a = 0; a < 5; a++) { double sacc = 0; for (int l = 0; l < 5; l++) sacc += Q->A[i][l * 5 + a] * I->pi[i + 1][l]; rg[i][2 + a] += sacc; }
+        }
+        for (int a = 0; a < 5; a++) rg[i][2 + a] -= I->pi[i][a];
+    }
+    for (int j = 0; j < Q->n_s; j++) rs[j] = Q->Zs[j] * I->s[j] + Q->zs[j];
+    double rd = 0, rm = 0;
+    for (int e = 0; e < Q->n_items; e++) {
+        const item_t *it = &Q->it[e];
+        double rho = it->c0;
+        for (int a = 0; a < 7; a++) { rho += it->cz[a] * I->z[it->stage][a]; rg[it->stage][a] -= it->cz[a] * it->lam; }
+        if (it->kind == 1 || it->kind == 2) { rho += I->s[it->sidx]; rs[it->sidx] -= it->lam; }
+        double d = fabs(rho - it->t); if (d > rd) rd = d;
+        /* a pair whose t (or lam) sits at the floor is numerically active (inactive): t below ~1e-13 is under the
+         * rounding resolution of rho = c0 + c'z, so its product no longer measures distance from the solution */
+        double mm = (it->t <= 2 * TL_MIN || it->lam <= 2 * TL_MIN) ? 0.0 : fabs(it->lam * it->t); if (mm > rm) rm = mm;
+    }
+    double ng = 0, nb = 0;
+    for (int i = 0; i <= N; i++) for (int a = 0; a < 7; a++) { if (i == 0 && a >= 2) continue; /* x_0 is fixed: its multiplier pi_0 absorbs this block */ double v = fabs(rg[i][a]); if (v > ng) ng = v; }
+    for (int j = 0; j < Q->n_s; j++) { double v = fabs(rs[j]); if (v > ng) ng = v; }
+    for (int a = 0; a < 5; a++) { re0[a] = Q->d0[a] - I->z[0][2 + a]; double v = fabs(re0[a]); if (v > nb) nb = v; }
+    for (int i = 0; i < N; i++) for (int a = 0; a < 5; a++) {
+        double sacc = Q->b[i][a] - I->z[i + 1][2 + a];
+        for (int l = 0; l < 5; l++) sacc += Q->A[i][a * 5 + l] * I->z[i][2 + l];
+        sacc += Q->B[i][a * 2] * I->z[i][0] + Q->B[i][a * 2 + 1] * I->z[i][1];
+        rb[i][a] = sacc; double v = fabs(sacc); if (v > nb) nb = v;
+    }
+    res[0] = ng; res[1] = nb; res[2] = rd; res[3] = rm;
+}
+
+/*
+ * Mehrotra predictor-corrector primal-dual IPM, cold-started, single step length for primal and dual,
+ * Riccati factorisation of the reduced KKT system [acados-knowledge: this is the structure of HPIPM's
+ * OCP-QP solver, which robot_ocp_problem.py:126 selects; tolerance/caps are ours].
+ * Returns 0 converged, 2 max-iter, 4 failure (NaN / step collapse).
+ */
+static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, double *kkt)
+{
+    int N = Q->N, ni = Q->n_items, ns = Q->n_s;
+    double (*rg)[NZ] = malloc(sizeof(double[NZ]) * (N + 1));
+    double (*rb)[NX] = malloc(sizeof(double[NX]) * (N + 1));
+    double *rs = malloc(sizeof(double) * (ns + 1));
+    double (*Ht)[49] = malloc(sizeof(double[49]) * (N + 1));
+    double (*gt)[NZ] = malloc(sizeof(double[NZ]) * (N + 1));
+    double (*dz)[NZ] = malloc(sizeof(double[NZ]) * (N + 1));
+    double (*dpi)[NX] = malloc(sizeof(double[NX]) * (N + 1));
+    double *ds = malloc(sizeof(double) * (ns + 1)), *yds = malloc(sizeof(double) * (ns + 1));
+    double *w1 = malloc(sizeof(double) * (ns + 1)), *w2 = malloc(sizeof(double) * (ns + 1));
+    double *be1 = malloc(sizeof(double) * (ns + 1)), *be2 = malloc(sizeof(double) * (ns + 1));
+    int *soft_row = malloc(sizeof(int) * (ns + 1)), *soft_pos = malloc(sizeof(int) * (ns + 1));
+    ricc_t R;
+    R.P = malloc(sizeof(double[25]) * (N + 1)); R.p = malloc(sizeof(double[NX]) * (N + 1));
+    R.K = malloc(sizeof(double[10]) * N); R.k = malloc(sizeof(double[NU]) * N); R.L = malloc(sizeof(double[4]) * N); R.Mxu = malloc(sizeof(double[10]) * N);
+    double re0[5], res[4];
+    int status = 2, it = 0;
+
+    for (int e = 0; e < ni; e++) { if (Q->it[e].kind == 1) soft_row[Q->it[e].sidx] = e; if (Q->it[e].kind == 2) soft_pos[Q->it[e].sidx] = e; }
+
+    /* cold start: z = 0, s = 0, pi = 0, t = max(rho, thr0), lam = mu0 / t */
+    for (int i = 0; i <= N; i++) { memset(I->z[i], 0, sizeof(double[NZ])); memset(I->pi[i], 0, sizeof(double[NX])); }
+    /* soft rows start strictly feasible: s = max(0, -h) + thr0, so rho1 = h + s >= thr0 and rho2 = s >= thr0 */
+    for (int j = 0; j < ns; j++) { double h = Q->it[soft_row[j]].c0; I->s[j] = (h < 0 ? -h : 0.0) + c->thr0; }
+    for (int e = 0; e < ni; e++) {
+        item_t *q = &Q->it[e];
+        double rho = q->c0 + (q->kind ? I->s[q->sidx] : 0.0);
+        q->t = rho > c->thr0 ? rho : c->thr0; q->lam = c->mu0 / q->t;
+    }
+
+    for (it = 0; ; it++) {
+        residuals(Q, I, rg, rs, rb, re0, res);
+        double mu = 0; for (int e = 0; e < ni; e++) mu += Q->it[e].lam * Q->it[e].t; mu = ni ? mu / ni : 0.0;
+        if (!(res[0] == res[0]) || !(res[1] == res[1]) || !(mu == mu)) { status = 4; break; }
+        /* Termination (shared spec with the HIP kernel): linear residuals (dynamics, initial condition, rho - t; they
+         * all decay by the same factor prod(1 - alpha_k)) and the largest complementarity product below qp_tol.
+         * The stationarity residual res[0] is REPORTED, not gated: late in the iteration its rounding floor is
+         * ~ eps * lam^2 |z| / mu for active rows (multiplier accuracy), while the primal point is unaffected. */
+        if (res[1] <= c->qp_tol && res[2] <= c->qp_tol && res[3] <= c->qp_tol) { status = 0; break; }
+        if (it >= c->qp_iter_max) { status = 2; break; }
+
+        double sigma = 0.0; double alpha = 1.0;
+        for (int pass = 0; pass < 2; pass++) {
+            /* reduced Hessian / gradient */
+            for (int i = 0; i <= N; i++) {
+                memset(Ht[i], 0, sizeof(double[49]));
+                for (int a = 0; a < 7; a++) { Ht[i][a * 7 + a] = Q->Hd[i][a]; gt[i][a] = rg[i][a]; }
+                if (i == N) { Ht[i][0] = Ht[i][8] = 1.0; gt[i][0] = gt[i][1] = 0; }
+            }
+            for (int e = 0; e < ni; e++) {
+                item_t *q = &Q->it[e];
+                double rd = q->c0; for (int a = 0; a < 7; a++) rd += q->cz[a] * I->z[q->stage][a];
+                if (q->kind) rd += I->s[q->sidx];
+                rd -= q->t;
+                double rm = q->lam * q->t - sigma * mu;
+                if (pass == 1) rm += q->dlam_aff * q->dt_aff;
+                double w = q->lam / q->t, beta = (rm + q->lam * rd) / q->t;
+                if (q->kind == 0) {
+                    for (int a = 0; a < 7; a++) { if (q->cz[a] == 0.0) continue; gt[q->stage][a] += q->cz[a] * beta; for (int bq = 0; bq < 7; bq++) Ht[q->stage][a * 7 + bq] += w * q->cz[a] * q->cz[bq]; }
+                } else if (q->kind == 1) { w1[q->sidx] = w; be1[q->sidx] = beta; }
+                else { w2[q->sidx] = w; be2[q->sidx] = beta; }
+            }
+            for (int j = 0; j < ns; j++) {
+                item_t *q = &Q->it[soft_row[j]];
+                double D = Q->Zs[j] + w1[j] + w2[j];
+                /* cancellation-free forms of w1 - w1^2/D and be1 - w1 (rs + be1 + be2)/D */
+                double weff = w1[j] * (Q->Zs[j] + w2[j]) / D;
+                double geff = (be1[j] * (Q->Zs[j] + w2[j]) - w1[j] * (rs[j] + be2[j])) / D;
+                for (int a = 0; a < 7; a++) { if (q->cz[a] == 0.0) continue; gt[q->stage][a] += q->cz[a] * geff; for (int bq = 0; bq < 7; bq++) Ht[q->stage][a * 7 + bq] += weff * q->cz[a] * q->cz[bq]; }
+            }
+            riccati(Q, Ht, gt, rb, re0, &R, pass == 0, dz, dpi);
+            /* recover ds, dt, dlam */
+            for (int j = 0; j < ns; j++) {
+                item_t *q = &Q->it[soft_row[j]];
+                double y = 0; for (int a = 0; a < 7; a++) y += q->cz[a] * dz[q->stage][a];
+                double D = Q->Zs[j] + w1[j] + w2[j];
+                ds[j] = -(rs[j] + be1[j] + be2[j] + w1[j] * y) / D;
+                /* y + ds without the cancellation it suffers when w1 >> Z + w2 (active row late in the iteration) */
+                yds[j] = (y * (Q->Zs[j] + w2[j]) - (rs[j] + be1[j] + be2[j])) / D;
+            }
+            double amax = 1.0;
+            for (int e = 0; e < ni; e++) {
+                item_t *q = &Q->it[e];
+                double rd = q->c0; for (int a = 0; a < 7; a++) rd += q->cz[a] * I->z[q->stage][a];
+                if (q->kind) rd += I->s[q->sidx];
+                rd -= q->t;
+                double dt_ = rd;
+                if (q->kind == 1) dt_ += yds[q->sidx];
+                else { for (int a = 0; a < 7; a++) dt_ += q->cz[a] * dz[q->stage][a]; if (q->kind == 2) dt_ += ds[q->sidx]; }
+                double rm = q->lam * q->t - sigma * mu; if (pass == 1) rm += q->dlam_aff * q->dt_aff;
+                double dl = -(rm + q->lam * dt_) / q->t;
+                q->dt_ = dt_; q->dlam = dl;
+                if (dt_ < 0) { double a_ = -q->t / dt_; if (a_ < amax) amax = a_; }
+                if (dl < 0) { double a_ = -q->lam / dl; if (a_ < amax) amax = a_; }
+            }
+            if (pass == 0) {
+                double mu_aff = 0;
+                for (int e = 0; e < ni; e++) { item_t *q = &Q->it[e]; mu_aff += (q->lam + amax * q->dlam) * (q->t + amax * q->dt_); q->dlam_aff = q->dlam; q->dt_aff = q->dt_; }
+                mu_aff = ni ? mu_aff / ni : 0.0;
+                double ratio = mu > 0 ? mu_aff / mu : 0.0;
+                sigma = ratio * ratio * ratio;
+                if (sigma > 1.0) sigma = 1.0;
+                if (ni == 0) { alpha = 1.0; break; }
+            } else {
+                alpha = 0.995 * amax; if (amax >= 1.0) alpha = 1.0; if (alpha > 1.0) alpha = 1.0;
+            }
+        }
+        if (!(alpha > 1e-14)) { status = 4; break; }
+        for (int i = 0; i <= N; i++) { for (int a = 0; a < 7; a++) I->z[i][a] += alpha * dz[i][a]; }
+        for (int j = 0; j < ns; j++) I->s[j] += alpha * ds[j];
+        for (int e = 0; e < ni; e++) {
+            item_t *q = &Q->it[e]; q->t += alpha * q->dt_; q->lam += alpha * q->dlam;
+            if (q->t < TL_MIN) q->t = TL_MIN;      /* floors as in HPIPM's t_min / lam_min [acados-knowledge]: keep */
+            if (q->lam < TL_MIN) q->lam = TL_MIN;  /* lam/t finite once a pair has collapsed below rounding        */
+        }
+    }
+    if (iters_out) *iters_out = it;
+    if (kkt) for (int a = 0; a < 4; a++) kkt[a] = res[a];
+    free(rg); free(rb); free(rs); free(Ht); free(gt); free(dz); free(dpi); free(ds); free(yds); free(w1); free(w2); free(be1); free(be2); free(soft_row); free(soft_pos);
+    free(R.P); free(R.p); free(R.K); free(R.k); free(R.L); free(R.Mxu);
+    return status;
+}
+
+/* robot_ocp_problem.py:186-198 around ocp_solver.solve(): one SQP_RTI iteration = QP + full step */
+int orc_rti_solve(const orc_config *c, const double *x0, const double *P, const double *goal,
+                  double *X, double *U, double *u0, double *cost, int *iters, double *kkt)
+{
+    int N = c->N;
+    qp_t Q; build_qp(c, x0, P, goal, X, U, &Q);
+    iter_t I;
+    I.z = malloc(sizeof(double[NZ]) * (N + 1)); I.pi = malloc(sizeof(double[NX]) * (N + 1)); I.s = malloc(sizeof(double) * (Q.n_s + 1));
+    int status = ipm_solve(c, &Q, &I, iters, kkt);
+    if (status != 4) { /* full step; a max-iter QP still has its step applied (3.2-6) */
+        for (int i = 0; i <= N; i++) for (int k = 0; k < 5; k++) X[5 * i + k] += I.z[i][2 + k];
+        for (int i = 0; i < N; i++) for (int k = 0; k < 2; k++) U[2 * i + k] += I.z[i][k];
+    }
+    if (u0) { u0[0] = U[0]; u0[1] = U[1]; }
+    if (cost) *cost = orc_cost(c, x0, P, goal, X, U);
+    free(I.z); free(I.pi); free(I.s); qp_free(&Q);
+    return status;
+}
+
+void orc_rti_solve_batch(const orc_config *c, int batch, const double *x0, const double *P, const double *goal,
+                         double *X, double *U, double *u0, double *cost, int *status, int *iters, int nthreads)
+{
+    int N = c->N, no = c->n_obst;
+    size_t sP = (size_t)(N + 1) * no * 2, sX = (size_t)(N + 1) * 5, sU = (size_t)N * 2;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 8)
+#endif
+    for (int b = 0; b < batch; b++) {
+        int it = 0;
+        int st = orc_rti_solve(c, x0 + 5 * (size_t)b, P + sP * b, goal + 2 * (size_t)b, X + sX * b, U + sU * b,
+                               u0 ? u0 + 2 * (size_t)b : NULL, cost ? cost + b : NULL, &it, NULL);
+        if (status) status[b] = st;
+        if (iters) iters[b] = it;
+    }
+    (void)nthreads;
+}
+
+int orc_export_qp(const orc_config *c, const double *x0, const double *P, const double *goal,
+                  const double *X, const double *U,
+                  double *H, double *g, double *Aeq, double *beq, double *lb, double *ub,
+                  double *Cs, double *hs, double *zs, double *Zs)
+{
+    int N = c->N; int nv = 7 * N;
+    qp_t Q; build_qp(c, x0, P, goal, X, U, &Q);
+    /* variable map: du_i -> 7i + {0,1} ; dx_i (i>=1) -> 7(i-1) + 2 + k */
+    memset(H, 0, sizeof(double) * nv * nv); memset(g, 0, sizeof(double) * nv);
+    memset(Aeq, 0, sizeof(double) * 5 * N * nv); memset(beq, 0, sizeof(double) * 5 * N);
+    for (int v = 0; v < nv; v++) { lb[v] = -INFINITY; ub[v] = INFINITY; }
+    for (int i = 0; i < N; i++) for (int k = 0; k < 2; k++) { int v = 7 * i + k; H[v * nv + v] = Q.Hd[i][k]; g[v] = Q.q[i][k]; }
+    for (int i = 1; i <= N; i++) for (int k = 0; k < 5; k++) { int v = 7 * (i - 1) + 2 + k; H[v * nv + v] = Q.Hd[i][2 + k]; g[v] = Q.q[i][2 + k]; }
+    /* dynamics rows: dx_{i+1} - A dx_i - B du_i = b_i  (dx_0 = d0 moved to rhs) */
+    for (int i = 0; i < N; i++) for (int a = 0; a < 5; a++) {
+        int r = 5 * i + a; double rhs = Q.b[i][a];
+        Aeq[r * nv + 7 * i + 2 + a] = 1.0;
+        for (int k = 0; k < 2; k++) Aeq[r * nv + 7 * i + k] = -Q.B[i][a * 2 + k];
+        for (int l = 0; l < 5; l++) {
+            if (i == 0) rhs += Q.A[i][a * 5 + l] * Q.d0[l];
+            else Aeq[r * nv + 7 * (i - 1) + 2 + l] = -Q.A[i][a * 5 + l];
+        }
+        beq[r] = rhs;
+    }
+    int ns = 0;
+    for (int e = 0; e < Q.n_items; e++) {
+        item_t *it = &Q.it[e];
+        if (it->kind == 0) {
+            int nnz = 0, idx = -1; for (int a = 0; a < 7; a++) if (it->cz[a] != 0.0) { nnz++; idx = a; }
+            int v = (idx < 2) ? 7 * it->stage + idx : 7 * (it->stage - 1) + idx;
+            if (nnz == 1 && it->cz[idx] == 1.0) lb[v] = -it->c0;       /* z - (lo - val) >= 0 */
+            else if (nnz == 1 && it->cz[idx] == -1.0) ub[v] = it->c0;
+            else { /* hard obstacle row: export as a soft row with infinite penalty marker */
+                memset(Cs + (size_t)ns * nv, 0, sizeof(double) * nv);
+                for (int a = 2; a < 7; a++) Cs[(size_t)ns * nv + 7 * (it->stage - 1) + a] = it->cz[a];
+                hs[ns] = it->c0; zs[ns] = INFINITY; Zs[ns] = INFINITY; ns++;
+            }
+        } else if (it->kind == 1) {
+            memset(Cs + (size_t)ns * nv, 0, sizeof(double) * nv);
+            for (int a = 2; a < 7; a++) Cs[(size_t)ns * nv + 7 * (it->stage - 1) + a] = it->cz[a];
+            hs[ns] = it->c0; zs[ns] = Q.zs[it->sidx]; Zs[ns] = Q.Zs[it->sidx]; ns++;
+        }
+    }
+    qp_free(&Q);
+    return ns;
+}

@@ -1,0 +1,124 @@
+/*
+ * mpc_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C float64 restatement of the reference's per-control-step MPC solve
+ * ("linearise horizon -> build QP -> solve QP -> full step", i.e. one acados
+ * SQP_RTI iteration) for abdelhakim96/Dynamic-Obstacle-Avoidance-MPC.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * call into this library.  The product (libmpcgpu.so) never links or loads it.
+ *
+ * PARITY UNPINNED for the solve outputs: the reference's arithmetic lives in
+ * acados / HPIPM / BLASFEO / CasADi (un-vendored, un-pinned, absent from
+ * /root/reference and from this image), and the reference holds no tests or
+ * golden vectors for (X+, U+, u*).  The oracle restates the mathematical
+ * problem the reference's own files define; it is pinned only where the
+ * reference is importable (obstacle predictor / scenario generator / constants,
+ * tests/golden/) and by solver-independent checks (GL4 collocation identity,
+ * finite differences, scipy on the assembled QP, explicit KKT residuals).
+ *
+ * Reference lines each function follows are cited at its definition in
+ * mpc_oracle.c (paths relative to /root/reference).
+ */
+#ifndef MPC_ORACLE_H
+#define MPC_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_NX 5
+#define ORC_NU 2
+#define ORC_NZ 7
+
+typedef struct orc_config {
+    int N;              /* horizon intervals: N_SOLV, world_specification.py:44            */
+    int n_obst;         /* N_OBST, world_specification.py:25                               */
+    double Tf;          /* TF, world_specification.py:43 (dt = Tf/N)                       */
+    double W[6];        /* diag(W) for y=[x,y,v,w,ua,ualpha], robot_ocp_problem.py:24-26,78-80 */
+    double We[4];       /* diag(W_e) for y_e=[x,y,v,w], robot_ocp_problem.py:27,83         */
+    double lm;          /* levenberg_marquardt, robot_ocp_problem.py:128                   */
+    double bx_lo[4];    /* lbx on idx [0,1,3,4], robot_ocp_problem.py:91-93                */
+    double bx_hi[4];
+    double bu_lo[2];    /* lbu/ubu, robot_ocp_problem.py:95-97                             */
+    double bu_hi[2];
+    double r_safe;      /* R_OBST+R_ROBOT+MARGIN, robot_model.py:62                        */
+    double slack_a;     /* 1e4, robot_ocp_problem.py:146                                   */
+    double slack_b;     /* 50,  robot_ocp_problem.py:146                                   */
+    int qp_iter_max;    /* QP_ITER, robot_ocp_problem.py:131                               */
+    double qp_tol;      /* IPM tolerance (residuals and complementarity)                   */
+    /* acados-semantics switches, SURVEY.md 8(c) (defaults = 2022-era acados)            */
+    int cost_scale_dt;  /* stage cost multiplied by dt                                     */
+    int slack_scale_dt; /* slack penalties z,Z multiplied by dt for stages < N             */
+    int lm_scaled;      /* LM term multiplied by dt (newer acados); default 0              */
+    int bx_terminal;    /* path box also on stage N; default 0                             */
+    int soft_h;         /* obstacle rows softened (slack=True), robot_ocp_problem.py:106   */
+    /* obstacle world, world_specification.py:7-10 and visualization.py:62-79            */
+    double arena[4];    /* X_MIN, X_MAX, Y_MIN, Y_MAX                                      */
+    int bug_compat_predict; /* predict_trajectory uses vx = self.vy, visualization.py:69   */
+    /* interior-point start (cold start every call, as HPIPM with warm_start=0)          */
+    double mu0;
+    double thr0;
+} orc_config;
+
+void orc_default_config(orc_config *c, int N, int n_obst, double Tf);
+
+/* a1/a14: unicycle step, closed form of IRK Gauss-Legendre(4 stages, 1 step). A 5x5, B 5x2 row-major, may be NULL */
+void orc_dynamics(const double *x, const double *u, double dt, double *xn, double *A, double *B);
+/* general GL4 collocation with Newton on the stage equations + IFT sensitivities (identity check only) */
+void orc_dynamics_collocation(const double *x, const double *u, double dt, int newton_iter,
+                              double *xn, double *A, double *B);
+/* robot_model.py:39-43 */
+void orc_ode(const double *x, const double *u, double *xdot);
+
+/* a9: visualization.py:25-60 (noise = NULL -> deterministic; else 2 standard normals, randomness, vmax) */
+void orc_obstacle_step(const orc_config *c, double *state /*x,y,vx,vy*/, double dt,
+                       const double *noise, double randomness, double vmax);
+/* a9: visualization.py:62-79 -> traj[(n+1)*2] */
+void orc_predict_trajectory(const orc_config *c, const double *state, int n, double dt, double *traj);
+/* a8: P[(N+1)*n_obst*2] from obst[n_obst*4] */
+void orc_predict_params(const orc_config *c, const double *obst, double *P);
+
+/* a7: robot_ocp_problem.py:145-152 */
+void orc_slack_alpha(const orc_config *c, const double *x0, const double *goal, double *alpha);
+
+/* a13 / a12 */
+void orc_initial_guess(const orc_config *c, const double *x0, double *X, double *U);
+void orc_shift(const orc_config *c, double *X, double *U);
+
+/* linearisation products, for parity tests of the linearise stage:
+ * A[N*25], B[N*10], b[N*5], q[(N+1)*7] (order u,x; last stage x only in slots 2..6),
+ * h[(N+1)*n_obst], dh[(N+1)*n_obst*2] */
+void orc_linearize(const orc_config *c, const double *x0, const double *P, const double *goal,
+                   const double *X, const double *U,
+                   double *A, double *B, double *b, double *q, double *h, double *dh);
+
+/* NLP objective at (X,U): LS cost + exact penalty of obstacle violation (north_star "per-scenario cost") */
+double orc_cost(const orc_config *c, const double *x0, const double *P, const double *goal,
+                const double *X, const double *U);
+
+/* a10/a11: one RTI step.  X,U updated in place.  status: 0 ok, 2 max-iter (step applied), 4 QP failure (no step).
+ * kkt[4] (optional): final inf-norm residuals {stationarity, equality, inequality, complementarity}. */
+int orc_rti_solve(const orc_config *c, const double *x0, const double *P, const double *goal,
+                  double *X, double *U, double *u0, double *cost, int *iters, double *kkt);
+
+/* batched driver (OpenMP over instances); arrays are [batch][...] contiguous. */
+void orc_rti_solve_batch(const orc_config *c, int batch, const double *x0, const double *P, const double *goal,
+                         double *X, double *U, double *u0, double *cost, int *status, int *iters,
+                         int nthreads);
+
+/* Assembled QP of one RTI step in dense form for cross-checking with scipy.
+ * Variables v = [du_0, dx_1, du_1, ..., dx_N] (dx_0 eliminated), nv = 7N.
+ *   min 0.5 v'Hv + g'v + sum_j (zs_j s_j + 0.5 Zs_j s_j^2)
+ *   s.t. Aeq v = beq;  lb <= v <= ub;  Cs v + hs + s >= 0, s >= 0   (ns soft rows)
+ * Returns ns. Arrays sized by caller: H[nv*nv], g[nv], Aeq[(5N)*nv], beq[5N], lb[nv], ub[nv],
+ * Cs[ns_max*nv], hs[ns_max], zs[ns_max], Zs[ns_max] with ns_max = N*n_obst. */
+int orc_export_qp(const orc_config *c, const double *x0, const double *P, const double *goal,
+                  const double *X, const double *U,
+                  double *H, double *g, double *Aeq, double *beq, double *lb, double *ub,
+                  double *Cs, double *hs, double *zs, double *Zs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
