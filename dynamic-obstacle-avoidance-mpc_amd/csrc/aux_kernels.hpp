@@ -1,0 +1,156 @@
+// aux_kernels.hpp -- the small kernels either side of the solve: obstacle look-ahead (a9), warm-start shift (a12),
+// initial guess (a13), plant step (a14), ground-truth obstacle motion and a dense dump of the linearisation for tests.
+// File:line citations are relative to the reference repository root.
+#pragma once
+#include "rti_kernel.hpp"
+
+namespace mpc {
+
+struct World {
+    double xmin, xmax, ymin, ymax;
+    int bug_compat_predict;
+};
+
+// One constant-velocity step with wall reflection, src/utils/visualization.py:35-59.  Written with explicit IEEE
+// add/mul/div (no FMA contraction) in the reference's own operation order so the look-ahead is bit-exact against numpy.
+__device__ __forceinline__ void obstacle_advance(const World w, double dt, double &x, double &vx, double &y, double &vy)
+{
+    double t_hit;
+    if (vx < 0) t_hit = __ddiv_rn(__dsub_rn(x, w.xmin), fabs(vx));
+    else if (vx > 0) t_hit = __ddiv_rn(__dsub_rn(w.xmax, x), fabs(vx));
+    else t_hit = INFINITY;
+    if (t_hit <= dt) { x = __dadd_rn(x, __dsub_rn(__dmul_rn(vx, t_hit), __dmul_rn(vx, __dsub_rn(dt, t_hit)))); vx = -vx; }
+    else x = __dadd_rn(x, __dmul_rn(vx, dt));
+    if (vy < 0) t_hit = __ddiv_rn(__dsub_rn(y, w.ymin), fabs(vy));
+    else if (vy > 0) t_hit = __ddiv_rn(__dsub_rn(w.ymax, y), fabs(vy));
+    else t_hit = INFINITY;
+    if (t_hit <= dt) { y = __dadd_rn(y, __dsub_rn(__dmul_rn(vy, t_hit), __dmul_rn(vy, __dsub_rn(dt, t_hit)))); vy = -vy; }
+    else y = __dadd_rn(y, __dmul_rn(vy, dt));
+}
+
+// Obstacle.predict_trajectory (visualization.py:62-79) for every obstacle of every instance, written straight into the
+// parameter tensor P[B][N+1][n_obst][2] (parameterize_model, robot_ocp_problem.py:154-166).  One thread per obstacle.
+__global__ void predict_kernel(World w, int count, int n_obst, int N, double dt, const double *__restrict__ obst, double *__restrict__ P)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const int inst = t / n_obst, j = t - inst * n_obst;
+    const double *o = obst + (size_t)t * 4;
+    double x = o[0], y = o[1], vy = o[3];
+    double vx = w.bug_compat_predict ? o[3] : o[2];   // visualization.py:69 (reference defect D1)
+    double *Pi = P + ((size_t)inst * (N + 1) * n_obst + j) * 2;
+    Pi[0] = x; Pi[1] = y;
+    for (int i = 1; i <= N; i++) {
+        obstacle_advance(w, dt, x, vx, y, vy);
+        Pi[(size_t)i * n_obst * 2] = x; Pi[(size_t)i * n_obst * 2 + 1] = y;
+    }
+}
+
+// Obstacle.step(): ground-truth motion with optional multiplicative velocity noise, visualization.py:20-33.
+__global__ void obstacle_step_kernel(World w, int count, double dt, double *__restrict__ obst, const double *__restrict__ noise,
+                                     double randomness, double vmax)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    double *o = obst + (size_t)t * 4;
+    double x = o[0], y = o[1], vx = o[2], vy = o[3];
+    if (noise) {
+        const double nx = noise[(size_t)t * 2], ny = noise[(size_t)t * 2 + 1];
+        vx = fmin(fmax(__dmul_rn(__dadd_rn(1.0, __dmul_rn(randomness, nx)), vx), -vmax), vmax);
+        vy = fmin(fmax(__dmul_rn(__dadd_rn(1.0, __dmul_rn(randomness, ny)), vy), -vmax), vmax);
+    }
+    obstacle_advance(w, dt, x, vx, y, vy);
+    o[0] = x; o[1] = y; o[2] = vx; o[3] = vy;
+}
+
+// Warm-start shift, robot_ocp_problem.py:253-258: X[j] <- X[j+1] (j < N), U[j] <- U[j+1] (j < N-1), U[N-1] <- 0.
+// One wavefront per instance; every lane reads its successor stage before anyone writes.
+__global__ __launch_bounds__(64) void shift_kernel(int batch, int N, double *__restrict__ X, double *__restrict__ U)
+{
+    const int inst = blockIdx.x;
+    if (inst >= batch) return;
+    const int i = threadIdx.x;
+    double *Xg = X + (size_t)inst * (N + 1) * 5, *Ug = U + (size_t)inst * N * 2;
+    double xv[5] = {0, 0, 0, 0, 0}, uv[2] = {0, 0};
+    if (i < N) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) xv[c] = Xg[(i + 1) * 5 + c];
+    }
+    if (i < N - 1) { uv[0] = Ug[(i + 1) * 2]; uv[1] = Ug[(i + 1) * 2 + 1]; }
+    __syncthreads();
+    if (i < N) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) Xg[i * 5 + c] = xv[c];
+        Ug[i * 2] = uv[0]; Ug[i * 2 + 1] = uv[1];
+    }
+}
+
+// set_initial_guess, robot_ocp_problem.py:286-306: X[i] = [x0_x, x0_y, x0_psi, 0, 0], U = 0.
+__global__ void reset_guess_kernel(int batch, int N, const double *__restrict__ x0, double *__restrict__ X, double *__restrict__ U)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * (N + 1)) return;
+    const int inst = t / (N + 1), i = t - inst * (N + 1);
+    const double *x = x0 + (size_t)inst * 5;
+    double *Xi = X + (size_t)t * 5;
+    Xi[0] = x[0]; Xi[1] = x[1]; Xi[2] = x[2]; Xi[3] = 0.0; Xi[4] = 0.0;
+    if (i < N) { double *Ui = U + ((size_t)inst * N + i) * 2; Ui[0] = 0.0; Ui[1] = 0.0; }
+}
+
+// Plant integrator, robot_ocp_problem.py:207-212.
+__global__ void plant_step_kernel(int batch, double dt, const double *__restrict__ x, const double *__restrict__ u, double *__restrict__ xn)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch) return;
+    double xi[5], ui[2], xo[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) xi[c] = x[(size_t)t * 5 + c];
+    ui[0] = u[(size_t)t * 2]; ui[1] = u[(size_t)t * 2 + 1];
+    dyn_step<false>(xi, ui, dt, xo, nullptr, nullptr);
+#pragma unroll
+    for (int c = 0; c < 5; c++) xn[(size_t)t * 5 + c] = xo[c];
+}
+
+// Dense dump of the linearisation of the iterate (tests only): same device functions the solve kernel uses.
+__global__ void linearize_kernel(KParams p, int n_obst, const double *__restrict__ Xin, const double *__restrict__ Uin,
+                                 double *__restrict__ A, double *__restrict__ B, double *__restrict__ b, double *__restrict__ q,
+                                 double *__restrict__ hval, double *__restrict__ dh)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = p.N;
+    if (t >= p.batch * (N + 1)) return;
+    const int inst = t / (N + 1), i = t - inst * (N + 1);
+    const double *Xg = Xin + (size_t)inst * (N + 1) * 5, *Ug = Uin + (size_t)inst * N * 2;
+    double xi[5], ui[2] = {0, 0};
+#pragma unroll
+    for (int c = 0; c < 5; c++) xi[c] = Xg[i * 5 + c];
+    const double gx = p.goal[(size_t)inst * 2], gy = p.goal[(size_t)inst * 2 + 1];
+    double *qo = q + (size_t)t * 7;
+    if (i < N) {
+        ui[0] = Ug[i * 2]; ui[1] = Ug[i * 2 + 1];
+        double xn[5], ae[6], be[4];
+        dyn_step<true>(xi, ui, p.dt, xn, ae, be);
+        double *Ao = A + ((size_t)inst * N + i) * 25, *Bo = B + ((size_t)inst * N + i) * 10, *bo = b + ((size_t)inst * N + i) * 5;
+        for (int c = 0; c < 25; c++) Ao[c] = 0.0;
+        for (int c = 0; c < 10; c++) Bo[c] = 0.0;
+        for (int c = 0; c < 5; c++) { Ao[c * 5 + c] = 1.0; bo[c] = xn[c] - Xg[(i + 1) * 5 + c]; }
+        Ao[0 * 5 + 2] = ae[0]; Ao[0 * 5 + 3] = ae[1]; Ao[0 * 5 + 4] = ae[2];
+        Ao[1 * 5 + 2] = ae[3]; Ao[1 * 5 + 3] = ae[4]; Ao[1 * 5 + 4] = ae[5];
+        Ao[2 * 5 + 4] = p.dt;
+        Bo[0] = be[0]; Bo[1] = be[1]; Bo[2] = be[2]; Bo[3] = be[3];
+        Bo[2 * 2 + 1] = p.h2; Bo[3 * 2 + 0] = p.dt; Bo[4 * 2 + 1] = p.dt;
+        qo[0] = p.Wg[4] * ui[0]; qo[1] = p.Wg[5] * ui[1];
+        qo[2] = p.Wg[0] * (xi[0] - gx); qo[3] = p.Wg[1] * (xi[1] - gy); qo[4] = 0.0; qo[5] = p.Wg[2] * xi[3]; qo[6] = p.Wg[3] * xi[4];
+    } else {
+        qo[0] = qo[1] = 0.0;
+        qo[2] = p.Weg[0] * (xi[0] - gx); qo[3] = p.Weg[1] * (xi[1] - gy); qo[4] = 0.0; qo[5] = p.Weg[2] * xi[3]; qo[6] = p.Weg[3] * xi[4];
+    }
+    const double *Pg = p.P + (size_t)t * n_obst * 2;
+    for (int j = 0; j < n_obst; j++) {
+        const double ex = xi[0] - Pg[2 * j], ey = xi[1] - Pg[2 * j + 1];
+        hval[(size_t)t * n_obst + j] = ex * ex + ey * ey - p.r2;
+        dh[((size_t)t * n_obst + j) * 2] = 2 * ex; dh[((size_t)t * n_obst + j) * 2 + 1] = 2 * ey;
+    }
+}
+
+}  // namespace mpc

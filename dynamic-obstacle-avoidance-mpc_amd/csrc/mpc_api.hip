@@ -1,0 +1,469 @@
+// mpc_api.hip -- C ABI of libmpcgpu.so (include/mpc_gpu.h): handle management, launches, host<->device staging.
+// No CPU fallback exists: every compute entry point launches a HIP kernel or fails.
+#include "../../include/mpc_gpu.h"
+#include "aux_kernels.hpp"
+#include "rti_kernel.hpp"
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, const char *a = "", const char *b = "")
+{
+    snprintf(g_err, sizeof(g_err), fmt, a, b);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                     \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) return fail(MPC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int kMaxEvents = 8192;
+
+}  // namespace
+
+struct mpc_handle {
+    mpc_config cfg;
+    int device, max_batch;
+    hipStream_t stream;
+    double *dX, *dU;                  // handle-owned iterate
+    double *d_x0, *d_P, *d_goal, *d_obst, *d_u0, *d_cost, *d_xa, *d_ua, *d_xb;   // staging for the host-pointer API
+    int32_t *d_status, *d_iters;
+    int lanes_override;
+    int profiling;
+    double *d_trace;                  // optional debug trace buffer (mpc_debug_trace)
+    std::vector<hipEvent_t> ev_start, ev_stop;
+    int ev_used;
+};
+
+namespace {
+
+mpc::KParams make_params(const mpc_config &c, int batch)
+{
+    mpc::KParams p;
+    memset(&p, 0, sizeof(p));
+    p.N = c.N; p.batch = batch;
+    p.soft_h = c.soft_h; p.bx_terminal = c.bx_terminal; p.iter_max = c.qp_iter_max;
+    p.dt = c.Tf / c.N; p.h2 = 0.5 * p.dt * p.dt;
+    const double cs = c.cost_scale_dt ? p.dt : 1.0;
+    const double lm = c.lm_scaled ? c.lm * p.dt : c.lm;
+    // z order (ua, ual, x, y, psi, v, om); y = [x, y, v, om, ua, ual]  (robot_ocp_problem.py:64-68)
+    p.Hd_stage[0] = cs * c.W[4] + lm; p.Hd_stage[1] = cs * c.W[5] + lm;
+    p.Hd_stage[2] = cs * c.W[0] + lm; p.Hd_stage[3] = cs * c.W[1] + lm; p.Hd_stage[4] = lm;
+    p.Hd_stage[5] = cs * c.W[2] + lm; p.Hd_stage[6] = cs * c.W[3] + lm;
+    p.Hd_term[0] = c.We[0] + c.lm; p.Hd_term[1] = c.We[1] + c.lm; p.Hd_term[2] = c.lm;
+    p.Hd_term[3] = c.We[2] + c.lm; p.Hd_term[4] = c.We[3] + c.lm;
+    for (int k = 0; k < 6; k++) p.Wg[k] = cs * c.W[k];
+    for (int k = 0; k < 4; k++) { p.Weg[k] = c.We[k]; p.bx_lo[k] = c.bx_lo[k]; p.bx_hi[k] = c.bx_hi[k]; }
+    for (int k = 0; k < 2; k++) { p.bu_lo[k] = c.bu_lo[k]; p.bu_hi[k] = c.bu_hi[k]; }
+    p.r2 = c.r_safe * c.r_safe;
+    p.slack_a = c.slack_a; p.slack_b = c.slack_b; p.ss = c.slack_scale_dt ? p.dt : 1.0;
+    p.tol = c.qp_tol; p.mu0 = c.mu0; p.thr0 = c.thr0;
+    return p;
+}
+
+mpc::World make_world(const mpc_config &c)
+{
+    mpc::World w;
+    w.xmin = c.arena[0]; w.xmax = c.arena[1]; w.ymin = c.arena[2]; w.ymax = c.arena[3];
+    w.bug_compat_predict = c.bug_compat_predict;
+    return w;
+}
+
+int check_batch(mpc_handle *h, int batch)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    if (batch < 0 || batch > h->max_batch) return fail(MPC_ERR_ARG, "batch outside [0, max_batch]");
+    return MPC_OK;
+}
+
+hipStream_t pick(mpc_handle *h, void *stream) { return stream ? (hipStream_t)stream : h->stream; }
+
+int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
+{
+    const size_t lds = (size_t)mpc::LdsMap::doubles(p.N) * sizeof(double);
+    const dim3 grid(p.batch), block(64);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profiling && h->ev_used < kMaxEvents) {
+        if ((int)h->ev_start.size() <= h->ev_used) {
+            hipEvent_t a, b;
+            HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+            h->ev_start.push_back(a); h->ev_stop.push_back(b);
+        }
+        e0 = h->ev_start[h->ev_used]; e1 = h->ev_stop[h->ev_used]; h->ev_used++;
+        HIPCHK(hipEventRecord(e0, s));
+    }
+    switch (h->cfg.n_obst) {
+    case 3: hipLaunchKernelGGL(mpc::rti_solve_kernel<3>, grid, block, lds, s, p); break;
+    case 5: hipLaunchKernelGGL(mpc::rti_solve_kernel<5>, grid, block, lds, s, p); break;
+    case 10: hipLaunchKernelGGL(mpc::rti_solve_kernel<10>, grid, block, lds, s, p); break;
+    default: return fail(MPC_ERR_ARG, "n_obst must be 3, 5 or 10");
+    }
+    HIPCHK(hipGetLastError());
+    if (e1) HIPCHK(hipEventRecord(e1, s));
+    return MPC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mpc_last_error(void) { return g_err; }
+
+int mpc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mpc_default_config(mpc_config *c, int N, int n_obst, double Tf)
+{
+    if (!c) return fail(MPC_ERR_ARG, "null config");
+    memset(c, 0, sizeof(*c));
+    c->N = N; c->n_obst = n_obst; c->Tf = Tf;
+    for (int k = 0; k < 4; k++) { c->W[k] = 2.0; c->We[k] = 5.0; }   // robot_ocp_problem.py:24-27
+    c->W[4] = c->W[5] = 0.15;
+    c->lm = 2.0;                                                       // :128
+    c->bx_lo[0] = c->bx_lo[1] = -7.0; c->bx_hi[0] = c->bx_hi[1] = 7.0;      // :91-92
+    c->bx_lo[2] = c->bx_lo[3] = -10.0; c->bx_hi[2] = c->bx_hi[3] = 10.0;
+    c->bu_lo[0] = c->bu_lo[1] = -8.0; c->bu_hi[0] = c->bu_hi[1] = 8.0;      // :95-96
+    c->r_safe = 1.0 + 0.2 + 1.2;                                       // robot_model.py:62
+    c->slack_a = 1e4; c->slack_b = 50.0;                               // :146
+    c->qp_iter_max = 50;                                               // world_specification.py:48
+    c->qp_tol = 1e-8;
+    c->cost_scale_dt = 1; c->slack_scale_dt = 1; c->lm_scaled = 0; c->bx_terminal = 0; c->soft_h = 1;
+    c->arena[0] = -8.0; c->arena[1] = 8.0; c->arena[2] = -8.0; c->arena[3] = 8.0;   // world_specification.py:7-10
+    c->bug_compat_predict = 1;
+    c->mu0 = 1e4; c->thr0 = 1e-1;
+    return MPC_OK;
+}
+
+int mpc_create(const mpc_config *cfg, int device, int max_batch, mpc_handle **out)
+{
+    if (!cfg || !out) return fail(MPC_ERR_ARG, "null argument");
+    if (cfg->N < 2 || cfg->N > 63) return fail(MPC_ERR_ARG, "N must be in [2, 63] (one horizon stage per lane of a wavefront)");
+    if (cfg->n_obst != 3 && cfg->n_obst != 5 && cfg->n_obst != 10) return fail(MPC_ERR_ARG, "n_obst must be 3, 5 or 10");
+    if (max_batch < 1) return fail(MPC_ERR_ARG, "max_batch must be >= 1");
+    if (!(cfg->Tf > 0) || !(cfg->qp_tol > 0) || cfg->qp_iter_max < 1) return fail(MPC_ERR_ARG, "Tf, qp_tol, qp_iter_max must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(MPC_ERR_NODEVICE, "no HIP device visible: libmpcgpu has no CPU path");
+    if (device < 0 || device >= ndev) return fail(MPC_ERR_ARG, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    mpc_handle *h = new mpc_handle();
+    h->cfg = *cfg; h->device = device; h->max_batch = max_batch;
+    h->lanes_override = 0; h->profiling = 0; h->ev_used = 0; h->d_trace = nullptr;
+    const size_t B = (size_t)max_batch, N = (size_t)cfg->N, no = (size_t)cfg->n_obst;
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc(&h->dX, B * (N + 1) * 5 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dU, B * N * 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_x0, B * 5 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_P, B * (N + 1) * no * 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_goal, B * 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_obst, B * no * 4 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_u0, B * 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_cost, B * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_xa, B * 5 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_ua, B * 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_xb, B * 5 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_status, B * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&h->d_iters, B * sizeof(int32_t)));
+    HIPCHK(hipMemsetAsync(h->dX, 0, B * (N + 1) * 5 * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->dU, 0, B * N * 2 * sizeof(double), h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *out = h;
+    return MPC_OK;
+}
+
+int mpc_destroy(mpc_handle *h)
+{
+    if (!h) return MPC_OK;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    void *bufs[] = {h->dX, h->dU, h->d_x0, h->d_P, h->d_goal, h->d_obst, h->d_u0, h->d_cost, h->d_xa, h->d_ua, h->d_xb, h->d_status, h->d_iters};
+    for (void *b : bufs) if (b) hipFree(b);
+    if (h->d_trace) hipFree(h->d_trace);
+    for (auto e : h->ev_start) hipEventDestroy(e);
+    for (auto e : h->ev_stop) hipEventDestroy(e);
+    hipStreamDestroy(h->stream);
+    delete h;
+    return MPC_OK;
+}
+
+int mpc_iterate_ptrs(mpc_handle *h, double **d_X, double **d_U, void **stream)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    if (d_X) *d_X = h->dX;
+    if (d_U) *d_U = h->dU;
+    if (stream) *stream = (void *)h->stream;
+    return MPC_OK;
+}
+
+/* ------------------------------------------------ device-pointer API ------------------------------------------------ */
+
+int mpc_solve_dev(mpc_handle *h, int batch, const double *d_x0, const double *d_P, const double *d_goal,
+                  double *d_X, double *d_U, double *d_u0, double *d_cost, int32_t *d_status, int32_t *d_iters, void *stream)
+{
+    int rc = check_batch(h, batch); if (rc) return rc;
+    if (batch == 0) return MPC_OK;
+    if (!d_x0 || !d_P || !d_goal || !d_X || !d_U) return fail(MPC_ERR_ARG, "null device pointer");
+    HIPCHK(hipSetDevice(h->device));
+    mpc::KParams p = make_params(h->cfg, batch);
+    p.x0 = d_x0; p.P = d_P; p.goal = d_goal; p.X = d_X; p.U = d_U;
+    p.u0 = d_u0; p.cost = d_cost; p.status = d_status; p.iters = d_iters; p.trace = h->d_trace;
+    return launch_solve(h, p, pick(h, stream));
+}
+
+int mpc_predict_dev(mpc_handle *h, int batch, const double *d_obst, double *d_P, void *stream)
+{
+    int rc = check_batch(h, batch); if (rc) return rc;
+    if (batch == 0) return MPC_OK;
+    if (!d_obst || !d_P) return fail(MPC_ERR_ARG, "null device pointer");
+    HIPCHK(hipSetDevice(h->device));
+    const int count = batch * h->cfg.n_obst;
+    hipLaunchKernelGGL(mpc::predict_kernel, dim3((count + 255) / 256), dim3(256), 0, pick(h, stream), make_world(h->cfg), count,
+                       h->cfg.n_obst, h->cfg.N, h->cfg.Tf / h->cfg.N, d_obst, d_P);
+    HIPCHK(hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_shift_dev(mpc_handle *h, int batch, double *d_X, double *d_U, void *stream)
+{
+    int rc = check_batch(h, batch); if (rc) return rc;
+    if (batch == 0) return MPC_OK;
+    if (!d_X || !d_U) return fail(MPC_ERR_ARG, "null device pointer");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(mpc::shift_kernel, dim3(batch), dim3(64), 0, pick(h, stream), batch, h->cfg.N, d_X, d_U);
+    HIPCHK(hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_reset_guess_dev(mpc_handle *h, int batch, const double *d_x0, double *d_X, double *d_U, void *stream)
+{
+    int rc = check_batch(h, batch); if (rc) return rc;
+    if (batch == 0) return MPC_OK;
+    if (!d_x0 || !d_X || !d_U) return fail(MPC_ERR_ARG, "null device pointer");
+    HIPCHK(hipSetDevice(h->device));
+    const int count = batch * (h->cfg.N + 1);
+    hipLaunchKernelGGL(mpc::reset_guess_kernel, dim3((count + 255) / 256), dim3(256), 0, pick(h, stream), batch, h->cfg.N, d_x0, d_X, d_U);
+    HIPCHK(hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_plant_step_dev(mpc_handle *h, int batch, const double *d_x, const double *d_u, double *d_xnext, void *stream)
+{
+    int rc = check_batch(h, batch); if (rc) return rc;
+    if (batch == 0) return MPC_OK;
+    if (!d_x || !d_u || !d_xnext) return fail(MPC_ERR_ARG, "null device pointer");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(mpc::plant_step_kernel, dim3((batch + 255) / 256), dim3(256), 0, pick(h, stream), batch, h->cfg.Tf / h->cfg.N, d_x, d_u, d_xnext);
+    HIPCHK(hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_obstacle_step_dev(mpc_handle *h, int count, double *d_obst, const double *d_noise, double randomness, double vmax, void *stream)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    if (count < 0 || count > h->max_batch * h->cfg.n_obst) return fail(MPC_ERR_ARG, "count outside [0, max_batch * n_obst]");
+    if (count == 0) return MPC_OK;
+    if (!d_obst) return fail(MPC_ERR_ARG, "null device pointer");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(mpc::obstacle_step_kernel, dim3((count + 255) / 256), dim3(256), 0, pick(h, stream), make_world(h->cfg), count,
+                       h->cfg.Tf / h->cfg.N, d_obst, d_noise, randomness, vmax);
+    HIPCHK(hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_linearize_dev(mpc_handle *h, int batch, const double *d_x0, const double *d_P, const double *d_goal,
+                      const double *d_X, const double *d_U, double *d_A, double *d_B, double *d_b, double *d_q,
+                      double *d_hval, double *d_dh, void *stream)
+{
+    int rc = check_batch(h, batch); if (rc) return rc;
+    if (batch == 0) return MPC_OK;
+    if (!d_x0 || !d_P || !d_goal || !d_X || !d_U || !d_A || !d_B || !d_b || !d_q || !d_hval || !d_dh) return fail(MPC_ERR_ARG, "null device pointer");
+    HIPCHK(hipSetDevice(h->device));
+    mpc::KParams p = make_params(h->cfg, batch);
+    p.x0 = d_x0; p.P = d_P; p.goal = d_goal;
+    const int count = batch * (h->cfg.N + 1);
+    hipLaunchKernelGGL(mpc::linearize_kernel, dim3((count + 127) / 128), dim3(128), 0, pick(h, stream), p, h->cfg.n_obst, d_X, d_U,
+                       d_A, d_B, d_b, d_q, d_hval, d_dh);
+    HIPCHK(hipGetLastError());
+    return MPC_OK;
+}
+
+/* ------------------------------------------------- host-pointer API ------------------------------------------------- */
+
+int mpc_set_warmstart(mpc_handle *h, int batch, const double *X, const double *U)
+{
+    int rc = check_batch(h, batch); if (rc) return rc;
+    if (!X || !U) return fail(MPC_ERR_ARG, "null pointer");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t N = h->cfg.N;
+    HIPCHK(hipMemcpyAsync(h->dX, X, (size_t)batch * (N + 1) * 5 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->dU, U, (size_t)batch * N * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPC_OK;
+}
+
+int mpc_get_traj(mpc_handle *h, int batch, double *X, double *U)
+{
+    int rc = check_batch(h, batch); if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t N = h->cfg.N;
+    if (X) HIPCHK(hipMemcpyAsync(X, h->dX, (size_t)batch * (N + 1) * 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (U) HIPCHK(hipMemcpyAsync(U, h->dU, (size_t)batch * N * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPC_OK;
+}
+
+int mpc_reset_guess(mpc_handle *h, int batch, const double *x0)
+{
+    int rc = check_batch(h, batch); if (rc) return rc;
+    if (!x0) return fail(MPC_ERR_ARG, "null pointer");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->d_x0, x0, (size_t)batch * 5 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    rc = mpc_reset_guess_dev(h, batch, h->d_x0, h->dX, h->dU, nullptr); if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPC_OK;
+}
+
+int mpc_shift(mpc_handle *h, int batch)
+{
+    int rc = mpc_shift_dev(h, batch, h ? h->dX : nullptr, h ? h->dU : nullptr, nullptr); if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPC_OK;
+}
+
+static int solve_common(mpc_handle *h, int batch, const double *x0, const double *P, const double *obst, const double *goal,
+                        double *u0, double *cost, int32_t *status, int32_t *iters)
+{
+    int rc = check_batch(h, batch); if (rc) return rc;
+    if (batch == 0) return MPC_OK;
+    if (!x0 || !goal || (!P && !obst)) return fail(MPC_ERR_ARG, "null pointer");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t N = h->cfg.N, no = h->cfg.n_obst;
+    HIPCHK(hipMemcpyAsync(h->d_x0, x0, (size_t)batch * 5 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_goal, goal, (size_t)batch * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (P) HIPCHK(hipMemcpyAsync(h->d_P, P, (size_t)batch * (N + 1) * no * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    else {
+        HIPCHK(hipMemcpyAsync(h->d_obst, obst, (size_t)batch * no * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        rc = mpc_predict_dev(h, batch, h->d_obst, h->d_P, nullptr); if (rc) return rc;
+    }
+    rc = mpc_solve_dev(h, batch, h->d_x0, h->d_P, h->d_goal, h->dX, h->dU, h->d_u0, h->d_cost, h->d_status, h->d_iters, nullptr);
+    if (rc) return rc;
+    if (u0) HIPCHK(hipMemcpyAsync(u0, h->d_u0, (size_t)batch * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (cost) HIPCHK(hipMemcpyAsync(cost, h->d_cost, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (status) HIPCHK(hipMemcpyAsync(status, h->d_status, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (iters) HIPCHK(hipMemcpyAsync(iters, h->d_iters, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPC_OK;
+}
+
+int mpc_solve(mpc_handle *h, int batch, const double *x0, const double *P, const double *goal,
+              double *u0, double *cost, int32_t *status, int32_t *iters)
+{
+    if (!P) return fail(MPC_ERR_ARG, "null pointer");
+    return solve_common(h, batch, x0, P, nullptr, goal, u0, cost, status, iters);
+}
+
+int mpc_solve_obst(mpc_handle *h, int batch, const double *x0, const double *obst, const double *goal,
+                   double *u0, double *cost, int32_t *status, int32_t *iters)
+{
+    if (!obst) return fail(MPC_ERR_ARG, "null pointer");
+    return solve_common(h, batch, x0, nullptr, obst, goal, u0, cost, status, iters);
+}
+
+int mpc_plant_step(mpc_handle *h, int batch, const double *x, const double *u, double *x_next)
+{
+    int rc = check_batch(h, batch); if (rc) return rc;
+    if (batch == 0) return MPC_OK;
+    if (!x || !u || !x_next) return fail(MPC_ERR_ARG, "null pointer");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->d_xa, x, (size_t)batch * 5 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_ua, u, (size_t)batch * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    rc = mpc_plant_step_dev(h, batch, h->d_xa, h->d_ua, h->d_xb, nullptr); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(x_next, h->d_xb, (size_t)batch * 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPC_OK;
+}
+
+int mpc_predict(mpc_handle *h, int batch, const double *obst, double *P)
+{
+    int rc = check_batch(h, batch); if (rc) return rc;
+    if (batch == 0) return MPC_OK;
+    if (!obst || !P) return fail(MPC_ERR_ARG, "null pointer");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t N = h->cfg.N, no = h->cfg.n_obst;
+    HIPCHK(hipMemcpyAsync(h->d_obst, obst, (size_t)batch * no * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    rc = mpc_predict_dev(h, batch, h->d_obst, h->d_P, nullptr); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(P, h->d_P, (size_t)batch * (N + 1) * no * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPC_OK;
+}
+
+/* --------------------------------------------------- measurement --------------------------------------------------- */
+
+int mpc_profile_enable(mpc_handle *h, int on)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    h->profiling = on ? 1 : 0;
+    h->ev_used = 0;
+    return MPC_OK;
+}
+
+int mpc_profile_read(mpc_handle *h, double *sum_ms, int *launches)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    double sum = 0.0;
+    for (int k = 0; k < h->ev_used; k++) {
+        HIPCHK(hipEventSynchronize(h->ev_stop[k]));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev_start[k], h->ev_stop[k]));
+        sum += ms;
+    }
+    if (sum_ms) *sum_ms = sum;
+    if (launches) *launches = h->ev_used;
+    h->ev_used = 0;
+    return MPC_OK;
+}
+
+int mpc_debug_trace(mpc_handle *h, int enable, int batch, double *host_out)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t bytes = (size_t)h->max_batch * h->cfg.qp_iter_max * 4 * sizeof(double);
+    if (enable && !h->d_trace) { HIPCHK(hipMalloc(&h->d_trace, bytes)); HIPCHK(hipMemset(h->d_trace, 0, bytes)); }
+    if (host_out && h->d_trace) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(host_out, h->d_trace, (size_t)batch * h->cfg.qp_iter_max * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (!enable && h->d_trace) { HIPCHK(hipFree(h->d_trace)); h->d_trace = nullptr; }
+    return MPC_OK;
+}
+
+int mpc_set_lanes_per_instance(mpc_handle *h, int lanes)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    if (lanes != 0 && lanes != 64) return fail(MPC_ERR_ARG, "this build maps one instance per wavefront (lanes = 64)");
+    h->lanes_override = lanes;
+    return MPC_OK;
+}
+
+int mpc_get_lanes_per_instance(mpc_handle *h, int batch)
+{
+    (void)batch;
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    return 64;
+}
+
+}  // extern "C"

@@ -1,0 +1,138 @@
+"""ctypes binding of libmpcgpu.so (C ABI declared in include/mpc_gpu.h).
+
+The library is built in-tree by `build()` (hipcc --offload-arch=gfx950) and has no CPU path: every solve entry
+point needs a HIP device.  Loading the library and reading its symbol table works without one.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(PKG_ROOT, "csrc")
+LIB_PATH = os.path.join(PKG_ROOT, "libmpcgpu.so")
+REPO_ROOT = os.path.dirname(PKG_ROOT)
+
+MPC_OK, MPC_ERR_ARG, MPC_ERR_HIP, MPC_ERR_NODEVICE = 0, -1, -2, -3
+
+_d = C.c_double
+_i32 = C.c_int32
+
+
+class MpcConfig(C.Structure):
+    """Mirror of `struct mpc_config` (include/mpc_gpu.h)."""
+    _fields_ = [
+        ("N", _i32), ("n_obst", _i32), ("Tf", _d),
+        ("W", _d * 6), ("We", _d * 4), ("lm", _d),
+        ("bx_lo", _d * 4), ("bx_hi", _d * 4), ("bu_lo", _d * 2), ("bu_hi", _d * 2),
+        ("r_safe", _d), ("slack_a", _d), ("slack_b", _d),
+        ("qp_iter_max", _i32), ("qp_tol", _d),
+        ("cost_scale_dt", _i32), ("slack_scale_dt", _i32), ("lm_scaled", _i32),
+        ("bx_terminal", _i32), ("soft_h", _i32),
+        ("arena", _d * 4), ("bug_compat_predict", _i32),
+        ("mu0", _d), ("thr0", _d),
+    ]
+
+
+# every symbol include/mpc_gpu.h declares: name -> (restype, argtypes)
+_vp = C.c_void_p
+_cfgp = C.POINTER(MpcConfig)
+SYMBOLS = {
+    "mpc_last_error": (C.c_char_p, []),
+    "mpc_device_count": (C.c_int, []),
+    "mpc_default_config": (C.c_int, [_cfgp, C.c_int, C.c_int, _d]),
+    "mpc_create": (C.c_int, [_cfgp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "mpc_destroy": (C.c_int, [_vp]),
+    "mpc_iterate_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "mpc_set_warmstart": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "mpc_get_traj": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "mpc_reset_guess": (C.c_int, [_vp, C.c_int, _vp]),
+    "mpc_shift": (C.c_int, [_vp, C.c_int]),
+    "mpc_solve": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mpc_solve_obst": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mpc_plant_step": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "mpc_predict": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "mpc_solve_dev": (C.c_int, [_vp, C.c_int] + [_vp] * 10),
+    "mpc_predict_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "mpc_shift_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "mpc_reset_guess_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "mpc_plant_step_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "mpc_obstacle_step_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _d, _d, _vp]),
+    "mpc_linearize_dev": (C.c_int, [_vp, C.c_int] + [_vp] * 12),
+    "mpc_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "mpc_profile_read": (C.c_int, [_vp, C.POINTER(_d), C.POINTER(C.c_int)]),
+    "mpc_debug_trace": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "mpc_set_lanes_per_instance": (C.c_int, [_vp, C.c_int]),
+    "mpc_get_lanes_per_instance": (C.c_int, [_vp, C.c_int]),
+}
+
+_LIB = None
+
+
+class MpcError(RuntimeError):
+    pass
+
+
+def sources():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp"))] + \
+        [os.path.join(REPO_ROOT, "include", "mpc_gpu.h")]
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip for gfx950 into libmpcgpu.so (in-tree).  hipcc cross-compiles without a GPU."""
+    srcs = sources()
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-o", LIB_PATH, os.path.join(CSRC, "mpc_api.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    """Load libmpcgpu.so and bind every symbol of the header.  Fails loudly when the library is absent."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise MpcError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU or PyTorch fallback for the solve path)")
+        # One HIP runtime per process: PyTorch's ROCm wheel bundles its own libamdhip64.so (soname libamdhip64.so.7) and
+        # libhsa-runtime64; if libmpcgpu pulled in /opt/rocm's copy first, torch's copy would come up second and see no
+        # GPU.  Importing torch first makes the dynamic linker bind libmpcgpu's NEEDED libamdhip64.so.7 to the runtime
+        # already in the process.  Without torch installed (or MPC_GPU_NO_TORCH=1) the system ROCm runtime is used.
+        if not os.environ.get("MPC_GPU_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)      # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().mpc_last_error()
+        raise MpcError(f"libmpcgpu error {rc}: {msg.decode() if msg else '?'}")
+
+
+def default_config(N=20, n_obst=3, Tf=2.0, **overrides):
+    cfg = MpcConfig()
+    check(lib().mpc_default_config(C.byref(cfg), N, n_obst, Tf))
+    for k, v in overrides.items():
+        cur = getattr(cfg, k)
+        if hasattr(cur, "__len__"):
+            for i, x in enumerate(v):
+                cur[i] = x
+        else:
+            setattr(cfg, k, v)
+    return cfg

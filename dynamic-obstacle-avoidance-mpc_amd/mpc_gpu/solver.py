@@ -1,0 +1,153 @@
+"""BatchedMpc: host-side owner of one libmpcgpu handle (one device, one stream, up to max_batch instances).
+
+Mirrors what the reference keeps inside its `AcadosOcpSolver` object (iterate X, U; parameters; options) for the
+solve path of src/simulation/robot_ocp_problem.py:186-198, batched over independent MPC instances.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data)
+    return C.c_void_p(a.data_ptr())      # torch tensor (device or host)
+
+
+class BatchedMpc:
+    def __init__(self, N=20, n_obst=3, Tf=2.0, max_batch=1, device=0, **cfg_overrides):
+        self.cfg = _lib.default_config(N, n_obst, Tf, **cfg_overrides)
+        self.N, self.n_obst, self.Tf = int(N), int(n_obst), float(Tf)
+        self.dt = self.Tf / self.N
+        self.max_batch = int(max_batch)
+        self.device = int(device)
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().mpc_create(C.byref(self.cfg), self.device, self.max_batch, C.byref(self._h)))
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().mpc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ------------------------------------------------------------------ host-pointer API (numpy in / numpy out)
+    def reset_guess(self, x0):
+        """set_initial_guess(), robot_ocp_problem.py:286-306."""
+        x0 = _f64(np.atleast_2d(x0))
+        _lib.check(_lib.lib().mpc_reset_guess(self._h, x0.shape[0], _ptr(x0)))
+
+    def set_warmstart(self, X, U):
+        X, U = _f64(X), _f64(U)
+        B = X.shape[0]
+        if X.shape != (B, self.N + 1, 5) or U.shape != (B, self.N, 2):
+            raise ValueError("X must be (B,N+1,5) and U (B,N,2)")
+        _lib.check(_lib.lib().mpc_set_warmstart(self._h, B, _ptr(X), _ptr(U)))
+
+    def get_traj(self, batch):
+        X = np.empty((batch, self.N + 1, 5)); U = np.empty((batch, self.N, 2))
+        _lib.check(_lib.lib().mpc_get_traj(self._h, batch, _ptr(X), _ptr(U)))
+        return X, U
+
+    def shift(self, batch):
+        """warm-start shift, robot_ocp_problem.py:253-258."""
+        _lib.check(_lib.lib().mpc_shift(self._h, batch))
+
+    def solve(self, x0, obstacles, goal):
+        """One RTI step for a batch.  `obstacles` is either the explicit parameter tensor P (B,N+1,n_obst,2)
+        (reference API, parameterize_model) or obstacle states (B,n_obst,4) = (x,y,vx,vy) whose look-ahead is
+        computed on the device.  Returns dict(u0, cost, status, iters)."""
+        x0 = _f64(np.atleast_2d(x0)); B = x0.shape[0]
+        goal = _f64(np.atleast_2d(goal), (B, 2))
+        obstacles = _f64(obstacles)
+        u0 = np.empty((B, 2)); cost = np.empty(B)
+        status = np.empty(B, np.int32); iters = np.empty(B, np.int32)
+        if obstacles.shape == (B, self.N + 1, self.n_obst, 2):
+            fn = _lib.lib().mpc_solve
+        elif obstacles.shape == (B, self.n_obst, 4):
+            fn = _lib.lib().mpc_solve_obst
+        else:
+            raise ValueError(f"obstacles must be (B,{self.N + 1},{self.n_obst},2) or (B,{self.n_obst},4), got {obstacles.shape}")
+        _lib.check(fn(self._h, B, _ptr(x0), _ptr(obstacles), _ptr(goal), _ptr(u0), _ptr(cost), _ptr(status), _ptr(iters)))
+        return dict(u0=u0, cost=cost, status=status, iters=iters)
+
+    def plant_step(self, x, u):
+        """ocp_integrator set/solve/get, robot_ocp_problem.py:207-212."""
+        x = _f64(np.atleast_2d(x)); u = _f64(np.atleast_2d(u), (x.shape[0], 2))
+        xn = np.empty_like(x)
+        _lib.check(_lib.lib().mpc_plant_step(self._h, x.shape[0], _ptr(x), _ptr(u), _ptr(xn)))
+        return xn
+
+    def predict(self, obst):
+        """Obstacle.predict_trajectory for every obstacle -> P (B,N+1,n_obst,2), visualization.py:62-79."""
+        obst = _f64(obst); B = obst.shape[0]
+        if obst.shape != (B, self.n_obst, 4):
+            raise ValueError("obst must be (B,n_obst,4)")
+        P = np.empty((B, self.N + 1, self.n_obst, 2))
+        _lib.check(_lib.lib().mpc_predict(self._h, B, _ptr(obst), _ptr(P)))
+        return P
+
+    # ------------------------------------------------------------------ device-pointer API (torch tensors or raw ints)
+    def iterate_ptrs(self):
+        dX, dU, st = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.check(_lib.lib().mpc_iterate_ptrs(self._h, C.byref(dX), C.byref(dU), C.byref(st)))
+        return dX.value, dU.value, st.value
+
+    def solve_dev(self, batch, x0, P, goal, X, U, u0=None, cost=None, status=None, iters=None, stream=None):
+        _lib.check(_lib.lib().mpc_solve_dev(self._h, batch, _ptr(x0), _ptr(P), _ptr(goal), _ptr(X), _ptr(U), _ptr(u0),
+                                            _ptr(cost), _ptr(status), _ptr(iters), _ptr(stream)))
+
+    def predict_dev(self, batch, obst, P, stream=None):
+        _lib.check(_lib.lib().mpc_predict_dev(self._h, batch, _ptr(obst), _ptr(P), _ptr(stream)))
+
+    def shift_dev(self, batch, X, U, stream=None):
+        _lib.check(_lib.lib().mpc_shift_dev(self._h, batch, _ptr(X), _ptr(U), _ptr(stream)))
+
+    def reset_guess_dev(self, batch, x0, X, U, stream=None):
+        _lib.check(_lib.lib().mpc_reset_guess_dev(self._h, batch, _ptr(x0), _ptr(X), _ptr(U), _ptr(stream)))
+
+    def plant_step_dev(self, batch, x, u, xn, stream=None):
+        _lib.check(_lib.lib().mpc_plant_step_dev(self._h, batch, _ptr(x), _ptr(u), _ptr(xn), _ptr(stream)))
+
+    def obstacle_step_dev(self, count, obst, noise=None, randomness=0.1, vmax=2.0, stream=None):
+        _lib.check(_lib.lib().mpc_obstacle_step_dev(self._h, count, _ptr(obst), _ptr(noise), randomness, vmax, _ptr(stream)))
+
+    def linearize_dev(self, batch, x0, P, goal, X, U, A, B, b, q, hval, dh, stream=None):
+        _lib.check(_lib.lib().mpc_linearize_dev(self._h, batch, _ptr(x0), _ptr(P), _ptr(goal), _ptr(X), _ptr(U), _ptr(A), _ptr(B),
+                                                _ptr(b), _ptr(q), _ptr(hval), _ptr(dh), _ptr(stream)))
+
+    # ------------------------------------------------------------------ measurement
+    def profile_enable(self, on=True):
+        _lib.check(_lib.lib().mpc_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        ms, n = C.c_double(), C.c_int()
+        _lib.check(_lib.lib().mpc_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def lanes_per_instance(self, batch):
+        return _lib.lib().mpc_get_lanes_per_instance(self._h, batch)

@@ -1,0 +1,147 @@
+/*
+ * mpc_gpu.h -- C ABI of libmpcgpu.so: batched real-time-iteration NMPC solve on AMD MI355X (gfx950).
+ *
+ * Drop-in boundary.  In the reference the hot path sits behind acados' ctypes objects
+ * `AcadosOcpSolver` / `AcadosSimSolver`, used from src/simulation/robot_ocp_problem.py.  Each entry point
+ * below names the reference call site(s) it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - plain C, no exceptions; every function returns 0 on success, a negative code on error
+ *     (MPC_ERR_*), and mpc_last_error() returns a thread-local message for the last failure.
+ *   - all arrays are float64, C-contiguous, batch-major:
+ *       x0[B][5], goal[B][2], P[B][N+1][n_obst][2], obst[B][n_obst][4] = (x, y, vx, vy),
+ *       X[B][N+1][5], U[B][N][2], u0[B][2], cost[B]; status/iters are int32[B].
+ *     State is [x, y, psi, v, omega], control is [u_a, u_alpha] (src/models/robot_model.py:14-25).
+ *   - per-instance solver status uses the acados codes the reference inspects
+ *     (robot_ocp_problem.py:203): 0 ok, 2 QP hit qp_iter_max (step still applied), 4 QP failure (no step).
+ *   - functions without the _dev suffix take HOST pointers and copy; they synchronise before returning.
+ *     _dev functions take DEVICE pointers, enqueue on `stream` (a hipStream_t passed as void*, NULL = the
+ *     handle's own stream) and do not synchronise.
+ *   - a handle is bound to one device and owns the warm-start iterate (X, U) for up to max_batch
+ *     instances, as the acados solver object owns it in the reference.  Calls on one handle must be
+ *     serialised by the caller; different handles may be used from different threads.
+ *   - the library never falls back to a CPU path: without a usable HIP device mpc_create fails.
+ */
+#ifndef MPC_GPU_H
+#define MPC_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPC_OK 0
+#define MPC_ERR_ARG (-1)      /* bad argument / unsupported size */
+#define MPC_ERR_HIP (-2)      /* HIP runtime error (message has the hipError string) */
+#define MPC_ERR_NODEVICE (-3) /* no usable gfx950 device */
+
+#define MPC_NX 5
+#define MPC_NU 2
+
+/* Problem definition.  Defaults (mpc_default_config) are the reference's constants. */
+typedef struct mpc_config {
+    int32_t N;              /* N_SOLV                     src/models/world_specification.py:44   */
+    int32_t n_obst;         /* N_OBST (3, 5 or 10 built)  world_specification.py:25              */
+    double Tf;              /* TF                         world_specification.py:43              */
+    double W[6];            /* diag W, y=[x,y,v,w,ua,ual] robot_ocp_problem.py:24-26,78-80       */
+    double We[4];           /* diag W_e, y_e=[x,y,v,w]    robot_ocp_problem.py:27,83             */
+    double lm;              /* levenberg_marquardt        robot_ocp_problem.py:128               */
+    double bx_lo[4];        /* lbx on idx [0,1,3,4]       robot_ocp_problem.py:91-93             */
+    double bx_hi[4];
+    double bu_lo[2];        /* lbu / ubu                  robot_ocp_problem.py:95-97             */
+    double bu_hi[2];
+    double r_safe;          /* R_OBST+R_ROBOT+MARGIN      src/models/robot_model.py:62           */
+    double slack_a;         /* 1e4                        robot_ocp_problem.py:146               */
+    double slack_b;         /* 50                         robot_ocp_problem.py:146               */
+    int32_t qp_iter_max;    /* QP_ITER                    robot_ocp_problem.py:131               */
+    double qp_tol;          /* interior-point tolerance (linear residuals, complementarity)      */
+    /* acados-semantics switches; defaults reproduce 2022-era acados           */
+    int32_t cost_scale_dt;  /* stage cost x dt                                      default 1   */
+    int32_t slack_scale_dt; /* slack penalties x dt for stages < N                  default 1   */
+    int32_t lm_scaled;      /* LM term x dt                                          default 0   */
+    int32_t bx_terminal;    /* path box also at stage N                              default 0   */
+    int32_t soft_h;         /* obstacle rows softened (slack=True, :106)             default 1   */
+    double arena[4];        /* X_MIN, X_MAX, Y_MIN, Y_MAX  world_specification.py:7-10           */
+    int32_t bug_compat_predict; /* look-ahead uses vx = vy, src/utils/visualization.py:69  default 1 */
+    double mu0;             /* interior-point cold start: lam = mu0 / t                          */
+    double thr0;            /*                            t = max(rho, thr0)                     */
+} mpc_config;
+
+typedef struct mpc_handle mpc_handle;
+
+/* thread-local description of the last error returned on this thread */
+const char *mpc_last_error(void);
+
+/* number of visible HIP devices (0 when none); never initialises a context */
+int mpc_device_count(void);
+
+/* fill `cfg` with the reference's constants for a given horizon / obstacle count */
+int mpc_default_config(mpc_config *cfg, int N, int n_obst, double Tf);
+
+/* Replaces AcadosOcpSolver(...) / AcadosSimSolver(...) construction, robot_ocp_problem.py:135-136.
+ * Allocates device buffers for up to max_batch instances on `device`; warm start is zero-initialised. */
+int mpc_create(const mpc_config *cfg, int device, int max_batch, mpc_handle **out);
+int mpc_destroy(mpc_handle *h);
+
+/* Device pointers of the handle-owned iterate (X[max_batch][N+1][5], U[max_batch][N][2]) and the handle's stream */
+int mpc_iterate_ptrs(mpc_handle *h, double **d_X, double **d_U, void **stream);
+
+/* ocp_solver.set(i,'x',..)/set(i,'u',..) for all stages, robot_ocp_problem.py:254-258,305-306 */
+int mpc_set_warmstart(mpc_handle *h, int batch, const double *X, const double *U);
+/* ocp_solver.get(i,'x') / get(i,'u') for all stages, robot_ocp_problem.py:198,232,240 */
+int mpc_get_traj(mpc_handle *h, int batch, double *X, double *U);
+/* set_initial_guess(): reset(), X[i] = [x0_x, x0_y, x0_psi, 0, 0], U = 0, robot_ocp_problem.py:286-306 */
+int mpc_reset_guess(mpc_handle *h, int batch, const double *x0);
+/* warm-start shift, robot_ocp_problem.py:253-258 */
+int mpc_shift(mpc_handle *h, int batch);
+
+/* The solve core, robot_ocp_problem.py:186-198: parameterize_model (P), parameterize_slack (from x0, goal),
+ * lbx_0 = ubx_0 = x0, ocp_solver.solve(), u* = get(0,'u').  One SQP_RTI iteration per instance on the
+ * handle-owned iterate.  u0/cost/status/iters may be NULL.  cost = NLP objective at the new iterate. */
+int mpc_solve(mpc_handle *h, int batch, const double *x0, const double *P, const double *goal,
+              double *u0, double *cost, int32_t *status, int32_t *iters);
+/* Same with the obstacle look-ahead fused: obst[B][n_obst][4] -> P on device
+ * (Obstacle.predict_trajectory, src/utils/visualization.py:62-79 + parameterize_model, :154-166) */
+int mpc_solve_obst(mpc_handle *h, int batch, const double *x0, const double *obst, const double *goal,
+                   double *u0, double *cost, int32_t *status, int32_t *iters);
+
+/* Plant integrator, ocp_integrator.set/solve/get, robot_ocp_problem.py:207-212 (same IRK as the OCP) */
+int mpc_plant_step(mpc_handle *h, int batch, const double *x, const double *u, double *x_next);
+/* Obstacle look-ahead only: obst[B][n_obst][4] -> P[B][N+1][n_obst][2] (visualization.py:62-79) */
+int mpc_predict(mpc_handle *h, int batch, const double *obst, double *P);
+
+/* ---- device-pointer (asynchronous) variants: inputs already resident in HBM ---- */
+int mpc_solve_dev(mpc_handle *h, int batch, const double *d_x0, const double *d_P, const double *d_goal,
+                  double *d_X, double *d_U, double *d_u0, double *d_cost, int32_t *d_status, int32_t *d_iters,
+                  void *stream);
+int mpc_predict_dev(mpc_handle *h, int batch, const double *d_obst, double *d_P, void *stream);
+int mpc_shift_dev(mpc_handle *h, int batch, double *d_X, double *d_U, void *stream);
+int mpc_reset_guess_dev(mpc_handle *h, int batch, const double *d_x0, double *d_X, double *d_U, void *stream);
+int mpc_plant_step_dev(mpc_handle *h, int batch, const double *d_x, const double *d_u, double *d_xnext, void *stream);
+/* Obstacle.step() ground-truth motion (visualization.py:20-33); d_noise[B*n_obst][2] standard normals or NULL */
+int mpc_obstacle_step_dev(mpc_handle *h, int count, double *d_obst, const double *d_noise,
+                          double randomness, double vmax, void *stream);
+/* Linearisation products of the current iterate, for parity tests of the linearise stage:
+ * A[B][N][5][5], Bm[B][N][5][2], b[B][N][5], q[B][N+1][7] (order u,x), hval[B][N+1][n_obst], dh[B][N+1][n_obst][2] */
+int mpc_linearize_dev(mpc_handle *h, int batch, const double *d_x0, const double *d_P, const double *d_goal,
+                      const double *d_X, const double *d_U,
+                      double *d_A, double *d_B, double *d_b, double *d_q, double *d_hval, double *d_dh, void *stream);
+
+/* ---- measurement: HIP events around every solve-kernel launch on the launch stream ---- */
+int mpc_profile_enable(mpc_handle *h, int on);
+/* synchronises; returns the summed duration and the number of solve-kernel launches since the last call */
+int mpc_profile_read(mpc_handle *h, double *sum_ms, int *launches);
+
+/* Debug aid for parity work: when enabled, every solve records (mu, sigma, alpha, cmax) of each interior-point
+ * iteration into a device buffer [max_batch][qp_iter_max][4]; host_out (may be NULL) receives the first `batch` rows. */
+int mpc_debug_trace(mpc_handle *h, int enable, int batch, double *host_out);
+
+/* lanes per instance (64, 32, 16 or 8) the dispatcher picked for `batch`; 0 = automatic (default) */
+int mpc_set_lanes_per_instance(mpc_handle *h, int lanes);
+int mpc_get_lanes_per_instance(mpc_handle *h, int batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPC_GPU_H */

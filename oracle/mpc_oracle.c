@@ -618,6 +618,10 @@ static void residuals(const qp_t *Q, iter_t *I, double (*rg)[NZ], double *rs, do
  * OCP-QP solver, which robot_ocp_problem.py:126 selects; tolerance/caps are ours].
  * Returns 0 converged, 2 max-iter, 4 failure (NaN / step collapse).
  */
+/* optional per-iteration trace (mu, sigma, alpha, cmax) for debugging parity; not thread-safe */
+static double *g_trace = NULL; static int g_trace_cap = 0;
+void orc_set_trace(double *buf, int cap) { g_trace = buf; g_trace_cap = cap; }
+
 static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, double *kkt)
 {
     int N = Q->N, ni = Q->n_items, ns = Q->n_s;
@@ -727,6 +731,7 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
                 alpha = 0.995 * amax; if (amax >= 1.0) alpha = 1.0; if (alpha > 1.0) alpha = 1.0;
             }
         }
+        if (g_trace && it < g_trace_cap) { g_trace[4 * it] = mu; g_trace[4 * it + 1] = sigma; g_trace[4 * it + 2] = alpha; g_trace[4 * it + 3] = res[3]; }
         if (!(alpha > 1e-14)) { status = 4; break; }
         for (int i = 0; i <= N; i++) { for (int a = 0; a < 7; a++) I->z[i][a] += alpha * dz[i][a]; }
         for (int j = 0; j < ns; j++) I->s[j] += alpha * ds[j];
