@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- MPC solves/s of the RTI hot path on MI355X (contract: see the task statement / DESIGN.md section 6).
+
+A "step" is one closed-loop control step for the whole batch, everything resident in HBM:
+    obstacle look-ahead (a9) -> RTI solve (a10/a11) -> plant step (a14) -> obstacle motion -> warm-start shift (a12)
+Workload (default, BASELINE.json configs[1] = "C2"): batch = 1024 identical scenarios, N = 20, Tf = 2 s, 3 moving obstacles
+(positions and velocities of the reference generator's seed-0 RANDOM draw, tests/golden/), x0 = [-6,-6,pi/4,0,0], goal [6,6].
+`--workload c3` runs 65536 randomized scenarios instead.
+
+N > 1 GPUs (launched by torch.distributed.run, one rank per GPU): the batch is replicated per rank (weak scaling, no
+data-path collective); the per-scenario costs are all-gathered over RCCL every step on a side stream.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "dynamic-obstacle-avoidance-mpc_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VALU_PEAK_TF = 78.6     # MI355X FP64 vector peak
+
+
+def algorithmic_bytes_per_solve(N, n_obst):
+    """read x0 5 + goal 2 + P (N+1)*2*n_obst + X 5(N+1) + U 2N; write X, U, cost (f64) + status (4 B)."""
+    rd = 5 + 2 + (N + 1) * 2 * n_obst + 5 * (N + 1) + 2 * N
+    wr = 5 * (N + 1) + 2 * N + 1
+    return 8 * (rd + wr) + 4
+
+
+def algorithmic_flops_per_solve(N, n_obst, k_iters):
+    """F = N c_lin + K [N (7/3 nx^3 + 4 nx^2 nu + 2 nx nu^2 + nu^3/3) + N (2 (nx+nu)^2 + 6 n_ineq)]"""
+    nx, nu = 5, 2
+    n_ineq = 2 * nu + 2 * 4 + 2 * n_obst
+    c_lin = 200.0
+    per_iter = N * (7.0 / 3 * nx ** 3 + 4 * nx ** 2 * nu + 2 * nx * nu ** 2 + nu ** 3 / 3.0) + N * (2 * (nx + nu) ** 2 + 6 * n_ineq)
+    return N * c_lin + k_iters * per_iter
+
+
+def make_workload(name, batch, N, n_obst, rank=0):
+    if name == "c2":
+        gold = np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz"))
+        obst1 = gold[f"gen_RANDOM_{n_obst}"][0]               # seed-0 RANDOM draw of the reference generator
+        x0 = np.tile(np.array([-6.0, -6.0, np.pi / 4, 0.0, 0.0]), (batch, 1))
+        goal = np.tile(np.array([6.0, 6.0]), (batch, 1))
+        obst = np.tile(obst1[None], (batch, 1, 1))
+        desc = f"C2: batch={batch} identical scenarios, N={N}, Tf={0.1 * N:g}s, {n_obst} moving obstacles"
+    else:
+        rng = np.random.default_rng(1234 + rank)
+        x0 = np.zeros((batch, 5)); x0[:, :2] = rng.uniform(-6, 6, (batch, 2)); x0[:, 2] = rng.uniform(-np.pi, np.pi, batch)
+        goal = rng.uniform(-6, 6, (batch, 2))
+        obst = np.zeros((batch, n_obst, 4)); obst[:, :, :2] = rng.uniform(-4.4, 6, (batch, n_obst, 2)); obst[:, :, 2:] = rng.uniform(-2, 2, (batch, n_obst, 2))
+        desc = f"C3: batch={batch} randomized start/goal/obstacle velocities, N={N}, Tf={0.1 * N:g}s, {n_obst} obstacles"
+    return x0, goal, obst, desc
+
+
+class Loop:
+    """closed-loop state on one GPU"""
+
+    def __init__(self, mpc_gpu, N, n_obst, batch, x0, goal, obst, dev):
+        self.m = mpc_gpu.BatchedMpc(N, n_obst, 0.1 * N, max_batch=batch, device=dev.index or 0)
+        self.B, self.N, self.no = batch, N, n_obst
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        z = lambda *s, dt=torch.float64: torch.zeros(*s, dtype=dt, device=dev)
+        self.x0, self.goal, self.obst = t(x0), t(goal), t(obst)
+        self.x1 = z(batch, 5)
+        self.P = z(batch, N + 1, n_obst, 2)
+        self.X, self.U = z(batch, N + 1, 5), z(batch, N, 2)
+        self.u0, self.cost = z(batch, 2), z(batch)
+        self.status, self.iters = z(batch, dt=torch.int32), z(batch, dt=torch.int32)
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.m.reset_guess_dev(batch, self.x0, self.X, self.U, stream=self.stream)
+
+    def step(self):
+        m, B, s = self.m, self.B, self.stream
+        m.predict_dev(B, self.obst, self.P, stream=s)
+        m.solve_dev(B, self.x0, self.P, self.goal, self.X, self.U, self.u0, self.cost, self.status, self.iters, stream=s)
+        m.plant_step_dev(B, self.x0, self.u0, self.x1, stream=s)
+        self.x0, self.x1 = self.x1, self.x0
+        m.obstacle_step_dev(B * self.no, self.obst, None, stream=s)
+        m.shift_dev(B, self.X, self.U, stream=s)
+
+
+def cpu_baseline(N, n_obst, x0, goal, obst, warm_steps, target_s=12.0):
+    """The oracle (CPU restatement, OpenMP over instances) on a bounded sample of the same workload, host cores of this box."""
+    from oracle import oracle as orc
+    cfg = orc.config(N, n_obst, 0.1 * N, qp_tol=1e-8)
+    nthreads = os.cpu_count() or 1
+    S = min(len(x0), max(64, 4 * nthreads))
+    x0, goal, obst = x0[:S].copy(), goal[:S].copy(), obst[:S].copy()
+    X = np.zeros((S, N + 1, 5)); U = np.zeros((S, N, 2))
+    for b in range(S):
+        X[b], U[b] = orc.initial_guess(cfg, x0[b])
+    dt = 0.1
+    solves, t_solve, steps = 0, 0.0, 0
+    t_begin = time.perf_counter()
+    while True:
+        P = np.stack([orc.predict_params(cfg, obst[b]) for b in range(S)])
+        t0 = time.perf_counter()
+        r = orc.rti_solve_batch(cfg, x0, P, goal, X, U, nthreads=nthreads)
+        t1 = time.perf_counter()
+        if steps >= warm_steps:
+            t_solve += t1 - t0; solves += S
+        X, U = r["X"], r["U"]
+        for b in range(S):
+            x0[b] = orc.dynamics(x0[b], r["u0"][b], dt)[0]
+            for j in range(n_obst):
+                obst[b, j] = orc.obstacle_step(cfg, obst[b, j], dt)
+            X[b], U[b] = orc.shift(cfg, X[b], U[b])
+        steps += 1
+        if (time.perf_counter() - t_begin > target_s and solves > 0) or steps > 400:
+            break
+    return {"value": solves / t_solve, "unit": "solves/s", "cores": nthreads, "kind": "port",
+            "sample": f"{S} instances x {steps - warm_steps} closed-loop steps of the same workload, oracle/liborc.so (C, f64, "
+                      f"OpenMP {nthreads} threads), solve time only; acados itself cannot run here"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 1024 for c2, 65536 for c3)")
+    ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--n-obst", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the supplementary C3 measurement")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    import __graft_entry__ as g
+    g.build()
+    import mpc_gpu
+
+    N, no = args.horizon, args.n_obst
+    batch = args.batch or (1024 if args.workload == "c2" else 65536)
+    x0, goal, obst, desc = make_workload(args.workload, batch, N, no, rank)
+    loop = Loop(mpc_gpu, N, no, batch, x0, goal, obst, dev)
+
+    gathered = torch.zeros(world * batch, dtype=torch.float64, device=dev) if world > 1 else None
+    side = torch.cuda.Stream(device=dev) if world > 1 else None
+    handle = None
+
+    def one_step():
+        nonlocal handle
+        loop.step()
+        if world > 1:   # RCCL all-gather of the per-scenario costs over xGMI, off the critical path
+            if handle is not None:
+                handle.wait()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                handle = dist.all_gather_into_tensor(gathered, loop.cost.clone(), async_op=True)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    loop.m.profile_enable(True)
+    it_acc = torch.zeros(batch, dtype=torch.int32, device=dev)   # per-instance sums, one tiny in-place add per step
+    st_acc = torch.zeros(batch, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+        it_acc.add_(loop.iters)
+        st_acc.add_(loop.status)
+    if handle is not None:
+        handle.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms, launches = loop.m.profile_read()
+    loop.m.profile_enable(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    total_solves = world * batch * args.steps
+    value = total_solves / elapsed
+    mean_iters = float(it_acc.double().sum().item()) / (batch * args.steps)
+    avg_kernel_s = kern_ms / max(1, launches) * 1e-3
+    abytes = algorithmic_bytes_per_solve(N, no) * batch
+    roof = {"bound": "hbm", "achieved": abytes / avg_kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": abytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "kernel": f"rti_solve_kernel<{no}>", "avg_launch_us": avg_kernel_s * 1e6, "launches": launches,
+            "algorithmic_bytes_per_launch": abytes,
+            "fp64_valu": {"achieved": algorithmic_flops_per_solve(N, no, mean_iters) * batch / avg_kernel_s / 1e12,
+                          "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                          "frac": algorithmic_flops_per_solve(N, no, mean_iters) * batch / avg_kernel_s / 1e12 / FP64_VALU_PEAK_TF,
+                          "note": "the path is FP64-vector-ALU/latency bound, not HBM bound (DESIGN.md section 5); SURVEY 8(d) flop model x measured mean IPM iterations"}}
+    out = {"metric": "MPC solves/sec (N=20, 3 obstacles)", "value": value, "unit": "solves/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": desc, "per_gpu_batch": batch, "N": N, "n_obst": no, "qp_tol": 1e-8, "qp_iter_max": 50,
+                      "step": "predict + RTI solve + plant step + obstacle step + shift, device resident",
+                      "parallelism": f"replicas x{world}, cost all-gather (RCCL)" if world > 1 else "single GPU"},
+           "mean_ipm_iters": mean_iters, "instances_with_nonzero_status": int((st_acc != 0).sum().item()),
+           "lanes_per_instance": loop.m.lanes_per_instance(batch), "roofline": roof}
+
+    if rank == 0 and world == 1 and not args.no_extra and args.workload == "c2":
+        # supplementary: the large-batch configuration (configs[2]) on the same GPU
+        xb, gb, ob, d3 = make_workload("c3", 65536, N, no)
+        l3 = Loop(mpc_gpu, N, no, 65536, xb, gb, ob, dev)
+        for _ in range(3):
+            l3.step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            l3.step()
+        torch.cuda.synchronize()
+        e3 = time.perf_counter() - t1
+        out["extra"] = {"workload": d3, "value": 65536 * 5 / e3, "unit": "solves/s", "ms_per_step": e3 / 5 * 1e3,
+                        "mean_ipm_iters": float(l3.iters.double().mean().item())}
+        del l3
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(N, no, x0, goal, obst, warm_steps=args.warmup)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

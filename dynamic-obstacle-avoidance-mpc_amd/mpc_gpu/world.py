@@ -123,4 +123,7 @@ def obstacle_states(obstacles):
     """list[Obstacle-like with .x .y .vx .vy] | (n_obst,4) array -> (n_obst,4) float64"""
     if isinstance(obstacles, np.ndarray):
         return np.ascontiguousarray(obstacles, dtype=np.float64)
-    return np.array([[o.x, o.y, o.vx, o.vy] for o in obstacles], dtype=np.float64)
+    obstacles = list(obstacles)
+    if obstacles and hasattr(obstacles[0], "vx"):
+        return np.array([[o.x, o.y, o.vx, o.vy] for o in obstacles], dtype=np.float64)
+    return np.ascontiguousarray(obstacles, dtype=np.float64)

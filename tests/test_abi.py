@@ -1,0 +1,85 @@
+"""The C-ABI library: loads without a GPU, exports every symbol include/mpc_gpu.h declares, fails loudly without a device.
+No compute calls here (CPU-only suite)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib(built):
+    from mpc_gpu import _lib
+    return _lib
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "mpc_gpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpc_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    L = C.CDLL(lib.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/mpc_gpu.h but not exported by libmpcgpu.so"
+    assert set(names) == set(lib.SYMBOLS), set(names) ^ set(lib.SYMBOLS)
+
+
+def test_default_config_matches_reference_constants_and_oracle(lib):
+    from oracle import oracle as orc
+    cfg = lib.default_config(20, 3, 2.0)
+    o = orc.config(20, 3, 2.0)
+    assert C.sizeof(lib.MpcConfig) == C.sizeof(orc.OrcConfig)
+    for name, _ in lib.MpcConfig._fields_:
+        a, b = getattr(cfg, name), getattr(o, name)
+        if hasattr(a, "__len__"):
+            assert list(a) == list(b), name
+        elif name != "qp_tol":
+            assert a == b, name
+    assert list(cfg.W) == [2, 2, 2, 2, 0.15, 0.15] and list(cfg.We) == [5, 5, 5, 5] and cfg.lm == 2.0
+    assert cfg.r_safe == pytest.approx(2.4) and cfg.qp_iter_max == 50 and list(cfg.bu_hi) == [8, 8]
+
+
+def test_no_device_means_loud_failure_not_a_fallback(lib):
+    L = lib.lib()
+    if L.mpc_device_count() > 0:
+        pytest.skip("a GPU is present")
+    cfg = lib.default_config(20, 3, 2.0)
+    h = C.c_void_p()
+    rc = L.mpc_create(C.byref(cfg), 0, 4, C.byref(h))
+    assert rc == lib.MPC_ERR_NODEVICE and b"no CPU path" in L.mpc_last_error()
+    import mpc_gpu
+    with pytest.raises(mpc_gpu.MpcError):
+        mpc_gpu.BatchedMpc(20, 3, 2.0)
+    with pytest.raises(mpc_gpu.MpcError):
+        mpc_gpu.solve([0, 0, 0, 0, 0], [[1, 1, 0, 0]] * 3, [1, 1])
+
+
+def test_argument_validation_without_device(lib):
+    L = lib.lib()
+    assert L.mpc_default_config(None, 20, 3, 2.0) == lib.MPC_ERR_ARG
+    cfg = lib.default_config(20, 3, 2.0)
+    h = C.c_void_p()
+    for bad in (dict(N=1), dict(N=64), dict(n_obst=4)):
+        c2 = lib.default_config(20, 3, 2.0)
+        for k, v in bad.items():
+            setattr(c2, k, v)
+        assert L.mpc_create(C.byref(c2), 0, 1, C.byref(h)) == lib.MPC_ERR_ARG
+    assert L.mpc_create(C.byref(cfg), 0, 0, C.byref(h)) == lib.MPC_ERR_ARG
+    assert L.mpc_solve(None, 1, None, None, None, None, None, None, None) == lib.MPC_ERR_ARG
+    assert L.mpc_destroy(None) == 0
+
+
+def test_product_does_not_touch_the_oracle():
+    """the shipped package must not import, link or load anything under oracle/"""
+    pkg = os.path.join(ROOT, "dynamic-obstacle-avoidance-mpc_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "liborc" not in txt and "from oracle" not in txt and "import oracle" not in txt, f

@@ -1,0 +1,111 @@
+"""GPU tests of the kernels either side of the solve (a9, a12, a13, a14) and of the Python call surface, through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import oracle_P, random_batch
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.npz"))
+
+
+@pytest.fixture(scope="module")
+def env(built):
+    import mpc_gpu
+    from oracle import oracle as orc
+    return mpc_gpu, orc
+
+
+@pytest.mark.parametrize("n", [5, 20, 50])
+def test_predict_kernel_bit_exact_vs_reference_vectors(env, n):
+    """device look-ahead == Obstacle.predict_trajectory of the reference (golden vectors), bit for bit, incl. wall bounces"""
+    mpc_gpu, orc = env
+    states = GOLD["pred_states"]; ref = GOLD[f"pred_traj_{n}"]          # (50,4), (50,n+1,2)
+    B = 10                                                               # 50 states = 10 instances x 5 obstacles
+    with mpc_gpu.BatchedMpc(n, 5, 0.1 * n, max_batch=B) as s:
+        P = s.predict(states.reshape(B, 5, 4))
+    assert np.array_equal(P.transpose(0, 2, 1, 3).reshape(50, n + 1, 2), ref)
+    with mpc_gpu.BatchedMpc(n, 5, 0.1 * n, max_batch=B, bug_compat_predict=0) as s:   # defect D1 fixed: x uses vx
+        Pf = s.predict(states.reshape(B, 5, 4))
+    cfg = orc.config(n, 5, 0.1 * n, bug_compat_predict=0)
+    want = np.stack([orc.predict_params(cfg, o) for o in states.reshape(B, 5, 4)])
+    assert np.array_equal(Pf, want)
+
+
+def test_obstacle_step_kernel_vs_reference_sequences(env):
+    import torch
+    mpc_gpu, orc = env
+    seq, noise = GOLD["noisy_seq"], GOLD["noisy_noise"]                  # (8,31,4), (8,30,2)
+    dev = torch.device("cuda:0")
+    with mpc_gpu.BatchedMpc(20, 5, 2.0, max_batch=2) as s:
+        st = torch.from_numpy(seq[:, 0].copy()).to(dev)
+        for k in range(30):
+            s.obstacle_step_dev(8, st, torch.from_numpy(noise[:, k].copy()).to(dev), 0.1, 2.0, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(st.cpu().numpy(), seq[:, k + 1])
+        det = torch.from_numpy(GOLD["pred_states"][:10].copy()).to(dev)
+        s.obstacle_step_dev(10, det, None, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(det.cpu().numpy(), GOLD["step_det"][:10])
+
+
+def test_shift_reset_plant(env):
+    mpc_gpu, orc = env
+    N, B = 20, 37
+    cfg = orc.config(N, 3, 2.0)
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(B, N + 1, 5)); U = rng.normal(size=(B, N, 2))
+    with mpc_gpu.BatchedMpc(N, 3, 2.0, max_batch=B) as s:
+        s.set_warmstart(X, U); s.shift(B); Xs, Us = s.get_traj(B)
+        for b in range(B):
+            xr, ur = orc.shift(cfg, X[b], U[b])
+            assert np.array_equal(Xs[b], xr) and np.array_equal(Us[b], ur)
+        x0 = rng.normal(size=(B, 5))
+        s.reset_guess(x0); Xr, Ur = s.get_traj(B)
+        assert (Ur == 0).all() and (Xr[:, :, :3] == x0[:, None, :3]).all() and (Xr[:, :, 3:] == 0).all()
+        x = np.column_stack([rng.uniform(-7, 7, (B, 2)), rng.uniform(-6, 6, B), rng.uniform(-10, 10, (B, 2))]); u = rng.uniform(-8, 8, (B, 2))
+        xn = s.plant_step(x, u)
+        want = np.stack([orc.dynamics(x[b], u[b], 0.1)[0] for b in range(B)])
+        assert np.abs(xn - want).max() < 1e-13
+
+
+def test_python_solve_surface_scalar_and_batched(env):
+    """solve(x0, obstacles, ref) -> u*: Obstacle objects, state arrays and explicit P all give the oracle's control"""
+    mpc_gpu, orc = env
+    from mpc_gpu import world as W
+    np.random.seed(0)
+    obstacles = W.generate_random_moving_obstacles("RANDOM", False, n_obst=3)
+    x0 = np.array([-6.0, -6.0, np.pi / 4, 0, 0]); ref = np.array([6.0, 6.0])
+    cfg = orc.config(20, 3, 2.0, qp_tol=1e-8)
+    P = orc.predict_params(cfg, W.obstacle_states(obstacles))
+    Xg, Ug = orc.initial_guess(cfg, x0)
+    want = orc.rti_solve(cfg, x0, P, ref, Xg, Ug)["u0"]
+    u1 = mpc_gpu.solve(x0, obstacles, ref, reset=True)
+    u2 = mpc_gpu.solve(x0, W.obstacle_states(obstacles), ref, reset=True)
+    u3 = mpc_gpu.solve(x0, P, ref, reset=True)
+    for u in (u1, u2, u3):
+        assert u.shape == (2,) and np.abs(u - want).max() < 8e-6
+    xb, gb, ob = random_batch(16, 3, seed=2)
+    ub = mpc_gpu.solve(xb, ob, gb, reset=True, full_output=True)
+    assert ub["u0"].shape == (16, 2) and ub["status"].shape == (16,)
+    with pytest.raises(ValueError):
+        mpc_gpu.get_solver(20, 3, 2.0, max_batch=16).solve(xb, ob[:, :2], gb)
+
+
+def test_reference_step_loop_on_the_shims(env):
+    """RobotOcpProblem.step (robot_ocp_problem.py:168-277) on the acados-shaped shims: free-space run reaches the goal,
+    and its first control equals the oracle's for the same scenario"""
+    mpc_gpu, orc = env
+    np.random.seed(3)
+    prob = mpc_gpu.RobotOcpProblem(np.array([-6.0, -6.0, np.pi / 4, 0, 0]), np.array([6.0, 6.0]), scenario="EDGE", N=20, Tf=2.0,
+                                   n_obst=3, init_guess_when_error=True)
+    for o in prob.obstacles:               # park the obstacles far from the diagonal
+        o.x, o.y, o.vx, o.vy = -7.0, 7.0, 0.0, 0.0
+    x_last, hit, reached, min_margin, dist, iters, oob = prob.step(300)
+    assert reached and not hit and not oob and iters < 200 and dist <= 0.15
+    cfg = orc.config(20, 3, 2.0, qp_tol=1e-8)
+    x0 = np.array([-6.0, -6.0, np.pi / 4, 0, 0])
+    Xg, Ug = orc.initial_guess(cfg, x0)
+    want = orc.rti_solve(cfg, x0, orc.predict_params(cfg, np.array([[-7.0, 7.0, 0, 0]] * 3)), np.array([6.0, 6.0]), Xg, Ug)["u0"]
+    assert np.abs(prob.simU[0] - want).max() < 8e-6

@@ -1,0 +1,79 @@
+"""Host-side mirror of the reference interface (no GPU needed): shims' set/get plumbing, argument handling, sharding."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shim_set_get_plumbing(built):
+    from mpc_gpu.acados_shim import AcadosOcpSolverShim, AcadosSimSolverShim
+
+    class Fake:            # stands in for the device handle: the plumbing under test never launches anything
+        pass
+    s = AcadosOcpSolverShim(N=6, n_obst=3, Tf=0.6, mpc=Fake())
+    s.set(2, "x", [1, 2, 3, 4, 5]); s.set(1, "u", [0.5, -0.5])
+    assert (s.get(2, "x") == [1, 2, 3, 4, 5]).all() and (s.get(1, "u") == [0.5, -0.5]).all()
+    g = s.get(2, "x"); g[:] = 0
+    assert s.get(2, "x")[0] == 1                                   # get returns copies, like acados
+    s.set(3, "p", [1, 2, 3, 4, 5, 6])                              # p = [o0x, o0y, o1x, ...], :166
+    assert (s.P[3] == [[1, 2], [3, 4], [5, 6]]).all()
+    s.set_params_sparse(3, [0, 5], [9, 8])                         # :165
+    assert s.P[3, 0, 0] == 9 and s.P[3, 2, 1] == 8
+    s.set(0, "lbx", [1, 1, 0, 0, 0]); s.set(0, "ubx", [1, 1, 0, 0, 0])
+    assert (s.x0 == [1, 1, 0, 0, 0]).all()
+    with pytest.raises(ValueError):
+        s.set(1, "lbx", np.zeros(5))
+    s.cost_set(6, "yref", [3, 4, 0, 0, 0])                         # set_subgoal's 5-vector (:284): position only
+    assert (s.goal == [3, 4]).all()
+    a = s.slack_schedule()                                         # :145-152
+    assert a[0] == pytest.approx(1e4 * ((1 - 3) ** 2 + (1 - 4) ** 2 + 50)) and a[-1] == 0
+    s.reset()
+    assert (s.X == 0).all() and (s.U == 0).all()
+    sim = AcadosSimSolverShim(Fake())
+    sim.set("x", [1, 2, 3, 4, 5]); sim.set("u", [1, 1])
+    assert (sim.get("x") == [1, 2, 3, 4, 5]).all()
+
+
+def test_shard_slices_cover_the_batch(built):
+    from mpc_gpu.sharding import shard_slice
+    for total, world in ((262144, 8), (32768, 8), (1000, 3), (7, 8)):
+        sl = [shard_slice(total, r, world) for r in range(world)]
+        assert sl[0][0] == 0 and sl[-1][1] == total and all(sl[i][1] == sl[i + 1][0] for i in range(world - 1))
+    assert shard_slice(262144, 3, 8) == (3 * 32768, 4 * 32768)     # C4: contiguous 32768 per GPU
+
+
+WORKER = r'''
+import os, sys
+sys.path[:0] = [%r, %r]
+import torch, torch.distributed as dist
+from mpc_gpu.sharding import shard_slice, gather_costs, gather_costs_ragged
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+total = 10
+lo, hi = shard_slice(total, rank, world)
+cost = torch.arange(lo, hi, dtype=torch.float64) * 1.5          # this rank's per-scenario costs
+full, _ = gather_costs(cost)
+assert torch.equal(full, torch.arange(total, dtype=torch.float64) * 1.5), full
+out, work = gather_costs(cost, async_op=True); work.wait()
+assert torch.equal(out, full)
+lo, hi = shard_slice(7, rank, world)                             # ragged: 4 + 3
+rag = gather_costs_ragged(torch.arange(lo, hi, dtype=torch.float64), [4, 3])
+assert torch.equal(rag, torch.arange(7, dtype=torch.float64)), rag
+dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_cost_allgather_world_size_2_gloo(built, tmp_path):
+    """N>1 path on CPU: two processes, gloo backend, contiguous shards + all-gather of per-scenario costs"""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % (ROOT, os.path.join(ROOT, "dynamic-obstacle-avoidance-mpc_amd")))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", MPC_GPU_NO_TORCH="")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", str(script)], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok") == 2

@@ -1,0 +1,169 @@
+"""Solver-independent checks of the oracle (SURVEY.md section 4 test plan (i)-(ii)): GL4 collocation identity, finite
+differences, scipy on the assembled QP, explicit KKT residuals, closed-loop sanity.  CPU only."""
+import numpy as np
+import pytest
+from scipy.optimize import Bounds, LinearConstraint, minimize
+
+from helpers import oracle_P, oracle_guess, random_batch
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def test_closed_form_equals_gl4_collocation(orc):
+    """IRK Gauss-Legendre(4 stages, 1 step, 3 Newton) == closed-form psi,v,omega + 4-point quadrature"""
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        x = np.array([*rng.uniform(-7, 7, 2), rng.uniform(-6, 6), *rng.uniform(-10, 10, 2)])
+        u = rng.uniform(-8, 8, 2)
+        a = orc.dynamics(x, u, 0.1); b = orc.dynamics_collocation(x, u, 0.1, 3)
+        for p, q in zip(a, b):
+            assert np.abs(p - q).max() < 1e-13
+    # 2 Newton iterations are already exact, 1 is not (triangular structure)
+    assert all(np.abs(p - q).max() < 1e-14 for p, q in zip(orc.dynamics_collocation(x, u, 0.1, 2), b))
+    assert np.abs(orc.dynamics_collocation(x, u, 0.1, 1)[0] - b[0]).max() > 1e-6
+
+
+def test_jacobians_vs_finite_differences(orc):
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        x = np.array([*rng.uniform(-7, 7, 2), rng.uniform(-3, 3), *rng.uniform(-5, 5, 2)]); u = rng.uniform(-8, 8, 2)
+        f0, A, B = orc.dynamics(x, u, 0.1)
+        for k in range(5):
+            e = np.zeros(5); e[k] = 1e-6
+            fd = (orc.dynamics(x + e, u, 0.1)[0] - orc.dynamics(x - e, u, 0.1)[0]) / 2e-6
+            assert np.abs(fd - A[:, k]).max() < 1e-8
+        for k in range(2):
+            e = np.zeros(2); e[k] = 1e-6
+            fd = (orc.dynamics(x, u + e, 0.1)[0] - orc.dynamics(x, u - e, 0.1)[0]) / 2e-6
+            assert np.abs(fd - B[:, k]).max() < 1e-8
+
+
+def test_linearize_blocks(orc):
+    N, no = 6, 3
+    cfg = orc.config(N, no, 0.6)
+    x0, goal, obst = random_batch(1, no, seed=2)
+    P = oracle_P(orc, cfg, obst)[0]
+    rng = np.random.default_rng(3)
+    X = rng.uniform(-5, 5, (N + 1, 5)); U = rng.uniform(-3, 3, (N, 2))
+    L = orc.linearize(cfg, x0[0], P, goal[0], X, U)
+    for i in range(N):
+        xn, A, B = orc.dynamics(X[i], U[i], 0.1)
+        assert np.allclose(L["A"][i], A, atol=1e-13) and np.allclose(L["B"][i], B, atol=1e-13)   # dt = 0.6/6 vs 0.1: one ulp
+        assert np.allclose(L["b"][i], xn - X[i + 1], atol=1e-13)
+    # LINEAR_LS gradient: dt * V' W (y - yref), robot_ocp_problem.py:59-83
+    i = 2
+    assert L["q"][i] == pytest.approx([0.1 * 0.15 * U[i, 0], 0.1 * 0.15 * U[i, 1], 0.1 * 2 * (X[i, 0] - goal[0, 0]),
+                                       0.1 * 2 * (X[i, 1] - goal[0, 1]), 0.0, 0.1 * 2 * X[i, 3], 0.1 * 2 * X[i, 4]])
+    assert L["q"][N][2:] == pytest.approx([5 * (X[N, 0] - goal[0, 0]), 5 * (X[N, 1] - goal[0, 1]), 0, 5 * X[N, 3], 5 * X[N, 4]])
+    # h_j = (x - px)^2 + (y - py)^2 - 2.4^2, robot_model.py:62
+    assert L["h"][i, 1] == pytest.approx((X[i, 0] - P[i, 1, 0]) ** 2 + (X[i, 1] - P[i, 1, 1]) ** 2 - 2.4 ** 2)
+    assert L["dh"][i, 1] == pytest.approx([2 * (X[i, 0] - P[i, 1, 0]), 2 * (X[i, 1] - P[i, 1, 1])])
+
+
+def test_slack_schedule_and_shift_and_guess(orc):
+    cfg = orc.config(20, 3, 2.0)
+    x0 = np.array([-7.0, -7.0, 0.7, 0.0, 0.0]); goal = np.array([7.0, 7.0])
+    a = orc.slack_alpha(cfg, x0, goal)
+    assert a[0] == pytest.approx(1e4 * (2 * 14 ** 2 + 50)) and a[20] == 0.0 and a[10] == pytest.approx(a[0] / 2)   # :145-152
+    X, U = orc.initial_guess(cfg, np.array([1.0, 2.0, 0.3, 4.0, 5.0]))
+    assert (X == [1.0, 2.0, 0.3, 0.0, 0.0]).all() and (U == 0).all()                                                   # :301-306
+    X = np.arange(21 * 5, dtype=float).reshape(21, 5); U = np.arange(40, dtype=float).reshape(20, 2) + 1
+    Xs, Us = orc.shift(cfg, X, U)
+    assert (Xs[:20] == X[1:]).all() and (Xs[20] == X[20]).all() and (Us[:19] == U[1:]).all() and (Us[19] == 0).all()   # :253-258
+
+
+def _scipy_qp(q):
+    nv, ns = q["H"].shape[0], len(q["hs"])
+    n = nv + ns
+    H = np.zeros((n, n)); H[:nv, :nv] = q["H"]; H[nv:, nv:] = np.diag(q["Zs"])
+    g = np.concatenate([q["g"], q["zs"]])
+    Aeq = np.hstack([q["Aeq"], np.zeros((q["Aeq"].shape[0], ns))])
+    Cin = np.hstack([q["Cs"], np.eye(ns)])
+    lb = np.concatenate([q["lb"], np.zeros(ns)]); ub = np.concatenate([q["ub"], np.full(ns, np.inf)])
+    r = minimize(lambda x: 0.5 * x @ H @ x + g @ x, np.zeros(n), jac=lambda x: H @ x + g, hess=lambda x: H, method="trust-constr",
+                 constraints=[LinearConstraint(Aeq, q["beq"], q["beq"]), LinearConstraint(Cin, -q["hs"], np.inf)],
+                 bounds=Bounds(lb, ub), options=dict(gtol=1e-12, xtol=1e-14, barrier_tol=1e-12, maxiter=3000))
+    return r.x[:nv]
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_qp_solution_matches_scipy(orc, case):
+    """the interior point's answer on the assembled QP agrees with an unrelated solver (scipy trust-constr)"""
+    N, no = 5, 2
+    cfg = orc.config(N, no, 0.5)
+    if case == 0:      # robot inside two obstacles' margins, input saturating
+        x0 = np.array([0.0, 0.0, 0.3, 1.0, 0.1]); goal = np.array([3.0, 1.0])
+        obst = np.array([[1.6, 0.8, -0.5, 0.2], [2.0, -2.0, 0.3, 0.5]])
+    elif case == 1:    # free space
+        x0 = np.array([-3.0, 2.0, -1.0, 0.5, 0.0]); goal = np.array([0.0, 0.0])
+        obst = np.array([[6.0, 6.0, 0.0, 0.0], [-6.0, -6.0, 0.0, 0.0]])
+    else:              # state box active (v at the bound region, x near the wall)
+        x0 = np.array([6.3, 0.0, 0.0, 3.0, 0.0]); goal = np.array([-5.0, 0.0])
+        obst = np.array([[0.0, 3.0, 0.0, -1.0], [0.0, -3.0, 0.0, 1.0]])
+    P = orc.predict_params(cfg, obst)
+    X, U = orc.initial_guess(cfg, x0)
+    X[:, 0] += np.linspace(0, 0.3, N + 1); U[:, 0] = 0.5
+    r = orc.rti_solve(cfg, x0, P, goal, X, U)
+    assert r["status"] == 0
+    v = _scipy_qp(orc.export_qp(cfg, x0, P, goal, X, U))
+    dX, dU = r["X"] - X, r["U"] - U
+    v_or = np.concatenate([np.concatenate([dU[i], dX[i + 1]]) for i in range(N)])
+    assert np.abs(v - v_or).max() < 5e-6       # scipy's own accuracy is the limit here
+
+
+def test_kkt_residuals_small_on_random_batch(orc):
+    N, no, B = 20, 3, 64
+    cfg = orc.config(N, no, 2.0, qp_tol=1e-8)
+    x0, goal, obst = random_batch(B, no, seed=4)
+    P = oracle_P(orc, cfg, obst); X, U = oracle_guess(orc, cfg, x0)
+    n_ok = 0
+    for b in range(B):
+        r = orc.rti_solve(cfg, x0[b], P[b], goal[b], X[b], U[b])
+        if r["status"] == 0:
+            n_ok += 1
+            stat, eq, ineq, comp = r["kkt"]
+            assert eq < 1e-8 and ineq < 1e-8 and comp < 1e-8
+            assert stat < 1e-4          # reported, not gated: rounding floor ~ eps * lam^2 |z| / mu (oracle header)
+            assert np.abs(r["X"][0] - x0[b]).max() < 1e-12          # lbx_0 = ubx_0 = x0
+            assert (np.abs(r["U"]) <= 8 + 1e-9).all()
+    assert n_ok >= B - 2
+
+
+def test_tighter_tolerance_moves_the_solution_little(orc):
+    x0, goal, obst = random_batch(32, 3, seed=6)
+    c8, c11 = orc.config(20, 3, 2.0, qp_tol=1e-8), orc.config(20, 3, 2.0, qp_tol=1e-11)
+    P = oracle_P(orc, c8, obst); X, U = oracle_guess(orc, c8, x0)
+    a, b = orc.rti_solve_batch(c8, x0, P, goal, X, U), orc.rti_solve_batch(c11, x0, P, goal, X, U)
+    ok = (a["status"] == 0) & (b["status"] == 0)
+    assert ok.sum() >= 30 and np.abs(a["X"][ok] - b["X"][ok]).max() < 1e-7
+
+
+def test_closed_loop_reaches_goal_in_free_space(orc):
+    cfg = orc.config(20, 3, 2.0)
+    x0 = np.array([-6.0, -6.0, np.pi / 4, 0.0, 0.0]); goal = np.array([6.0, 6.0])
+    obst = np.array([[-6.0, 6.0, 0, 0], [6.0, -6.0, 0, 0], [-6.5, 6.5, 0, 0.0]])
+    X, U = orc.initial_guess(cfg, x0)
+    for k in range(300):
+        r = orc.rti_solve(cfg, x0, orc.predict_params(cfg, obst), goal, X, U)
+        assert r["status"] == 0
+        x0 = orc.dynamics(x0, r["u0"], 0.1)[0]
+        if np.linalg.norm(x0[:2] - goal) <= 0.15:
+            break
+        X, U = orc.shift(cfg, r["X"], r["U"])
+    assert k < 200
+
+
+def test_cost_definition(orc):
+    cfg = orc.config(4, 3, 0.4)
+    x0 = np.zeros(5); goal = np.array([1.0, 0.0])
+    P = np.tile(np.array([[5.0, 5.0], [0.5, 0.0], [-5.0, 5.0]]), (5, 1, 1))
+    X = np.zeros((5, 5)); U = np.ones((4, 2))
+    a = orc.slack_alpha(cfg, x0, goal)
+    h = (0 - 0.5) ** 2 - 2.4 ** 2
+    v = -h
+    want = 4 * 0.1 * 0.5 * (2 * 1.0 + 0.15 * 2) + 0.5 * 5 * 1.0 + sum(0.1 * a[i] * (v + 0.5 * v * v) for i in range(4))
+    assert orc.cost(cfg, x0, P, goal, X, U) == pytest.approx(want, rel=1e-12)
