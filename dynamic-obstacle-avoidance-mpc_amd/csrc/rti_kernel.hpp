@@ -7,10 +7,11 @@
 // Mapping (v1): ONE INSTANCE PER WAVEFRONT (64 lanes, one workgroup = one wave).
 //   * lane i owns horizon stage i (N+1 <= 64): its linearisation, its inequality rows (multiplier lam, slack t for the
 //     4 input-box, 8 state-box and 2*NOBST soft-obstacle rows live in that lane's REGISTERS for the whole solve);
-//   * the per-stage blocks that the Riccati recursion consumes/produces are staged in LDS (56 N + 26 doubles
-//     per instance: 9.2 KB at N=20, 22.6 KB at N=50), never in HBM;
+//   * the per-stage blocks that the Riccati recursion consumes/produces are staged in LDS (92 N + 27 doubles
+//     per instance: 14.9 KB at N=20, 37 KB at N=50), never in HBM;
 //   * wavefront reductions (max step ratio, complementarity sum / max) are shuffle butterflies;
-//   * the stage recursion itself (backward Riccati, forward rollout) is sequential in the stage index and runs on lane 0,
+//   * the stage recursion (backward Riccati, forward rollout) is sequential in the stage index; inside a stage the
+//     factorisation is spread column-per-lane over 7 lanes (M = H~ + W'PW, wave-uniform P re-broadcast by v_readlane),
 //     hand-expanded for the sparsity of A_i = I + E_i (6 non-trivial entries) and B_i (4 non-trivial entries).
 // HBM traffic is therefore the algorithmic minimum: read x0, goal, P, X, U once, write X, U, u0, cost, status once.
 //
@@ -21,6 +22,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+// Diagnostic build only (-DMPC_PHASE_TIMING, scripts/phase_timing.py): per-phase cycle counts into KParams::trace.
+#ifdef MPC_PHASE_TIMING
+#define MPC_T0() long long t_prev_ = clock64()
+#define MPC_TICK(k) do { const long long t_now_ = clock64(); tacc_[k] += t_now_ - t_prev_; t_prev_ = t_now_; } while (0)
+#else
+#define MPC_T0() do {} while (0)
+#define MPC_TICK(k) do {} while (0)
+#endif
 
 namespace mpc {
 
@@ -121,162 +131,182 @@ struct StageLin {
 
 // LDS carve-up for one instance (doubles)
 struct LdsMap {
-    double *AE, *BE, *BB, *HQ, *GQ, *GX, *KK, *MI, *KV, *ZH;
+    double *AE, *BE, *BB, *WC, *HQ, *GQ, *GX, *KK, *MI, *KV, *ZH;
     __device__ __forceinline__ LdsMap(double *base, int N)
     {
         AE = base;            // [N][6]
         BE = AE + 6 * N;      // [N][4]
         BB = BE + 4 * N;      // [N][5]   dynamics defects b_i of the SQP iterate
-        HQ = BB + 5 * N;      // [N+1][7] barrier-modified Hessian: Ruu0, Ruu1, Qxx, Qyy, Qxy, Qvv, Qww
-        GQ = HQ + 7 * (N + 1);// [N+1][7] linear term: (l_u0, l_u1, cb_x[5]) for the predictor, the rhs difference for the corrector
+        WC = BB + 5 * N;      // [N][7][5] columns of W = [B A]: column c (ua, ual, x, y, psi, v, om) as a 5-vector
+        HQ = WC + 35 * N;     // [N+1][8] barrier-modified Hessian: diagonal in z order (Ruu0, Ruu1, Qxx, Qyy, Qpsi, Qvv, Qww), then Qxy
+        GQ = HQ + 8 * (N + 1);// [N+1][7] linear term: (l_u0, l_u1, cb_x[5]) for the predictor, the rhs difference for the corrector
         GX = GQ + 7 * (N + 1);// [N+1][5] local Lagrangian gradient (H z + q - C'lam)_x, input of the costate recursion
         KK = GX + 5 * (N + 1);// [N][10]  feedback gains K (2 x 5)
         MI = KK + 10 * N;     // [N][3]   LDL' factors of Muu: 1/d0, l, 1/d1
         KV = MI + 3 * N;      // [N][2]   feed-forward k
         ZH = KV + 2 * N;      // [N+1][7] Newton step dz = (du, dx)
     }
-    static __host__ __device__ constexpr int doubles(int N) { return 56 * N + 26; }
+    static __host__ __device__ constexpr int doubles(int N) { return 92 * N + 27; }
 };
 
-// Backward Riccati + forward rollout on ONE lane.
-// FACTOR = true  (predictor): factorise, run the costate recursion, use the affine terms rs * b_i and rs * d0;
-// FACTOR = false (corrector): reuse K and Muu^-1, homogeneous dynamics, linear term GQ only.
-template <bool FACTOR>
-__device__ __forceinline__ void stage_recursion(const LdsMap L, int N, double dt, double h2, double Hpsi, double HpsiN, const double d0[5], double rs)
+// wave-uniform copy of lane `src`'s value (v_readlane_b32 x2 -> SGPR pair)
+__device__ __forceinline__ double bcast(double v, int src)
 {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ StageLin load_stage_lin(const LdsMap L, int i, double dt, double h2)
+{
+    StageLin S;
+    const double *ae = L.AE + 6 * i, *be = L.BE + 4 * i;
+    S.a02 = ae[0]; S.a03 = ae[1]; S.a04 = ae[2]; S.a12 = ae[3]; S.a13 = ae[4]; S.a14 = ae[5];
+    S.b00 = be[0]; S.b01 = be[1]; S.b10 = be[2]; S.b11 = be[3]; S.dt = dt; S.h2 = h2;
+    return S;
+}
+
+// Backward Riccati factorisation + predictor right-hand side, COLUMN-PER-LANE: lane c < 7 owns column c of
+// M = H~ + W'PW (z order ua, ual, x, y, psi, v, om); lanes >= 7 mirror lane 6.  The cost-to-go Hessian P (15 unique
+// entries), its gradient pv and the costate pi are wave-uniform; after each stage the new P / pv are re-broadcast from
+// the owning lanes with v_readlane.  Muu is solved by LDL' (see DESIGN.md section 2 on why not the closed-form inverse).
+__device__ __forceinline__ void factor_sweep(const LdsMap L, int N, int lane, double dt, double h2, double rs)
+{
+    const int c = lane < 7 ? lane : 6;
     double P[5][5], pv[5], pi[5];
     {
-        const double *hq = L.HQ + 7 * N, *gq = L.GQ + 7 * N, *gx = L.GX + 5 * N;
-        if (FACTOR) {
+        const double *hq = L.HQ + 8 * N, *gq = L.GQ + 7 * N, *gx = L.GX + 5 * N;
 #pragma unroll
-            for (int r = 0; r < 5; r++)
+        for (int r = 0; r < 5; r++)
 #pragma unroll
-                for (int c = 0; c < 5; c++) P[r][c] = 0.0;
-            P[0][0] = hq[2]; P[1][1] = hq[3]; P[0][1] = P[1][0] = hq[4]; P[2][2] = HpsiN; P[3][3] = hq[5]; P[4][4] = hq[6];
+            for (int k = 0; k < 5; k++) P[r][k] = 0.0;
+        P[0][0] = hq[2]; P[1][1] = hq[3]; P[0][1] = P[1][0] = hq[7]; P[2][2] = hq[4]; P[3][3] = hq[5]; P[4][4] = hq[6];
 #pragma unroll
-            for (int c = 0; c < 5; c++) pi[c] = gx[c];
-        }
-#pragma unroll
-        for (int c = 0; c < 5; c++) pv[c] = gq[2 + c];
+        for (int k = 0; k < 5; k++) { pv[k] = gq[2 + k]; pi[k] = gx[k]; }
     }
     for (int i = N - 1; i >= 0; i--) {
-        StageLin S;
+        const StageLin S = load_stage_lin(L, i, dt, h2);
+        double w[5];
         {
-            const double *ae = L.AE + 6 * i, *be = L.BE + 4 * i;
-            S.a02 = ae[0]; S.a03 = ae[1]; S.a04 = ae[2]; S.a12 = ae[3]; S.a13 = ae[4]; S.a14 = ae[5];
-            S.b00 = be[0]; S.b01 = be[1]; S.b10 = be[2]; S.b11 = be[3]; S.dt = dt; S.h2 = h2;
+            const double *wc = L.WC + 35 * i + 5 * c;
+#pragma unroll
+            for (int k = 0; k < 5; k++) w[k] = wc[k];
         }
-        const double *hq = L.HQ + 7 * i, *gq = L.GQ + 7 * i;
-        double g[7];
+        const double hd = L.HQ[8 * i + c], qxy = L.HQ[8 * i + 7];
+        double g = L.GQ[7 * i + c];
+        // stationarity residual of the input block with the costate of the NEXT stage; then this stage's costate
+        {
+            const double wpi = w[0] * pi[0] + w[1] * pi[1] + w[2] * pi[2] + w[3] * pi[3] + w[4] * pi[4];
+            g += (c < 2) ? wpi : 0.0;
+            const double *gx = L.GX + 5 * i;
+            const double n0 = gx[0] + pi[0], n1 = gx[1] + pi[1], n2 = gx[2] + S.dpsi(pi), n3 = gx[3] + S.dv(pi), n4 = gx[4] + S.dom(pi);
+            pi[0] = n0; pi[1] = n1; pi[2] = n2; pi[3] = n3; pi[4] = n4;
+        }
+        // column c of M
+        double T[5];
 #pragma unroll
-        for (int c = 0; c < 7; c++) g[c] = gq[c];
-        double K0[5], K1[5], i00, i01, i11;
-        if (FACTOR) {
-            // stationarity residual of the input block with the costate of the NEXT stage; then this stage's costate
-            g[0] += S.dua(pi); g[1] += S.dual(pi);
-            {
-                const double *gx = L.GX + 5 * i;
-                const double n0 = gx[0] + pi[0], n1 = gx[1] + pi[1], n2 = gx[2] + S.dpsi(pi), n3 = gx[3] + S.dv(pi), n4 = gx[4] + S.dom(pi);
-                pi[0] = n0; pi[1] = n1; pi[2] = n2; pi[3] = n3; pi[4] = n4;
-            }
-            double Tua[5], Tual[5], Tx[5], Ty[5], Tps[5], Tv[5], Tom[5];
+        for (int k = 0; k < 5; k++) T[k] = P[k][0] * w[0] + P[k][1] * w[1] + P[k][2] * w[2] + P[k][3] * w[3] + P[k][4] * w[4];
+        double Mc[7] = {S.dua(T), S.dual(T), T[0], T[1], S.dpsi(T), S.dv(T), S.dom(T)};
 #pragma unroll
-            for (int k = 0; k < 5; k++) {
-                Tua[k] = P[k][0] * S.b00 + P[k][1] * S.b10 + P[k][3] * dt;
-                Tual[k] = P[k][0] * S.b01 + P[k][1] * S.b11 + P[k][2] * h2 + P[k][4] * dt;
-                Tx[k] = P[k][0]; Ty[k] = P[k][1];
-                Tps[k] = P[k][0] * S.a02 + P[k][1] * S.a12 + P[k][2];
-                Tv[k] = P[k][0] * S.a03 + P[k][1] * S.a13 + P[k][3];
-                Tom[k] = P[k][0] * S.a04 + P[k][1] * S.a14 + P[k][2] * dt + P[k][4];
-            }
-            const double m00 = hq[0] + S.dua(Tua), m01 = S.dua(Tual), m11 = hq[1] + S.dual(Tual);
-            const double mu0[5] = {S.dua(Tx), S.dua(Ty), S.dua(Tps), S.dua(Tv), S.dua(Tom)};
-            const double mu1[5] = {S.dual(Tx), S.dual(Ty), S.dual(Tps), S.dual(Tv), S.dual(Tom)};
-            double M[5][5];
-            M[0][0] = hq[2] + Tx[0]; M[0][1] = hq[4] + Ty[0]; M[0][2] = Tps[0]; M[0][3] = Tv[0]; M[0][4] = Tom[0];
-            M[1][1] = hq[3] + Ty[1]; M[1][2] = Tps[1]; M[1][3] = Tv[1]; M[1][4] = Tom[1];
-            M[2][2] = Hpsi + S.dpsi(Tps); M[2][3] = S.dpsi(Tv); M[2][4] = S.dpsi(Tom);
-            M[3][3] = hq[5] + S.dv(Tv); M[3][4] = S.dv(Tom);
-            M[4][4] = hq[6] + S.dom(Tom);
-            // Muu = L D L' (backward stable).  The closed-form inverse through det = m00 m11 - m01^2 is NOT: when a state
-            // row's barrier weight dominates, B'PB is nearly rank one and the determinant cancels catastrophically.
-            i00 = 1.0 / m00;                 // 1/d0
-            i01 = m01 * i00;                 // l
-            i11 = 1.0 / (m11 - i01 * m01);   // 1/d1
+        for (int r = 0; r < 7; r++) Mc[r] += (r == c) ? hd : 0.0;
+        Mc[3] += (c == 2) ? qxy : 0.0;
+        Mc[2] += (c == 3) ? qxy : 0.0;
+        // the two input rows of M, wave-uniform (lane 0 / lane 1 hold them as columns; M is symmetric)
+        double Mu0[7], Mu1[7];
 #pragma unroll
-            for (int c = 0; c < 5; c++) {
-                const double x1 = (mu1[c] - i01 * mu0[c]) * i11;
-                K1[c] = -x1;
-                K0[c] = -(mu0[c] * i00 - i01 * x1);
-            }
-            // affine part first (it needs the OLD P): Pb = P r_b + p with r_b = rs * b_i
-            double Pb[5];
-            {
-                const double *bb = L.BB + 5 * i;
-                const double b0 = rs * bb[0], b1 = rs * bb[1], b2 = rs * bb[2], b3 = rs * bb[3], b4 = rs * bb[4];
+        for (int r = 0; r < 7; r++) { Mu0[r] = bcast(Mc[r], 0); Mu1[r] = bcast(Mc[r], 1); }
+        const double i00 = 1.0 / Mu0[0];
+        const double l = Mu0[1] * i00;
+        const double i11 = 1.0 / (Mu1[1] - l * Mu0[1]);
+        // gains of this lane's column: K[:, c] = -Muu^{-1} M[u, c]
+        const double x1 = (Mc[1] - l * Mc[0]) * i11;
+        const double K1c = -x1, K0c = -(Mc[0] * i00 - l * x1);
+        // affine part (needs the OLD P): Pb = P r_b + p, r_b = rs * b_i
+        double Pb[5];
+        if (rs != 0.0) {
+            const double *bb = L.BB + 5 * i;
+            const double b0 = rs * bb[0], b1 = rs * bb[1], b2 = rs * bb[2], b3 = rs * bb[3], b4 = rs * bb[4];
 #pragma unroll
-                for (int k = 0; k < 5; k++) Pb[k] = pv[k] + P[k][0] * b0 + P[k][1] * b1 + P[k][2] * b2 + P[k][3] * b3 + P[k][4] * b4;
-            }
-#pragma unroll
-            for (int r = 0; r < 5; r++)
-#pragma unroll
-                for (int c = r; c < 5; c++) {
-                    const double v = M[r][c] + K0[r] * mu0[c] + K1[r] * mu1[c];
-                    P[r][c] = v; P[c][r] = v;
-                }
-            double *kk = L.KK + 10 * i, *mi = L.MI + 3 * i;
-#pragma unroll
-            for (int c = 0; c < 5; c++) { kk[c] = K0[c]; kk[5 + c] = K1[c]; }
-            mi[0] = i00; mi[1] = i01; mi[2] = i11;
-            const double m0 = g[0] + S.dua(Pb), m1 = g[1] + S.dual(Pb);
-            const double mx[5] = {g[2] + Pb[0], g[3] + Pb[1], g[4] + S.dpsi(Pb), g[5] + S.dv(Pb), g[6] + S.dom(Pb)};
-            const double x1 = (m1 - i01 * m0) * i11;
-            const double k0 = -(m0 * i00 - i01 * x1), k1 = -x1;
-            L.KV[2 * i] = k0; L.KV[2 * i + 1] = k1;
-#pragma unroll
-            for (int c = 0; c < 5; c++) pv[c] = mx[c] + K0[c] * m0 + K1[c] * m1;
+            for (int k = 0; k < 5; k++) Pb[k] = pv[k] + P[k][0] * b0 + P[k][1] * b1 + P[k][2] * b2 + P[k][3] * b3 + P[k][4] * b4;
         } else {
-            const double *kk = L.KK + 10 * i, *mi = L.MI + 3 * i;
 #pragma unroll
-            for (int c = 0; c < 5; c++) { K0[c] = kk[c]; K1[c] = kk[5 + c]; }
-            i00 = mi[0]; i01 = mi[1]; i11 = mi[2];
-            const double m0 = g[0] + S.dua(pv), m1 = g[1] + S.dual(pv);
-            const double mx[5] = {g[2] + pv[0], g[3] + pv[1], g[4] + S.dpsi(pv), g[5] + S.dv(pv), g[6] + S.dom(pv)};
-            const double x1 = (m1 - i01 * m0) * i11;
-            const double k0 = -(m0 * i00 - i01 * x1), k1 = -x1;
-            L.KV[2 * i] = k0; L.KV[2 * i + 1] = k1;
-#pragma unroll
-            for (int c = 0; c < 5; c++) pv[c] = mx[c] + K0[c] * m0 + K1[c] * m1;
+            for (int k = 0; k < 5; k++) Pb[k] = pv[k];
         }
+        const double m = g + (w[0] * Pb[0] + w[1] * Pb[1] + w[2] * Pb[2] + w[3] * Pb[3] + w[4] * Pb[4]);
+        const double m0 = bcast(m, 0), m1 = bcast(m, 1);
+        const double kx1 = (m1 - l * m0) * i11;
+        const double k1 = -kx1, k0 = -(m0 * i00 - l * kx1);
+        const double pvc = m + K0c * m0 + K1c * m1;           // lanes c >= 2: entry c-2 of the new cost-to-go gradient
+        // column c-2 of the new cost-to-go Hessian (lanes c >= 2): P+[r][c-2] = M[2+r][c] + K0c M[0][2+r] + K1c M[1][2+r]
+        double Pn[5];
+#pragma unroll
+        for (int r = 0; r < 5; r++) Pn[r] = Mc[2 + r] + K0c * Mu0[2 + r] + K1c * Mu1[2 + r];
+        if (lane >= 2 && lane < 7) { L.KK[10 * i + (lane - 2)] = K0c; L.KK[10 * i + 5 + (lane - 2)] = K1c; }
+        if (lane == 0) { L.MI[3 * i] = i00; L.MI[3 * i + 1] = l; L.MI[3 * i + 2] = i11; L.KV[2 * i] = k0; L.KV[2 * i + 1] = k1; }
+#pragma unroll
+        for (int r = 0; r < 5; r++)
+#pragma unroll
+            for (int cc = r; cc < 5; cc++) { const double v = bcast(Pn[r], 2 + cc); P[r][cc] = v; P[cc][r] = v; }
+#pragma unroll
+        for (int k = 0; k < 5; k++) pv[k] = bcast(pvc, 2 + k);
     }
-    // forward rollout of the Newton step
+}
+
+// Corrector right-hand side: homogeneous system, reuses K and the LDL' factors; wave-uniform (every lane computes the same).
+__device__ __forceinline__ void corrector_sweep(const LdsMap L, int N, int lane, double dt, double h2)
+{
+    double pv[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) pv[k] = L.GQ[7 * N + 2 + k];
+    for (int i = N - 1; i >= 0; i--) {
+        const StageLin S = load_stage_lin(L, i, dt, h2);
+        const double *gq = L.GQ + 7 * i, *kk = L.KK + 10 * i, *mi = L.MI + 3 * i;
+        const double i00 = mi[0], l = mi[1], i11 = mi[2];
+        const double m0 = gq[0] + S.dua(pv), m1 = gq[1] + S.dual(pv);
+        const double mx[5] = {gq[2] + pv[0], gq[3] + pv[1], gq[4] + S.dpsi(pv), gq[5] + S.dv(pv), gq[6] + S.dom(pv)};
+        const double x1 = (m1 - l * m0) * i11;
+        const double k0 = -(m0 * i00 - l * x1), k1 = -x1;
+        if (lane == 0) { L.KV[2 * i] = k0; L.KV[2 * i + 1] = k1; }
+#pragma unroll
+        for (int k = 0; k < 5; k++) pv[k] = mx[k] + kk[k] * m0 + kk[5 + k] * m1;
+    }
+}
+
+// Forward rollout of the Newton step through the stored gains; wave-uniform.  AFFINE: with the terms rs * b_i, rs * d0.
+template <bool AFFINE>
+__device__ __forceinline__ void forward_rollout(const LdsMap L, int N, int lane, double dt, double h2, const double d0[5], double rs)
+{
     double x[5];
 #pragma unroll
-    for (int c = 0; c < 5; c++) x[c] = FACTOR ? rs * d0[c] : 0.0;
+    for (int k = 0; k < 5; k++) x[k] = AFFINE ? rs * d0[k] : 0.0;
     for (int i = 0; i < N; i++) {
         const double *kk = L.KK + 10 * i, *ae = L.AE + 6 * i, *be = L.BE + 4 * i;
         double u0 = L.KV[2 * i], u1 = L.KV[2 * i + 1];
 #pragma unroll
-        for (int c = 0; c < 5; c++) { u0 += kk[c] * x[c]; u1 += kk[5 + c] * x[c]; }
-        double *zh = L.ZH + 7 * i;
-        zh[0] = u0; zh[1] = u1;
+        for (int k = 0; k < 5; k++) { u0 += kk[k] * x[k]; u1 += kk[5 + k] * x[k]; }
+        if (lane == 0) {
+            double *zh = L.ZH + 7 * i;
+            zh[0] = u0; zh[1] = u1;
 #pragma unroll
-        for (int c = 0; c < 5; c++) zh[2 + c] = x[c];
+            for (int k = 0; k < 5; k++) zh[2 + k] = x[k];
+        }
         double xn0 = x[0] + ae[0] * x[2] + ae[1] * x[3] + ae[2] * x[4] + be[0] * u0 + be[1] * u1;
         double xn1 = x[1] + ae[3] * x[2] + ae[4] * x[3] + ae[5] * x[4] + be[2] * u0 + be[3] * u1;
         double xn2 = x[2] + dt * x[4] + h2 * u1;
         double xn3 = x[3] + dt * u0;
         double xn4 = x[4] + dt * u1;
-        if (FACTOR) {
+        if (AFFINE) {
             const double *bb = L.BB + 5 * i;
             xn0 += rs * bb[0]; xn1 += rs * bb[1]; xn2 += rs * bb[2]; xn3 += rs * bb[3]; xn4 += rs * bb[4];
         }
         x[0] = xn0; x[1] = xn1; x[2] = xn2; x[3] = xn3; x[4] = xn4;
     }
-    double *zh = L.ZH + 7 * N;
-    zh[0] = 0.0; zh[1] = 0.0;
+    if (lane == 0) {
+        double *zh = L.ZH + 7 * N;
+        zh[0] = 0.0; zh[1] = 0.0;
 #pragma unroll
-    for (int c = 0; c < 5; c++) zh[2 + c] = x[c];
+        for (int k = 0; k < 5; k++) zh[2 + k] = x[k];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -338,11 +368,20 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         for (int c = 0; c < 4; c++) L.BE[4 * i + c] = be[c];
 #pragma unroll
         for (int c = 0; c < 5; c++) { const double b = xn[c] - xnext[c]; L.BB[5 * i + c] = b; lin0 = fmax(lin0, fabs(b)); }
+        // columns of W = [B A] as 5-vectors, for the column-per-lane factorisation
+        const double wcol[7][5] = {{be[0], be[2], 0.0, dt, 0.0}, {be[1], be[3], h2, 0.0, dt}, {1.0, 0.0, 0.0, 0.0, 0.0}, {0.0, 1.0, 0.0, 0.0, 0.0},
+                                   {ae[0], ae[3], 1.0, 0.0, 0.0}, {ae[1], ae[4], 0.0, 1.0, 0.0}, {ae[2], ae[5], dt, 0.0, 1.0}};
+#pragma unroll
+        for (int cc = 0; cc < 7; cc++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) L.WC[35 * i + 5 * cc + k] = wcol[cc][k];
     }
     if (i == 0) {
 #pragma unroll
         for (int c = 0; c < 5; c++) { d0[c] = x0v[c] - xi[c]; lin0 = fmax(lin0, fabs(d0[c])); }
     }
+#pragma unroll
+    for (int c = 0; c < 5; c++) d0[c] = bcast(d0[c], 0);      // wave-uniform: every lane runs the rollouts
     // Gauss-Newton gradient q and diagonal Hessian, z order (ua, ual, x, y, psi, v, om); robot_ocp_problem.py:59-83
     double q[7], Hd[7];
     if (has_u) {
@@ -413,6 +452,10 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     double rhoPi = 1.0;
     int status = 2, it = 0;
 
+#ifdef MPC_PHASE_TIMING
+    long long tacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    MPC_T0();
     for (it = 0;; it++) {
         // ---- complementarity measures ----
         double msum = 0.0, cmax = 0.0;
@@ -443,9 +486,10 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         if (!(mu == mu) || !(fabs(mu) <= 1e300)) { status = 4; break; }
         if (lin <= p.tol && cmax <= p.tol) { status = 0; break; }
         if (it >= p.iter_max) { status = 2; break; }
+        MPC_TICK(0);
 
         // ---- predictor (sigma = 0): local gradient, barrier terms, reduced Hessian ----
-        double Hq[7] = {Hd[0], Hd[1], Hd[2], Hd[3], 0.0, Hd[5], Hd[6]};   // Ruu0, Ruu1, Qxx, Qyy, Qxy, Qvv, Qww
+        double Hq[8] = {Hd[0], Hd[1], Hd[2], Hd[3], Hd[4], Hd[5], Hd[6], 0.0};   // diagonal in z order, then Qxy
         double gloc[7], cb[7];                                             // (H z + q - C'lam), sum_c c beta_c
 #pragma unroll
         for (int c = 0; c < 7; c++) { gloc[c] = Hd[c] * z[c] + q[c]; cb[c] = 0.0; }
@@ -486,21 +530,26 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                     be1[j] = (l1[j] * t1[j] + l1[j] * rd1[j]) * rt1[j];
                     weff = w1[j]; geff = be1[j];
                 }
-                Hq[2] += weff * ax[j] * ax[j]; Hq[3] += weff * ay[j] * ay[j]; Hq[4] += weff * ax[j] * ay[j];
+                Hq[2] += weff * ax[j] * ax[j]; Hq[3] += weff * ay[j] * ay[j]; Hq[7] += weff * ax[j] * ay[j];
                 gloc[2] -= l1[j] * ax[j]; gloc[3] -= l1[j] * ay[j];
                 cb[2] += geff * ax[j]; cb[3] += geff * ay[j];
             }
         }
         if (act) {
 #pragma unroll
-            for (int c = 0; c < 7; c++) L.HQ[7 * i + c] = Hq[c];
+            for (int c = 0; c < 8; c++) L.HQ[8 * i + c] = Hq[c];
             L.GQ[7 * i + 0] = gloc[0] + cb[0]; L.GQ[7 * i + 1] = gloc[1] + cb[1];
 #pragma unroll
             for (int c = 0; c < 5; c++) { L.GQ[7 * i + 2 + c] = cb[2 + c]; L.GX[5 * i + c] = gloc[2 + c]; }
         }
         __syncthreads();
-        if (lane == 0) stage_recursion<true>(L, N, dt, h2, p.Hd_stage[4], p.Hd_term[2], d0, rhoPi);
+        MPC_TICK(1);
+        factor_sweep(L, N, lane, dt, h2, rhoPi);
         __syncthreads();
+        MPC_TICK(2);
+        forward_rollout<true>(L, N, lane, dt, h2, d0, rhoPi);
+        __syncthreads();
+        MPC_TICK(3);
         double za[7] = {0, 0, 0, 0, 0, 0, 0};
         if (act) {
 #pragma unroll
@@ -558,6 +607,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         sigma = sigma * sigma * sigma;
         if (sigma > 1.0) sigma = 1.0;
         const double smu = sigma * mu;
+        MPC_TICK(4);
 
         // ---- corrector: homogeneous system for the change of right-hand side, d beta_c = (dlam_aff dt_aff - sigma mu) / t ----
         double gc[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -585,8 +635,13 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             for (int c = 0; c < 7; c++) L.GQ[7 * i + c] = gc[c];
         }
         __syncthreads();
-        if (lane == 0) stage_recursion<false>(L, N, dt, h2, p.Hd_stage[4], p.Hd_term[2], d0, 0.0);
+        MPC_TICK(5);
+        corrector_sweep(L, N, lane, dt, h2);
         __syncthreads();
+        MPC_TICK(6);
+        forward_rollout<false>(L, N, lane, dt, h2, d0, 0.0);
+        __syncthreads();
+        MPC_TICK(7);
         double dz[7] = {0, 0, 0, 0, 0, 0, 0};
         if (act) {
 #pragma unroll
@@ -620,10 +675,12 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         rmax = wave_max(rmax);
         const double amax = rmax > 1.0 ? 1.0 / rmax : 1.0;
         const double alpha = (amax >= 1.0) ? 1.0 : 0.995 * amax;
+#ifndef MPC_PHASE_TIMING
         if (p.trace && lane == 0) {
             double *tr = p.trace + ((size_t)inst * p.iter_max + it) * 4;
             tr[0] = mu; tr[1] = sigma; tr[2] = alpha; tr[3] = cmax;
         }
+#endif
         if (!(alpha > 1e-14)) { status = 4; break; }
         // ---- update ----
 #pragma unroll
@@ -647,7 +704,11 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             }
         }
         rhoPi *= (1.0 - alpha);
+        MPC_TICK(8);
     }
+#ifdef MPC_PHASE_TIMING
+    if (p.trace && lane == 0) { for (int k = 0; k < 10; k++) p.trace[((size_t)inst * p.iter_max) * 4 + k] = (double)tacc_[k]; }
+#endif
 
     // ---- full step on the iterate; status 4 leaves it unchanged ----
     if (status != 4) {
