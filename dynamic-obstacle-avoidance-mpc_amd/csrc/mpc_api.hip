@@ -89,7 +89,7 @@ hipStream_t pick(mpc_handle *h, void *stream) { return stream ? (hipStream_t)str
 
 int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
 {
-    const size_t lds = (size_t)mpc::LdsMap::doubles(p.N) * sizeof(double);
+    const size_t lds = 0;
     const dim3 grid(p.batch), block(64);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling && h->ev_used < kMaxEvents) {

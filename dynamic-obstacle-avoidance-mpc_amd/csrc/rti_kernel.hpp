@@ -7,12 +7,12 @@
 // Mapping (v1): ONE INSTANCE PER WAVEFRONT (64 lanes, one workgroup = one wave).
 //   * lane i owns horizon stage i (N+1 <= 64): its linearisation, its inequality rows (multiplier lam, slack t for the
 //     4 input-box, 8 state-box and 2*NOBST soft-obstacle rows live in that lane's REGISTERS for the whole solve);
-//   * the per-stage blocks that the Riccati recursion consumes/produces are staged in LDS (92 N + 27 doubles
-//     per instance: 14.9 KB at N=20, 37 KB at N=50), never in HBM;
+//   * the per-stage blocks that the Riccati recursion consumes/produces (A, B entries, barrier-modified Hessian and
+//     gradient, gains, LDL' factors, Newton step) also live in the owning lane's registers: no LDS, never HBM;
 //   * wavefront reductions (max step ratio, complementarity sum / max) are shuffle butterflies;
-//   * the stage recursion (backward Riccati, forward rollout) is sequential in the stage index; inside a stage the
-//     factorisation is spread column-per-lane over 7 lanes (M = H~ + W'PW, wave-uniform P re-broadcast by v_readlane),
-//     hand-expanded for the sparsity of A_i = I + E_i (6 non-trivial entries) and B_i (4 non-trivial entries).
+//   * the stage recursions (backward Riccati, forward rollout) are sequential in the stage index and run SYSTOLICALLY:
+//     the recursion state (P, p, costate / dx) hops from lane to lane with one-lane DPP wave shifts, in step t only lane t
+//     computes, hand-expanded for the sparsity of A_i = I + E_i (6 non-trivial entries) and B_i (4 non-trivial entries).
 // HBM traffic is therefore the algorithmic minimum: read x0, goal, P, X, U once, write X, U, u0, cost, status once.
 //
 // Interior point method: Mehrotra predictor-corrector in residual ("delta") form.  The costates the stationarity
@@ -97,17 +97,36 @@ __device__ __forceinline__ void dyn_step(const double x[5], const double u[2], d
     }
 }
 
+// Wavefront reductions with DPP (no LDS crossbar, no waits): four row-local butterfly steps, then the four row totals
+// are combined through v_readlane.  The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_value(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_max(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmax(v, dpp_f64<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = fmax(v, dpp_f64<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = fmax(v, dpp_f64<0x141>(v));   // row_half_mirror
+    v = fmax(v, dpp_f64<0x140>(v));   // row_mirror: every lane of a 16-lane row now holds the row's result
+    return fmax(fmax(lane_value(v, 0), lane_value(v, 16)), fmax(lane_value(v, 32), lane_value(v, 48)));
 }
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
 // reciprocal: hardware seed + two Newton steps (1-2 ulp); used for 1/t of the inequality rows
@@ -129,26 +148,6 @@ struct StageLin {
     __device__ __forceinline__ double dom(const double T[5]) const { return a04 * T[0] + a14 * T[1] + dt * T[2] + T[4]; }
 };
 
-// LDS carve-up for one instance (doubles)
-struct LdsMap {
-    double *AE, *BE, *BB, *WC, *HQ, *GQ, *GX, *KK, *MI, *KV, *ZH;
-    __device__ __forceinline__ LdsMap(double *base, int N)
-    {
-        AE = base;            // [N][6]
-        BE = AE + 6 * N;      // [N][4]
-        BB = BE + 4 * N;      // [N][5]   dynamics defects b_i of the SQP iterate
-        WC = BB + 5 * N;      // [N][7][5] columns of W = [B A]: column c (ua, ual, x, y, psi, v, om) as a 5-vector
-        HQ = WC + 35 * N;     // [N+1][8] barrier-modified Hessian: diagonal in z order (Ruu0, Ruu1, Qxx, Qyy, Qpsi, Qvv, Qww), then Qxy
-        GQ = HQ + 8 * (N + 1);// [N+1][7] linear term: (l_u0, l_u1, cb_x[5]) for the predictor, the rhs difference for the corrector
-        GX = GQ + 7 * (N + 1);// [N+1][5] local Lagrangian gradient (H z + q - C'lam)_x, input of the costate recursion
-        KK = GX + 5 * (N + 1);// [N][10]  feedback gains K (2 x 5)
-        MI = KK + 10 * N;     // [N][3]   LDL' factors of Muu: 1/d0, l, 1/d1
-        KV = MI + 3 * N;      // [N][2]   feed-forward k
-        ZH = KV + 2 * N;      // [N+1][7] Newton step dz = (du, dx)
-    }
-    static __host__ __device__ constexpr int doubles(int N) { return 92 * N + 27; }
-};
-
 // wave-uniform copy of lane `src`'s value (v_readlane_b32 x2 -> SGPR pair)
 __device__ __forceinline__ double bcast(double v, int src)
 {
@@ -156,166 +155,193 @@ __device__ __forceinline__ double bcast(double v, int src)
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
 }
-
-__device__ __forceinline__ StageLin load_stage_lin(const LdsMap L, int i, double dt, double h2)
+// DPP whole-wave shifts: from_right(v)[j] = v[j+1] (wave_shl:1), from_left(v)[j] = v[j-1] (wave_shr:1); bound_ctrl makes
+// the end lane read 0, so no "old" operand has to be materialised in front of every DPP move
+__device__ __forceinline__ double from_right(double v)
 {
-    StageLin S;
-    const double *ae = L.AE + 6 * i, *be = L.BE + 4 * i;
-    S.a02 = ae[0]; S.a03 = ae[1]; S.a04 = ae[2]; S.a12 = ae[3]; S.a13 = ae[4]; S.a14 = ae[5];
-    S.b00 = be[0]; S.b01 = be[1]; S.b10 = be[2]; S.b11 = be[3]; S.dt = dt; S.h2 = h2;
-    return S;
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_left(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x138, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
 }
 
-// Backward Riccati factorisation + predictor right-hand side, COLUMN-PER-LANE: lane c < 7 owns column c of
-// M = H~ + W'PW (z order ua, ual, x, y, psi, v, om); lanes >= 7 mirror lane 6.  The cost-to-go Hessian P (15 unique
-// entries), its gradient pv and the costate pi are wave-uniform; after each stage the new P / pv are re-broadcast from
-// the owning lanes with v_readlane.  Muu is solved by LDL' (see DESIGN.md section 2 on why not the closed-form inverse).
-__device__ __forceinline__ void factor_sweep(const LdsMap L, int N, int lane, double dt, double h2, double rs)
+// Riccati factors of one stage, kept in the registers of the lane that owns the stage
+struct StageFac {
+    double K0[5], K1[5];   // feedback gains (2 x 5)
+    double i00, l, i11;    // LDL' of Muu: 1/d0, l, 1/d1
+    double k0, k1;         // feed-forward of the current right-hand side
+};
+
+// SYSTOLIC STAGE RECURSIONS.  Lane t owns stage t and holds that stage's blocks in registers.  The recursion state
+// (cost-to-go Hessian P and gradient q going backward; the state step dx going forward) travels from lane to lane by a
+// one-lane DPP wave shift per stage: in step t only lane t computes (exec-masked), then everything shifts by one lane.
+// No LDS, no barriers, no global traffic inside the interior-point loop.
+//
+// Backward Riccati factorisation + predictor right-hand side.
+//   q_t = gxs + A'(q+ + P+ r_b) + K'(lu + B'(q+ + P+ r_b)) is the cost-to-go gradient INCLUDING the costate of the
+//   current multipliers: gxs = (H z + q - C'lam)_x + (sum_c c beta_c)_x, lu the same for the input block.  It is the
+//   sum of the adjoint (costate) recursion and the Newton right-hand-side recursion, which share the propagator.
+// Terminal lane N: W = 0 and incoming P = 0 give M = H~_N, K = 0, P_N = Q~_N, q_N = gxs, so one code serves all stages.
+__device__ __forceinline__ void systolic_factor(int lane, int N, const StageLin &S, const double Hq[8], double lu0, double lu1,
+                                                const double gxs[5], const double bbr[5], bool affine, StageFac &F)
 {
-    const int c = lane < 7 ? lane : 6;
-    double P[5][5], pv[5], pi[5];
-    {
-        const double *hq = L.HQ + 8 * N, *gq = L.GQ + 7 * N, *gx = L.GX + 5 * N;
+    double P[5][5], qv[5];       // incoming state (valid in lane t at step t); symmetric entries share one value
+    double M[5][5], qo[5];       // outgoing state (upper triangle of M is overwritten with the new P)
 #pragma unroll
-        for (int r = 0; r < 5; r++)
+    for (int r = 0; r < 5; r++) {
+        qv[r] = 0.0; qo[r] = 0.0;
 #pragma unroll
-            for (int k = 0; k < 5; k++) P[r][k] = 0.0;
-        P[0][0] = hq[2]; P[1][1] = hq[3]; P[0][1] = P[1][0] = hq[7]; P[2][2] = hq[4]; P[3][3] = hq[5]; P[4][4] = hq[6];
-#pragma unroll
-        for (int k = 0; k < 5; k++) { pv[k] = gq[2 + k]; pi[k] = gx[k]; }
+        for (int c = 0; c < 5; c++) { P[r][c] = 0.0; M[r][c] = 0.0; }
     }
-    for (int i = N - 1; i >= 0; i--) {
-        const StageLin S = load_stage_lin(L, i, dt, h2);
-        double w[5];
-        {
-            const double *wc = L.WC + 35 * i + 5 * c;
+    const double dt = S.dt, h2 = S.h2;
+    for (int t = N; t >= 0; t--) {
+        if (lane == t) {
+            double mu0[5], mu1[5];
+            // columns x, y of P W are columns 0, 1 of P
+            mu0[0] = S.b00 * P[0][0] + S.b10 * P[1][0] + dt * P[3][0];
+            mu0[1] = S.b00 * P[0][1] + S.b10 * P[1][1] + dt * P[3][1];
+            mu1[0] = S.b01 * P[0][0] + S.b11 * P[1][0] + h2 * P[2][0] + dt * P[4][0];
+            mu1[1] = S.b01 * P[0][1] + S.b11 * P[1][1] + h2 * P[2][1] + dt * P[4][1];
+            M[0][0] = Hq[2] + P[0][0]; M[0][1] = Hq[7] + P[0][1]; M[1][1] = Hq[3] + P[1][1];
+            double m00, m01, m11;
+            {   // column ua
+                double T[5];
 #pragma unroll
-            for (int k = 0; k < 5; k++) w[k] = wc[k];
+                for (int k = 0; k < 5; k++) T[k] = P[k][0] * S.b00 + P[k][1] * S.b10 + P[k][3] * dt;
+                m00 = Hq[0] + S.dua(T);
+            }
+            {   // column ual
+                double T[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) T[k] = P[k][0] * S.b01 + P[k][1] * S.b11 + P[k][2] * h2 + P[k][4] * dt;
+                m01 = S.dua(T); m11 = Hq[1] + S.dual(T);
+            }
+            {   // column psi
+                double T[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) T[k] = P[k][0] * S.a02 + P[k][1] * S.a12 + P[k][2];
+                mu0[2] = S.dua(T); mu1[2] = S.dual(T);
+                M[0][2] = T[0]; M[1][2] = T[1]; M[2][2] = Hq[4] + S.dpsi(T);
+            }
+            {   // column v
+                double T[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) T[k] = P[k][0] * S.a03 + P[k][1] * S.a13 + P[k][3];
+                mu0[3] = S.dua(T); mu1[3] = S.dual(T);
+                M[0][3] = T[0]; M[1][3] = T[1]; M[2][3] = S.dpsi(T); M[3][3] = Hq[5] + S.dv(T);
+            }
+            {   // column om
+                double T[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) T[k] = P[k][0] * S.a04 + P[k][1] * S.a14 + P[k][2] * dt + P[k][4];
+                mu0[4] = S.dua(T); mu1[4] = S.dual(T);
+                M[0][4] = T[0]; M[1][4] = T[1]; M[2][4] = S.dpsi(T); M[3][4] = S.dv(T); M[4][4] = Hq[6] + S.dom(T);
+            }
+            // Muu = L D L' (backward stable; the closed-form inverse through det cancels catastrophically when a state
+            // row's barrier weight makes B'PB nearly rank one)
+            F.i00 = rcp_nr(m00);
+            F.l = m01 * F.i00;
+            F.i11 = rcp_nr(m11 - F.l * m01);
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const double x1 = (mu1[c] - F.l * mu0[c]) * F.i11;
+                F.K1[c] = -x1;
+                F.K0[c] = -(mu0[c] * F.i00 - F.l * x1);
+            }
+            // gradient part (needs the OLD P): qb = q+ + P+ r_b
+            double qb[5];
+            if (affine) {
+#pragma unroll
+                for (int k = 0; k < 5; k++) qb[k] = qv[k] + P[k][0] * bbr[0] + P[k][1] * bbr[1] + P[k][2] * bbr[2] + P[k][3] * bbr[3] + P[k][4] * bbr[4];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 5; k++) qb[k] = qv[k];
+            }
+            const double m0 = lu0 + S.dua(qb), m1 = lu1 + S.dual(qb);
+            const double x1 = (m1 - F.l * m0) * F.i11;
+            F.k1 = -x1; F.k0 = -(m0 * F.i00 - F.l * x1);
+            qo[0] = gxs[0] + qb[0] + F.K0[0] * m0 + F.K1[0] * m1;
+            qo[1] = gxs[1] + qb[1] + F.K0[1] * m0 + F.K1[1] * m1;
+            qo[2] = gxs[2] + S.dpsi(qb) + F.K0[2] * m0 + F.K1[2] * m1;
+            qo[3] = gxs[3] + S.dv(qb) + F.K0[3] * m0 + F.K1[3] * m1;
+            qo[4] = gxs[4] + S.dom(qb) + F.K0[4] * m0 + F.K1[4] * m1;
+            // new cost-to-go Hessian in place: P = Mxx + K'Mux (upper triangle)
+#pragma unroll
+            for (int r = 0; r < 5; r++)
+#pragma unroll
+                for (int c = r; c < 5; c++) M[r][c] += F.K0[r] * mu0[c] + F.K1[r] * mu1[c];
         }
-        const double hd = L.HQ[8 * i + c], qxy = L.HQ[8 * i + 7];
-        double g = L.GQ[7 * i + c];
-        // stationarity residual of the input block with the costate of the NEXT stage; then this stage's costate
-        {
-            const double wpi = w[0] * pi[0] + w[1] * pi[1] + w[2] * pi[2] + w[3] * pi[3] + w[4] * pi[4];
-            g += (c < 2) ? wpi : 0.0;
-            const double *gx = L.GX + 5 * i;
-            const double n0 = gx[0] + pi[0], n1 = gx[1] + pi[1], n2 = gx[2] + S.dpsi(pi), n3 = gx[3] + S.dv(pi), n4 = gx[4] + S.dom(pi);
-            pi[0] = n0; pi[1] = n1; pi[2] = n2; pi[3] = n3; pi[4] = n4;
+        // hand the state to the lane on the left (stage t-1)
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            qv[r] = from_right(qo[r]);
+#pragma unroll
+            for (int c = r; c < 5; c++) { const double v = from_right(M[r][c]); P[r][c] = v; P[c][r] = v; }
         }
-        // column c of M
-        double T[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) T[k] = P[k][0] * w[0] + P[k][1] * w[1] + P[k][2] * w[2] + P[k][3] * w[3] + P[k][4] * w[4];
-        double Mc[7] = {S.dua(T), S.dual(T), T[0], T[1], S.dpsi(T), S.dv(T), S.dom(T)};
-#pragma unroll
-        for (int r = 0; r < 7; r++) Mc[r] += (r == c) ? hd : 0.0;
-        Mc[3] += (c == 2) ? qxy : 0.0;
-        Mc[2] += (c == 3) ? qxy : 0.0;
-        // the two input rows of M, wave-uniform (lane 0 / lane 1 hold them as columns; M is symmetric)
-        double Mu0[7], Mu1[7];
-#pragma unroll
-        for (int r = 0; r < 7; r++) { Mu0[r] = bcast(Mc[r], 0); Mu1[r] = bcast(Mc[r], 1); }
-        const double i00 = 1.0 / Mu0[0];
-        const double l = Mu0[1] * i00;
-        const double i11 = 1.0 / (Mu1[1] - l * Mu0[1]);
-        // gains of this lane's column: K[:, c] = -Muu^{-1} M[u, c]
-        const double x1 = (Mc[1] - l * Mc[0]) * i11;
-        const double K1c = -x1, K0c = -(Mc[0] * i00 - l * x1);
-        // affine part (needs the OLD P): Pb = P r_b + p, r_b = rs * b_i
-        double Pb[5];
-        if (rs != 0.0) {
-            const double *bb = L.BB + 5 * i;
-            const double b0 = rs * bb[0], b1 = rs * bb[1], b2 = rs * bb[2], b3 = rs * bb[3], b4 = rs * bb[4];
-#pragma unroll
-            for (int k = 0; k < 5; k++) Pb[k] = pv[k] + P[k][0] * b0 + P[k][1] * b1 + P[k][2] * b2 + P[k][3] * b3 + P[k][4] * b4;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 5; k++) Pb[k] = pv[k];
-        }
-        const double m = g + (w[0] * Pb[0] + w[1] * Pb[1] + w[2] * Pb[2] + w[3] * Pb[3] + w[4] * Pb[4]);
-        const double m0 = bcast(m, 0), m1 = bcast(m, 1);
-        const double kx1 = (m1 - l * m0) * i11;
-        const double k1 = -kx1, k0 = -(m0 * i00 - l * kx1);
-        const double pvc = m + K0c * m0 + K1c * m1;           // lanes c >= 2: entry c-2 of the new cost-to-go gradient
-        // column c-2 of the new cost-to-go Hessian (lanes c >= 2): P+[r][c-2] = M[2+r][c] + K0c M[0][2+r] + K1c M[1][2+r]
-        double Pn[5];
-#pragma unroll
-        for (int r = 0; r < 5; r++) Pn[r] = Mc[2 + r] + K0c * Mu0[2 + r] + K1c * Mu1[2 + r];
-        if (lane >= 2 && lane < 7) { L.KK[10 * i + (lane - 2)] = K0c; L.KK[10 * i + 5 + (lane - 2)] = K1c; }
-        if (lane == 0) { L.MI[3 * i] = i00; L.MI[3 * i + 1] = l; L.MI[3 * i + 2] = i11; L.KV[2 * i] = k0; L.KV[2 * i + 1] = k1; }
-#pragma unroll
-        for (int r = 0; r < 5; r++)
-#pragma unroll
-            for (int cc = r; cc < 5; cc++) { const double v = bcast(Pn[r], 2 + cc); P[r][cc] = v; P[cc][r] = v; }
-#pragma unroll
-        for (int k = 0; k < 5; k++) pv[k] = bcast(pvc, 2 + k);
     }
 }
 
-// Corrector right-hand side: homogeneous system, reuses K and the LDL' factors; wave-uniform (every lane computes the same).
-__device__ __forceinline__ void corrector_sweep(const LdsMap L, int N, int lane, double dt, double h2)
+// Corrector right-hand side: homogeneous dynamics, reuses K and the LDL' factors; linear term gc (7) per lane.
+__device__ __forceinline__ void systolic_corrector(int lane, int N, const StageLin &S, const double gc[7], StageFac &F)
 {
-    double pv[5];
+    double pv[5] = {0, 0, 0, 0, 0}, pvo[5] = {0, 0, 0, 0, 0};
+    for (int t = N; t >= 0; t--) {
+        if (lane == t) {
+            const double m0 = gc[0] + S.dua(pv), m1 = gc[1] + S.dual(pv);
+            const double mx[5] = {gc[2] + pv[0], gc[3] + pv[1], gc[4] + S.dpsi(pv), gc[5] + S.dv(pv), gc[6] + S.dom(pv)};
+            const double x1 = (m1 - F.l * m0) * F.i11;
+            F.k1 = -x1; F.k0 = -(m0 * F.i00 - F.l * x1);
 #pragma unroll
-    for (int k = 0; k < 5; k++) pv[k] = L.GQ[7 * N + 2 + k];
-    for (int i = N - 1; i >= 0; i--) {
-        const StageLin S = load_stage_lin(L, i, dt, h2);
-        const double *gq = L.GQ + 7 * i, *kk = L.KK + 10 * i, *mi = L.MI + 3 * i;
-        const double i00 = mi[0], l = mi[1], i11 = mi[2];
-        const double m0 = gq[0] + S.dua(pv), m1 = gq[1] + S.dual(pv);
-        const double mx[5] = {gq[2] + pv[0], gq[3] + pv[1], gq[4] + S.dpsi(pv), gq[5] + S.dv(pv), gq[6] + S.dom(pv)};
-        const double x1 = (m1 - l * m0) * i11;
-        const double k0 = -(m0 * i00 - l * x1), k1 = -x1;
-        if (lane == 0) { L.KV[2 * i] = k0; L.KV[2 * i + 1] = k1; }
+            for (int c = 0; c < 5; c++) pvo[c] = mx[c] + F.K0[c] * m0 + F.K1[c] * m1;
+        }
 #pragma unroll
-        for (int k = 0; k < 5; k++) pv[k] = mx[k] + kk[k] * m0 + kk[5 + k] * m1;
+        for (int r = 0; r < 5; r++) pv[r] = from_right(pvo[r]);
     }
 }
 
-// Forward rollout of the Newton step through the stored gains; wave-uniform.  AFFINE: with the terms rs * b_i, rs * d0.
+// Forward rollout of the Newton step: dx travels left to right, every lane keeps its own (du_t, dx_t) in dz.
+// x_init is the initial-condition residual (meaningful in lane 0); bbr = rs * b_t for the affine (predictor) pass.
 template <bool AFFINE>
-__device__ __forceinline__ void forward_rollout(const LdsMap L, int N, int lane, double dt, double h2, const double d0[5], double rs)
+__device__ __forceinline__ void systolic_rollout(int lane, int N, const StageLin &S, const StageFac &F, const double x_init[5],
+                                                 const double bbr[5], double dz[7])
 {
-    double x[5];
+    double x[5], xo[5] = {0, 0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < 5; k++) x[k] = AFFINE ? rs * d0[k] : 0.0;
-    for (int i = 0; i < N; i++) {
-        const double *kk = L.KK + 10 * i, *ae = L.AE + 6 * i, *be = L.BE + 4 * i;
-        double u0 = L.KV[2 * i], u1 = L.KV[2 * i + 1];
+    for (int c = 0; c < 5; c++) x[c] = AFFINE ? x_init[c] : 0.0;
+    for (int t = 0; t <= N; t++) {
+        if (lane == t) {
+            double u0 = F.k0, u1 = F.k1;
 #pragma unroll
-        for (int k = 0; k < 5; k++) { u0 += kk[k] * x[k]; u1 += kk[5 + k] * x[k]; }
-        if (lane == 0) {
-            double *zh = L.ZH + 7 * i;
-            zh[0] = u0; zh[1] = u1;
+            for (int c = 0; c < 5; c++) { u0 += F.K0[c] * x[c]; u1 += F.K1[c] * x[c]; }
+            dz[0] = u0; dz[1] = u1;
 #pragma unroll
-            for (int k = 0; k < 5; k++) zh[2 + k] = x[k];
+            for (int c = 0; c < 5; c++) dz[2 + c] = x[c];
+            xo[0] = x[0] + S.a02 * x[2] + S.a03 * x[3] + S.a04 * x[4] + S.b00 * u0 + S.b01 * u1;
+            xo[1] = x[1] + S.a12 * x[2] + S.a13 * x[3] + S.a14 * x[4] + S.b10 * u0 + S.b11 * u1;
+            xo[2] = x[2] + S.dt * x[4] + S.h2 * u1;
+            xo[3] = x[3] + S.dt * u0;
+            xo[4] = x[4] + S.dt * u1;
+            if (AFFINE) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) xo[c] += bbr[c];
+            }
         }
-        double xn0 = x[0] + ae[0] * x[2] + ae[1] * x[3] + ae[2] * x[4] + be[0] * u0 + be[1] * u1;
-        double xn1 = x[1] + ae[3] * x[2] + ae[4] * x[3] + ae[5] * x[4] + be[2] * u0 + be[3] * u1;
-        double xn2 = x[2] + dt * x[4] + h2 * u1;
-        double xn3 = x[3] + dt * u0;
-        double xn4 = x[4] + dt * u1;
-        if (AFFINE) {
-            const double *bb = L.BB + 5 * i;
-            xn0 += rs * bb[0]; xn1 += rs * bb[1]; xn2 += rs * bb[2]; xn3 += rs * bb[3]; xn4 += rs * bb[4];
-        }
-        x[0] = xn0; x[1] = xn1; x[2] = xn2; x[3] = xn3; x[4] = xn4;
-    }
-    if (lane == 0) {
-        double *zh = L.ZH + 7 * N;
-        zh[0] = 0.0; zh[1] = 0.0;
 #pragma unroll
-        for (int k = 0; k < 5; k++) zh[2 + k] = x[k];
+        for (int c = 0; c < 5; c++) x[c] = from_left(xo[c]);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// The solve kernel.  grid = batch workgroups of 64 threads; dynamic LDS = LdsMap::doubles(N) * 8 bytes.
+// The solve kernel.  grid = batch workgroups of 64 threads (one wavefront per instance); no LDS.
 // ------------------------------------------------------------------------------------------------------------------
 template <int NOBST>
 __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 {
-    extern __shared__ double lds_raw[];
     const int inst = blockIdx.x;
     if (inst >= p.batch) return;
     const int lane = threadIdx.x;
@@ -324,7 +350,6 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     const bool act = (i <= N);
     const bool has_u = (i < N);
     const bool xb = (i >= 1) && (i < N || p.bx_terminal);
-    const LdsMap L(lds_raw, N);
     const double dt = p.dt, h2 = p.h2;
 
     // ---- load (coalesced: consecutive lanes read consecutive stages of this instance's records) ----
@@ -359,29 +384,21 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     // ---- linearise ----
     double lin0 = 0.0;
     double d0[5] = {0, 0, 0, 0, 0};
+    StageLin S;                    // this stage's non-trivial entries of A = dF/dx, B = dF/du (zero for the terminal lane)
+    S.a02 = S.a03 = S.a04 = S.a12 = S.a13 = S.a14 = S.b00 = S.b01 = S.b10 = S.b11 = 0.0; S.dt = dt; S.h2 = h2;
+    double bb[5] = {0, 0, 0, 0, 0};  // dynamics defect b_i = F(x_i, u_i) - x_{i+1} of the SQP iterate
     if (has_u) {
         double xn[5], ae[6], be[4];
         dyn_step<true>(xi, ui, dt, xn, ae, be);
+        S.a02 = ae[0]; S.a03 = ae[1]; S.a04 = ae[2]; S.a12 = ae[3]; S.a13 = ae[4]; S.a14 = ae[5];
+        S.b00 = be[0]; S.b01 = be[1]; S.b10 = be[2]; S.b11 = be[3];
 #pragma unroll
-        for (int c = 0; c < 6; c++) L.AE[6 * i + c] = ae[c];
-#pragma unroll
-        for (int c = 0; c < 4; c++) L.BE[4 * i + c] = be[c];
-#pragma unroll
-        for (int c = 0; c < 5; c++) { const double b = xn[c] - xnext[c]; L.BB[5 * i + c] = b; lin0 = fmax(lin0, fabs(b)); }
-        // columns of W = [B A] as 5-vectors, for the column-per-lane factorisation
-        const double wcol[7][5] = {{be[0], be[2], 0.0, dt, 0.0}, {be[1], be[3], h2, 0.0, dt}, {1.0, 0.0, 0.0, 0.0, 0.0}, {0.0, 1.0, 0.0, 0.0, 0.0},
-                                   {ae[0], ae[3], 1.0, 0.0, 0.0}, {ae[1], ae[4], 0.0, 1.0, 0.0}, {ae[2], ae[5], dt, 0.0, 1.0}};
-#pragma unroll
-        for (int cc = 0; cc < 7; cc++)
-#pragma unroll
-            for (int k = 0; k < 5; k++) L.WC[35 * i + 5 * cc + k] = wcol[cc][k];
+        for (int c = 0; c < 5; c++) { bb[c] = xn[c] - xnext[c]; lin0 = fmax(lin0, fabs(bb[c])); }
     }
     if (i == 0) {
 #pragma unroll
         for (int c = 0; c < 5; c++) { d0[c] = x0v[c] - xi[c]; lin0 = fmax(lin0, fabs(d0[c])); }
     }
-#pragma unroll
-    for (int c = 0; c < 5; c++) d0[c] = bcast(d0[c], 0);      // wave-uniform: every lane runs the rollouts
     // Gauss-Newton gradient q and diagonal Hessian, z order (ua, ual, x, y, psi, v, om); robot_ocp_problem.py:59-83
     double q[7], Hd[7];
     if (has_u) {
@@ -489,7 +506,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         MPC_TICK(0);
 
         // ---- predictor (sigma = 0): local gradient, barrier terms, reduced Hessian ----
-        double Hq[8] = {Hd[0], Hd[1], Hd[2], Hd[3], Hd[4], Hd[5], Hd[6], 0.0};   // diagonal in z order, then Qxy
+        double Hq[8] = {has_u ? Hd[0] : 1.0, has_u ? Hd[1] : 1.0, Hd[2], Hd[3], Hd[4], Hd[5], Hd[6], 0.0};   // diagonal in z order, then Qxy
         double gloc[7], cb[7];                                             // (H z + q - C'lam), sum_c c beta_c
 #pragma unroll
         for (int c = 0; c < 7; c++) { gloc[c] = Hd[c] * z[c] + q[c]; cb[c] = 0.0; }
@@ -522,7 +539,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                     be2[j] = (l2[j] * t2[j] + l2[j] * rd2[j]) * rt2[j];
                     rs_[j] = zpen * sv[j] + zpen - l1[j] - l2[j];
                     const double D = zpen + w1[j] + w2[j];
-                    rD[j] = 1.0 / D;
+                    rD[j] = rcp_nr(D);
                     weff = w1[j] * (zpen + w2[j]) * rD[j];
                     geff = (be1[j] * (zpen + w2[j]) - w1[j] * (rs_[j] + be2[j])) * rD[j];
                 } else {
@@ -535,26 +552,22 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 cb[2] += geff * ax[j]; cb[3] += geff * ay[j];
             }
         }
-        if (act) {
-#pragma unroll
-            for (int c = 0; c < 8; c++) L.HQ[8 * i + c] = Hq[c];
-            L.GQ[7 * i + 0] = gloc[0] + cb[0]; L.GQ[7 * i + 1] = gloc[1] + cb[1];
-#pragma unroll
-            for (int c = 0; c < 5; c++) { L.GQ[7 * i + 2 + c] = cb[2 + c]; L.GX[5 * i + c] = gloc[2 + c]; }
-        }
-        __syncthreads();
         MPC_TICK(1);
-        factor_sweep(L, N, lane, dt, h2, rhoPi);
-        __syncthreads();
-        MPC_TICK(2);
-        forward_rollout<true>(L, N, lane, dt, h2, d0, rhoPi);
-        __syncthreads();
-        MPC_TICK(3);
-        double za[7] = {0, 0, 0, 0, 0, 0, 0};
-        if (act) {
+        double bbr[5];
 #pragma unroll
-            for (int c = 0; c < 7; c++) za[c] = L.ZH[7 * i + c];
-        }
+        for (int c = 0; c < 5; c++) bbr[c] = rhoPi * bb[c];
+        double x_init[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) x_init[c] = rhoPi * d0[c];
+        StageFac F;
+        double gxs[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) gxs[c] = gloc[2 + c] + cb[2 + c];
+        systolic_factor(lane, N, S, Hq, gloc[0] + cb[0], gloc[1] + cb[1], gxs, bbr, rhoPi != 0.0, F);
+        MPC_TICK(2);
+        double za[7] = {0, 0, 0, 0, 0, 0, 0};
+        systolic_rollout<true>(lane, N, S, F, x_init, bbr, za);
+        MPC_TICK(3);
         // affine step: dt, dlam per row, step ratios, products
         double rmax = 0.0, maff = 0.0;
         double dtl_[NB], dth_[NB], dll_[NB], dlh_[NB];
@@ -630,23 +643,14 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 gc[2] += geff * ax[j]; gc[3] += geff * ay[j];
             }
         }
-        if (act) {
-#pragma unroll
-            for (int c = 0; c < 7; c++) L.GQ[7 * i + c] = gc[c];
-        }
-        __syncthreads();
         MPC_TICK(5);
-        corrector_sweep(L, N, lane, dt, h2);
-        __syncthreads();
+        systolic_corrector(lane, N, S, gc, F);
         MPC_TICK(6);
-        forward_rollout<false>(L, N, lane, dt, h2, d0, 0.0);
-        __syncthreads();
-        MPC_TICK(7);
         double dz[7] = {0, 0, 0, 0, 0, 0, 0};
-        if (act) {
+        systolic_rollout<false>(lane, N, S, F, x_init, bbr, dz);
 #pragma unroll
-            for (int c = 0; c < 7; c++) dz[c] = za[c] + L.ZH[7 * i + c];
-        }
+        for (int c = 0; c < 7; c++) dz[c] += za[c];
+        MPC_TICK(7);
         // ---- combined step ----
         rmax = 0.0;
 #pragma unroll
