@@ -65,26 +65,37 @@ def make_workload(name, batch, N, n_obst, rank=0):
 class Loop:
     """closed-loop state on one GPU"""
 
-    def __init__(self, mpc_gpu, N, n_obst, batch, x0, goal, obst, dev):
+    def __init__(self, mpc_gpu, N, n_obst, batch, x0, goal, obst, dev, episode_len=100):
         self.m = mpc_gpu.BatchedMpc(N, n_obst, 0.1 * N, max_batch=batch, device=dev.index or 0)
         self.B, self.N, self.no = batch, N, n_obst
+        self.k, self.episode_len = 0, episode_len
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         z = lambda *s, dt=torch.float64: torch.zeros(*s, dtype=dt, device=dev)
         self.x0, self.goal, self.obst = t(x0), t(goal), t(obst)
+        self.x0_init, self.obst_init = self.x0.clone(), self.obst.clone()
         self.x1 = z(batch, 5)
         self.P = z(batch, N + 1, n_obst, 2)
         self.X, self.U = z(batch, N + 1, 5), z(batch, N, 2)
         self.u0, self.cost = z(batch, 2), z(batch)
         self.status, self.iters = z(batch, dt=torch.int32), z(batch, dt=torch.int32)
-        self.stream = torch.cuda.current_stream().cuda_stream
+        self.stream = torch.cuda.current_stream().cuda_stream   # the caller runs us under `with torch.cuda.stream(...)`
+        assert self.stream != 0, "run under an explicit torch stream so torch ops and library kernels share one queue"
         self.m.reset_guess_dev(batch, self.x0, self.X, self.U, stream=self.stream)
+
+    def reset(self):
+        """start a new episode: initial scenario, set_initial_guess() (device-to-device copies + one small kernel)"""
+        self.x0.copy_(self.x0_init); self.obst.copy_(self.obst_init)
+        self.m.reset_guess_dev(self.B, self.x0, self.X, self.U, stream=self.stream)
 
     def step(self):
         m, B, s = self.m, self.B, self.stream
+        if self.episode_len and self.k % self.episode_len == 0 and self.k > 0:
+            self.reset()
+        self.k += 1
         m.predict_dev(B, self.obst, self.P, stream=s)
         m.solve_dev(B, self.x0, self.P, self.goal, self.X, self.U, self.u0, self.cost, self.status, self.iters, stream=s)
         m.plant_step_dev(B, self.x0, self.u0, self.x1, stream=s)
-        self.x0, self.x1 = self.x1, self.x0
+        self.x0.copy_(self.x1)
         m.obstacle_step_dev(B * self.no, self.obst, None, stream=s)
         m.shift_dev(B, self.X, self.U, stream=s)
 
@@ -126,8 +137,8 @@ def cpu_baseline(N, n_obst, x0, goal, obst, warm_steps, target_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 1024 for c2, 65536 for c3)")
     ap.add_argument("--horizon", type=int, default=20)
@@ -148,6 +159,7 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))   # one explicit queue for torch ops AND the library's kernels
 
     import __graft_entry__ as g
     g.build()
@@ -177,7 +189,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    loop.m.profile_enable(True)
+    loop.m.profile_enable(True)          # creates its HIP event pool here, outside the timed region
     it_acc = torch.zeros(batch, dtype=torch.int32, device=dev)   # per-instance sums, one tiny in-place add per step
     st_acc = torch.zeros(batch, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()

@@ -26,7 +26,7 @@ int fail(int code, const char *fmt, const char *a = "", const char *b = "")
         if (e_ != hipSuccess) return fail(MPC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-constexpr int kMaxEvents = 8192;
+constexpr int kMaxEvents = 2048;   // solve launches timed per profiling window; later launches are not timed
 
 }  // namespace
 
@@ -87,26 +87,37 @@ int check_batch(mpc_handle *h, int batch)
 
 hipStream_t pick(mpc_handle *h, void *stream) { return stream ? (hipStream_t)stream : h->stream; }
 
+// Lanes per instance: the smallest of {16, 32, 64} with N + 1 < G (an idle lane must separate instances that share a
+// wavefront), unless overridden.  Packing 64/G instances into one wavefront multiplies throughput for large batches
+// and costs a single small batch nothing (the instruction stream has the same length either way).
+int pick_lanes(mpc_handle *h, int batch)
+{
+    (void)batch;
+    const int need = h->cfg.N + 2;
+    int G = need <= 16 ? 16 : (need <= 32 ? 32 : 64);
+    if (h->lanes_override >= G) G = h->lanes_override;
+    return G;
+}
+
 int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
 {
-    const size_t lds = 0;
-    const dim3 grid(p.batch), block(64);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->profiling && h->ev_used < kMaxEvents) {
-        if ((int)h->ev_start.size() <= h->ev_used) {
-            hipEvent_t a, b;
-            HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-            h->ev_start.push_back(a); h->ev_stop.push_back(b);
-        }
+    if (h->profiling && h->ev_used < (int)h->ev_start.size()) {   // pool is created by mpc_profile_enable, never here
         e0 = h->ev_start[h->ev_used]; e1 = h->ev_stop[h->ev_used]; h->ev_used++;
         HIPCHK(hipEventRecord(e0, s));
     }
+    const int G = pick_lanes(h, p.batch);
+    const dim3 grid((p.batch + 64 / G - 1) / (64 / G)), block(64);
+#define MPC_LAUNCH(NO, GG) hipLaunchKernelGGL((mpc::rti_solve_kernel<NO, GG>), grid, block, 0, s, p)
+#define MPC_LAUNCH_G(NO) do { if (G == 16) MPC_LAUNCH(NO, 16); else if (G == 32) MPC_LAUNCH(NO, 32); else MPC_LAUNCH(NO, 64); } while (0)
     switch (h->cfg.n_obst) {
-    case 3: hipLaunchKernelGGL(mpc::rti_solve_kernel<3>, grid, block, lds, s, p); break;
-    case 5: hipLaunchKernelGGL(mpc::rti_solve_kernel<5>, grid, block, lds, s, p); break;
-    case 10: hipLaunchKernelGGL(mpc::rti_solve_kernel<10>, grid, block, lds, s, p); break;
+    case 3: MPC_LAUNCH_G(3); break;
+    case 5: MPC_LAUNCH_G(5); break;
+    case 10: MPC_LAUNCH_G(10); break;
     default: return fail(MPC_ERR_ARG, "n_obst must be 3, 5 or 10");
     }
+#undef MPC_LAUNCH_G
+#undef MPC_LAUNCH
     HIPCHK(hipGetLastError());
     if (e1) HIPCHK(hipEventRecord(e1, s));
     return MPC_OK;
@@ -150,7 +161,7 @@ int mpc_default_config(mpc_config *c, int N, int n_obst, double Tf)
 int mpc_create(const mpc_config *cfg, int device, int max_batch, mpc_handle **out)
 {
     if (!cfg || !out) return fail(MPC_ERR_ARG, "null argument");
-    if (cfg->N < 2 || cfg->N > 63) return fail(MPC_ERR_ARG, "N must be in [2, 63] (one horizon stage per lane of a wavefront)");
+    if (cfg->N < 2 || cfg->N > 62) return fail(MPC_ERR_ARG, "N must be in [2, 62] (one horizon stage per lane, N + 1 < 64)");
     if (cfg->n_obst != 3 && cfg->n_obst != 5 && cfg->n_obst != 10) return fail(MPC_ERR_ARG, "n_obst must be 3, 5 or 10");
     if (max_batch < 1) return fail(MPC_ERR_ARG, "max_batch must be >= 1");
     if (!(cfg->Tf > 0) || !(cfg->qp_tol > 0) || cfg->qp_iter_max < 1) return fail(MPC_ERR_ARG, "Tf, qp_tol, qp_iter_max must be positive");
@@ -417,6 +428,14 @@ int mpc_profile_enable(mpc_handle *h, int on)
     if (!h) return fail(MPC_ERR_ARG, "null handle");
     h->profiling = on ? 1 : 0;
     h->ev_used = 0;
+    if (on) {   // event pool up front, so that no event is created inside a timed region
+        HIPCHK(hipSetDevice(h->device));
+        while ((int)h->ev_start.size() < kMaxEvents) {
+            hipEvent_t a, b;
+            HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+            h->ev_start.push_back(a); h->ev_stop.push_back(b);
+        }
+    }
     return MPC_OK;
 }
 
@@ -454,16 +473,16 @@ int mpc_debug_trace(mpc_handle *h, int enable, int batch, double *host_out)
 int mpc_set_lanes_per_instance(mpc_handle *h, int lanes)
 {
     if (!h) return fail(MPC_ERR_ARG, "null handle");
-    if (lanes != 0 && lanes != 64) return fail(MPC_ERR_ARG, "this build maps one instance per wavefront (lanes = 64)");
+    if (lanes != 0 && lanes != 16 && lanes != 32 && lanes != 64) return fail(MPC_ERR_ARG, "lanes must be 0 (automatic), 16, 32 or 64");
+    if (lanes != 0 && lanes < h->cfg.N + 2) return fail(MPC_ERR_ARG, "lanes per instance must exceed N + 1");
     h->lanes_override = lanes;
     return MPC_OK;
 }
 
 int mpc_get_lanes_per_instance(mpc_handle *h, int batch)
 {
-    (void)batch;
     if (!h) return fail(MPC_ERR_ARG, "null handle");
-    return 64;
+    return pick_lanes(h, batch);
 }
 
 }  // extern "C"

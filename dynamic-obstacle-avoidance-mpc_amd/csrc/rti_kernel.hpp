@@ -4,7 +4,8 @@
 // (src/simulation/robot_ocp_problem.py:195, options :126-132), plus the per-step parameter uploads around it
 // (:145-152 slack schedule, :154-166 obstacle parameters, :191-192 initial-state bounds).  See DESIGN.md.
 //
-// Mapping (v1): ONE INSTANCE PER WAVEFRONT (64 lanes, one workgroup = one wave).
+// Mapping: G LANES PER INSTANCE (G = 64, 32 or 16 with N + 1 < G; one workgroup = one wavefront = 64/G instances that share
+// one instruction stream).
 //   * lane i owns horizon stage i (N+1 <= 64): its linearisation, its inequality rows (multiplier lam, slack t for the
 //     4 input-box, 8 state-box and 2*NOBST soft-obstacle rows live in that lane's REGISTERS for the whole solve);
 //   * the per-stage blocks that the Riccati recursion consumes/produces (A, B entries, barrier-modified Hessian and
@@ -112,21 +113,30 @@ __device__ __forceinline__ double lane_value(double v, int src)
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_max(double v)
+// G = lanes per instance (64, 32 or 16): the reduction is over the G-lane segment the calling lane belongs to.
+template <int G>
+__device__ __forceinline__ double seg_max(double v, int lane)
 {
     v = fmax(v, dpp_f64<0xB1>(v));    // quad_perm [1,0,3,2]
     v = fmax(v, dpp_f64<0x4E>(v));    // quad_perm [2,3,0,1]
     v = fmax(v, dpp_f64<0x141>(v));   // row_half_mirror
     v = fmax(v, dpp_f64<0x140>(v));   // row_mirror: every lane of a 16-lane row now holds the row's result
-    return fmax(fmax(lane_value(v, 0), lane_value(v, 16)), fmax(lane_value(v, 32), lane_value(v, 48)));
+    if (G == 16) return v;
+    const double a = fmax(lane_value(v, 0), lane_value(v, 16)), b = fmax(lane_value(v, 32), lane_value(v, 48));
+    if (G == 32) return lane < 32 ? a : b;
+    return fmax(a, b);
 }
-__device__ __forceinline__ double wave_sum(double v)
+template <int G>
+__device__ __forceinline__ double seg_sum(double v, int lane)
 {
     v += dpp_f64<0xB1>(v);
     v += dpp_f64<0x4E>(v);
     v += dpp_f64<0x141>(v);
     v += dpp_f64<0x140>(v);
-    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+    if (G == 16) return v;
+    const double a = lane_value(v, 0) + lane_value(v, 16), b = lane_value(v, 32) + lane_value(v, 48);
+    if (G == 32) return lane < 32 ? a : b;
+    return a + b;
 }
 
 // reciprocal: hardware seed + two Newton steps (1-2 ulp); used for 1/t of the inequality rows
@@ -177,7 +187,9 @@ struct StageFac {
     double k0, k1;         // feed-forward of the current right-hand side
 };
 
-// SYSTOLIC STAGE RECURSIONS.  Lane t owns stage t and holds that stage's blocks in registers.  The recursion state
+// SYSTOLIC STAGE RECURSIONS.  The lane with stage index t (lane = slot * G + t when several instances share a wavefront) owns
+// stage t and holds that stage's blocks in registers.  N + 1 < G guarantees an idle lane (all-zero outgoing state) between
+// the last stage of one instance and stage 0 of the next, so the shifts never leak state across instances.  The recursion state
 // (cost-to-go Hessian P and gradient q going backward; the state step dx going forward) travels from lane to lane by a
 // one-lane DPP wave shift per stage: in step t only lane t computes (exec-masked), then everything shifts by one lane.
 // No LDS, no barriers, no global traffic inside the interior-point loop.
@@ -187,7 +199,7 @@ struct StageFac {
 //   current multipliers: gxs = (H z + q - C'lam)_x + (sum_c c beta_c)_x, lu the same for the input block.  It is the
 //   sum of the adjoint (costate) recursion and the Newton right-hand-side recursion, which share the propagator.
 // Terminal lane N: W = 0 and incoming P = 0 give M = H~_N, K = 0, P_N = Q~_N, q_N = gxs, so one code serves all stages.
-__device__ __forceinline__ void systolic_factor(int lane, int N, const StageLin &S, const double Hq[8], double lu0, double lu1,
+__device__ __forceinline__ void systolic_factor(int stage, int N, const StageLin &S, const double Hq[8], double lu0, double lu1,
                                                 const double gxs[5], const double bbr[5], bool affine, StageFac &F)
 {
     double P[5][5], qv[5];       // incoming state (valid in lane t at step t); symmetric entries share one value
@@ -200,7 +212,7 @@ __device__ __forceinline__ void systolic_factor(int lane, int N, const StageLin 
     }
     const double dt = S.dt, h2 = S.h2;
     for (int t = N; t >= 0; t--) {
-        if (lane == t) {
+        if (stage == t) {
             double mu0[5], mu1[5];
             // columns x, y of P W are columns 0, 1 of P
             mu0[0] = S.b00 * P[0][0] + S.b10 * P[1][0] + dt * P[3][0];
@@ -287,11 +299,11 @@ __device__ __forceinline__ void systolic_factor(int lane, int N, const StageLin 
 }
 
 // Corrector right-hand side: homogeneous dynamics, reuses K and the LDL' factors; linear term gc (7) per lane.
-__device__ __forceinline__ void systolic_corrector(int lane, int N, const StageLin &S, const double gc[7], StageFac &F)
+__device__ __forceinline__ void systolic_corrector(int stage, int N, const StageLin &S, const double gc[7], StageFac &F)
 {
     double pv[5] = {0, 0, 0, 0, 0}, pvo[5] = {0, 0, 0, 0, 0};
     for (int t = N; t >= 0; t--) {
-        if (lane == t) {
+        if (stage == t) {
             const double m0 = gc[0] + S.dua(pv), m1 = gc[1] + S.dual(pv);
             const double mx[5] = {gc[2] + pv[0], gc[3] + pv[1], gc[4] + S.dpsi(pv), gc[5] + S.dv(pv), gc[6] + S.dom(pv)};
             const double x1 = (m1 - F.l * m0) * F.i11;
@@ -307,14 +319,14 @@ __device__ __forceinline__ void systolic_corrector(int lane, int N, const StageL
 // Forward rollout of the Newton step: dx travels left to right, every lane keeps its own (du_t, dx_t) in dz.
 // x_init is the initial-condition residual (meaningful in lane 0); bbr = rs * b_t for the affine (predictor) pass.
 template <bool AFFINE>
-__device__ __forceinline__ void systolic_rollout(int lane, int N, const StageLin &S, const StageFac &F, const double x_init[5],
+__device__ __forceinline__ void systolic_rollout(int stage, int N, const StageLin &S, const StageFac &F, const double x_init[5],
                                                  const double bbr[5], double dz[7])
 {
     double x[5], xo[5] = {0, 0, 0, 0, 0};
 #pragma unroll
     for (int c = 0; c < 5; c++) x[c] = AFFINE ? x_init[c] : 0.0;
     for (int t = 0; t <= N; t++) {
-        if (lane == t) {
+        if (stage == t) {
             double u0 = F.k0, u1 = F.k1;
 #pragma unroll
             for (int c = 0; c < 5; c++) { u0 += F.K0[c] * x[c]; u1 += F.K1[c] * x[c]; }
@@ -339,14 +351,17 @@ __device__ __forceinline__ void systolic_rollout(int lane, int N, const StageLin
 // ------------------------------------------------------------------------------------------------------------------
 // The solve kernel.  grid = batch workgroups of 64 threads (one wavefront per instance); no LDS.
 // ------------------------------------------------------------------------------------------------------------------
-template <int NOBST>
+template <int NOBST, int G>
 __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 {
-    const int inst = blockIdx.x;
-    if (inst >= p.batch) return;
+    constexpr int IPW = 64 / G;               // instances per wavefront
     const int lane = threadIdx.x;
+    const int slot = lane / G;
+    const int inst_raw = blockIdx.x * IPW + slot;
+    const bool valid = inst_raw < p.batch;    // tail wavefront: surplus slots replay the last instance and store nothing
+    const int inst = valid ? inst_raw : p.batch - 1;
     const int N = p.N;
-    const int i = lane;                       // this lane's stage
+    const int i = lane - slot * G;            // this lane's stage
     const bool act = (i <= N);
     const bool has_u = (i < N);
     const bool xb = (i >= 1) && (i < N || p.bx_terminal);
@@ -461,13 +476,14 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #pragma unroll
     for (int k = 0; k < NB; k++) n_items_lane += vb[k] ? 2 : 0;
     n_items_lane += vs ? (soft ? 2 * NOBST : NOBST) : 0;
-    const double n_items = wave_sum((double)n_items_lane);
+    const double n_items = seg_sum<G>((double)n_items_lane, lane);
     const double inv_items = n_items > 0 ? 1.0 / n_items : 0.0;
-    lin0 = wave_max(lin0);
+    lin0 = seg_max<G>(lin0, lane);
 
     double z[7] = {0, 0, 0, 0, 0, 0, 0};
     double rhoPi = 1.0;
-    int status = 2, it = 0;
+    int status = 2, it = 0, it_done = 0;
+    bool running = true;      // per instance: instances sharing a wavefront stop at their own iteration and then idle
 
 #ifdef MPC_PHASE_TIMING
     long long tacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -496,13 +512,16 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 }
             }
         }
-        msum = wave_sum(msum);
-        cmax = wave_max(cmax);
+        msum = seg_sum<G>(msum, lane);
+        cmax = seg_max<G>(cmax, lane);
         const double mu = msum * inv_items;
         const double lin = rhoPi * lin0;
-        if (!(mu == mu) || !(fabs(mu) <= 1e300)) { status = 4; break; }
-        if (lin <= p.tol && cmax <= p.tol) { status = 0; break; }
-        if (it >= p.iter_max) { status = 2; break; }
+        if (running) {
+            if (!(mu == mu) || !(fabs(mu) <= 1e300)) { status = 4; running = false; it_done = it; }
+            else if (lin <= p.tol && cmax <= p.tol) { status = 0; running = false; it_done = it; }
+            else if (it >= p.iter_max) { status = 2; running = false; it_done = it; }
+        }
+        if (__ballot(running) == 0ull) break;
         MPC_TICK(0);
 
         // ---- predictor (sigma = 0): local gradient, barrier terms, reduced Hessian ----
@@ -563,10 +582,10 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         double gxs[5];
 #pragma unroll
         for (int c = 0; c < 5; c++) gxs[c] = gloc[2 + c] + cb[2 + c];
-        systolic_factor(lane, N, S, Hq, gloc[0] + cb[0], gloc[1] + cb[1], gxs, bbr, rhoPi != 0.0, F);
+        systolic_factor(i, N, S, Hq, gloc[0] + cb[0], gloc[1] + cb[1], gxs, bbr, rhoPi != 0.0, F);
         MPC_TICK(2);
         double za[7] = {0, 0, 0, 0, 0, 0, 0};
-        systolic_rollout<true>(lane, N, S, F, x_init, bbr, za);
+        systolic_rollout<true>(i, N, S, F, x_init, bbr, za);
         MPC_TICK(3);
         // affine step: dt, dlam per row, step ratios, products
         double rmax = 0.0, maff = 0.0;
@@ -603,7 +622,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 rmax = fmax(rmax, fmax(-dt1_[j] * rt1[j], -dl1_[j] * rcp_nr(l1[j])));
             }
         }
-        rmax = wave_max(rmax);
+        rmax = seg_max<G>(rmax, lane);
         const double a_aff = rmax > 1.0 ? 1.0 / rmax : 1.0;
 #pragma unroll
         for (int k = 0; k < NB; k++) if (vb[k])
@@ -615,7 +634,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 if (soft) maff += (l2[j] + a_aff * dl2_[j]) * (t2[j] + a_aff * dt2_[j]);
             }
         }
-        maff = wave_sum(maff) * inv_items;
+        maff = seg_sum<G>(maff, lane) * inv_items;
         double sigma = mu > 0 ? maff / mu : 0.0;
         sigma = sigma * sigma * sigma;
         if (sigma > 1.0) sigma = 1.0;
@@ -644,10 +663,10 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             }
         }
         MPC_TICK(5);
-        systolic_corrector(lane, N, S, gc, F);
+        systolic_corrector(i, N, S, gc, F);
         MPC_TICK(6);
         double dz[7] = {0, 0, 0, 0, 0, 0, 0};
-        systolic_rollout<false>(lane, N, S, F, x_init, bbr, dz);
+        systolic_rollout<false>(i, N, S, F, x_init, bbr, dz);
 #pragma unroll
         for (int c = 0; c < 7; c++) dz[c] += za[c];
         MPC_TICK(7);
@@ -676,17 +695,18 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             dl1_[j] = -(l1[j] * t1[j] - smu + pp1[j] + l1[j] * dt1_[j]) * rt1[j];
             rmax = fmax(rmax, fmax(-dt1_[j] * rt1[j], -dl1_[j] * rcp_nr(l1[j])));
         }
-        rmax = wave_max(rmax);
+        rmax = seg_max<G>(rmax, lane);
         const double amax = rmax > 1.0 ? 1.0 / rmax : 1.0;
         const double alpha = (amax >= 1.0) ? 1.0 : 0.995 * amax;
 #ifndef MPC_PHASE_TIMING
-        if (p.trace && lane == 0) {
+        if (p.trace && i == 0 && valid && running) {
             double *tr = p.trace + ((size_t)inst * p.iter_max + it) * 4;
             tr[0] = mu; tr[1] = sigma; tr[2] = alpha; tr[3] = cmax;
         }
 #endif
-        if (!(alpha > 1e-14)) { status = 4; break; }
-        // ---- update ----
+        if (running && !(alpha > 1e-14)) { status = 4; running = false; it_done = it; }
+        // ---- update (instances that have stopped keep their state) ----
+        if (running) {
 #pragma unroll
         for (int c = 0; c < 7; c++) z[c] += alpha * dz[c];
 #pragma unroll
@@ -708,21 +728,22 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             }
         }
         rhoPi *= (1.0 - alpha);
+        }
         MPC_TICK(8);
     }
 #ifdef MPC_PHASE_TIMING
-    if (p.trace && lane == 0) { for (int k = 0; k < 10; k++) p.trace[((size_t)inst * p.iter_max) * 4 + k] = (double)tacc_[k]; }
+    if (p.trace && i == 0 && valid) { for (int k = 0; k < 10; k++) p.trace[((size_t)inst * p.iter_max) * 4 + k] = (double)tacc_[k]; }
 #endif
 
     // ---- full step on the iterate; status 4 leaves it unchanged ----
-    if (status != 4) {
+    if (status != 4 && valid) {
         if (act) {
 #pragma unroll
             for (int c = 0; c < 5; c++) { xi[c] += z[2 + c]; Xg[i * 5 + c] = xi[c]; }
         }
         if (has_u) { ui[0] += z[0]; ui[1] += z[1]; Ug[i * 2] = ui[0]; Ug[i * 2 + 1] = ui[1]; }
     }
-    if (i == 0 && p.u0) { p.u0[(size_t)inst * 2] = ui[0]; p.u0[(size_t)inst * 2 + 1] = ui[1]; }
+    if (i == 0 && p.u0 && valid) { p.u0[(size_t)inst * 2] = ui[0]; p.u0[(size_t)inst * 2 + 1] = ui[1]; }
     // NLP objective at the returned iterate: LS cost + exact penalty of the obstacle violation
     if (p.cost) {
         double J = 0.0;
@@ -739,12 +760,12 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 J += zpen * (v + 0.5 * v * v);
             }
         }
-        J = wave_sum(J);
-        if (lane == 0) p.cost[inst] = J;
+        J = seg_sum<G>(J, lane);
+        if (i == 0 && valid) p.cost[inst] = J;
     }
-    if (lane == 0) {
+    if (i == 0 && valid) {
         if (p.status) p.status[inst] = status;
-        if (p.iters) p.iters[inst] = it;
+        if (p.iters) p.iters[inst] = it_done;
     }
 }
 

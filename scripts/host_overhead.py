@@ -3,7 +3,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "dynamic-obstacle-avoidance-mpc_amd")]
 import numpy as np, torch
 import bench, mpc_gpu
-dev = torch.device("cuda:0"); torch.cuda.set_device(0)
+dev = torch.device("cuda:0"); torch.cuda.set_device(0); torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 x0, goal, obst, desc = bench.make_workload("c2", 1024, 20, 3)
 loop = bench.Loop(mpc_gpu, 20, 3, 1024, x0, goal, obst, dev)
 for _ in range(5): loop.step()

@@ -13,7 +13,7 @@ _lib.LIB_PATH = so
 import mpc_gpu, bench
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 x0, goal, obst, _ = bench.make_workload("c2" if B <= 4096 else "c3", B, 20, 3)
-dev = torch.device("cuda:0"); torch.cuda.set_device(0)
+dev = torch.device("cuda:0"); torch.cuda.set_device(0); torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 loop = bench.Loop(mpc_gpu, 20, 3, B, x0, goal, obst, dev)
 _lib.check(_lib.lib().mpc_debug_trace(loop.m._h, 1, B, None))
 for _ in range(10): loop.step()

@@ -190,3 +190,28 @@ def test_switches(env):
                dict(bug_compat_predict=0)):
         (g, Xg, Ug, o), = run_pair(mpc_gpu, orc, 20, 3, 2.0, x0, goal, obst, **kw)
         assert_close(g, Xg, Ug, o, allow_status_mismatch=1)
+
+
+def test_lanes_per_instance_packing(env):
+    """2 or 4 instances sharing one wavefront (G = 32 / 16 lanes each) give bitwise the results of one instance per wavefront,
+    also when the batch does not fill the last wavefront and when instances of one wavefront stop at different iterations"""
+    mpc_gpu, orc = env
+    from mpc_gpu import _lib
+    for N, no, B in ((20, 3, 203), (10, 5, 77)):
+        x0, goal, obst = random_batch(B, no, seed=31 + N)
+        res = {}
+        for lanes in (0, 64, 32) + ((16,) if N + 2 <= 16 else ()):
+            with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
+                _lib.check(_lib.lib().mpc_set_lanes_per_instance(s._h, lanes))
+                got = s.lanes_per_instance(B)
+                s.reset_guess(x0); g = s.solve(x0, obst, goal); X, U = s.get_traj(B)
+                res[lanes] = (got, g, X, U)
+        assert res[0][0] == (32 if N == 20 else 16) and res[64][0] == 64
+        assert len(set(res[0][1]["iters"].tolist())) > 3          # mixed iteration counts inside wavefronts
+        for lanes in res:
+            _, g, X, U = res[lanes]
+            assert np.array_equal(X, res[64][2]) and np.array_equal(U, res[64][3])
+            assert np.array_equal(g["iters"], res[64][1]["iters"]) and np.array_equal(g["status"], res[64][1]["status"])
+            assert np.array_equal(g["cost"], res[64][1]["cost"])
+    with mpc_gpu.BatchedMpc(20, 3, 2.0, max_batch=4) as s:
+        assert _lib.lib().mpc_set_lanes_per_instance(s._h, 16) == _lib.MPC_ERR_ARG     # N + 1 = 21 does not fit 16 lanes
