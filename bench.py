@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- MPC solves/s of the RTI hot path on MI355X (contract: see the task statement / DESIGN.md section 6).
 
-A "step" is one closed-loop control step for the whole batch, everything resident in HBM:
+A "step" is one closed-loop control step for the whole batch, everything resident in HBM, ONE kernel launch:
     obstacle look-ahead (a9) -> RTI solve (a10/a11) -> plant step (a14) -> obstacle motion -> warm-start shift (a12)
+Episodes of 100 control steps restart from the initial scenario, so the robots are always en route.
 Workload (default, BASELINE.json configs[1] = "C2"): batch = 1024 identical scenarios, N = 20, Tf = 2 s, 3 moving obstacles
 (positions and velocities of the reference generator's seed-0 RANDOM draw, tests/golden/), x0 = [-6,-6,pi/4,0,0], goal [6,6].
 `--workload c3` runs 65536 randomized scenarios instead.
@@ -65,10 +66,10 @@ def make_workload(name, batch, N, n_obst, rank=0):
 class Loop:
     """closed-loop state on one GPU"""
 
-    def __init__(self, mpc_gpu, N, n_obst, batch, x0, goal, obst, dev, episode_len=100):
+    def __init__(self, mpc_gpu, N, n_obst, batch, x0, goal, obst, dev, episode_len=100, fused=True):
         self.m = mpc_gpu.BatchedMpc(N, n_obst, 0.1 * N, max_batch=batch, device=dev.index or 0)
         self.B, self.N, self.no = batch, N, n_obst
-        self.k, self.episode_len = 0, episode_len
+        self.k, self.episode_len, self.fused = 0, episode_len, fused
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         z = lambda *s, dt=torch.float64: torch.zeros(*s, dtype=dt, device=dev)
         self.x0, self.goal, self.obst = t(x0), t(goal), t(obst)
@@ -88,10 +89,15 @@ class Loop:
         self.m.reset_guess_dev(self.B, self.x0, self.X, self.U, stream=self.stream)
 
     def step(self):
-        m, B, s = self.m, self.B, self.stream
+        """one control step of the whole batch = ONE kernel launch (look-ahead, solve, plant, obstacles, shift fused)"""
         if self.episode_len and self.k % self.episode_len == 0 and self.k > 0:
             self.reset()
         self.k += 1
+        if self.fused:
+            self.m.closed_loop_step_dev(self.B, self.x0, self.obst, self.goal, self.X, self.U, self.u0, self.cost, self.status, self.iters,
+                                        None, stream=self.stream)
+            return
+        m, B, s = self.m, self.B, self.stream
         m.predict_dev(B, self.obst, self.P, stream=s)
         m.solve_dev(B, self.x0, self.P, self.goal, self.X, self.U, self.u0, self.cost, self.status, self.iters, stream=s)
         m.plant_step_dev(B, self.x0, self.u0, self.x1, stream=s)
@@ -190,14 +196,13 @@ def main():
     if world > 1:
         dist.barrier()
     loop.m.profile_enable(True)          # creates its HIP event pool here, outside the timed region
-    it_acc = torch.zeros(batch, dtype=torch.int32, device=dev)   # per-instance sums, one tiny in-place add per step
+    it_acc = torch.zeros(batch, dtype=torch.int32, device=dev)   # summed inside the solve kernel (mpc_set_accumulators)
     st_acc = torch.zeros(batch, dtype=torch.int32, device=dev)
+    loop.m.set_accumulators(it_acc, st_acc)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
-        it_acc.add_(loop.iters)
-        st_acc.add_(loop.status)
     if handle is not None:
         handle.wait()
     torch.cuda.synchronize()
@@ -228,7 +233,7 @@ def main():
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": desc, "per_gpu_batch": batch, "N": N, "n_obst": no, "qp_tol": 1e-8, "qp_iter_max": 50,
-                      "step": "predict + RTI solve + plant step + obstacle step + shift, device resident",
+                      "step": "one fused launch: obstacle look-ahead + RTI solve + plant step + obstacle motion + warm-start shift, device resident; episodes of 100 control steps",
                       "parallelism": f"replicas x{world}, cost all-gather (RCCL)" if world > 1 else "single GPU"},
            "mean_ipm_iters": mean_iters, "instances_with_nonzero_status": int((st_acc != 0).sum().item()),
            "lanes_per_instance": loop.m.lanes_per_instance(batch), "roofline": roof}

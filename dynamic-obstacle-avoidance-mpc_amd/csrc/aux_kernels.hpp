@@ -6,30 +6,6 @@
 
 namespace mpc {
 
-struct World {
-    double xmin, xmax, ymin, ymax;
-    int bug_compat_predict;
-};
-
-// One constant-velocity step with wall reflection, src/utils/visualization.py:35-59.  Plain IEEE operators in the
-// reference's own operation order with FP contraction switched off for this block, so that the look-ahead is bit-exact
-// against numpy (HIP's __dmul_rn/__dadd_rn are inlined plain operators that the backend would still fuse into FMAs).
-__device__ __forceinline__ void obstacle_advance(const World w, double dt, double &x, double &vx, double &y, double &vy)
-{
-#pragma clang fp contract(off)
-    double t_hit;
-    if (vx < 0) t_hit = (x - w.xmin) / fabs(vx);
-    else if (vx > 0) t_hit = (w.xmax - x) / fabs(vx);
-    else t_hit = INFINITY;
-    if (t_hit <= dt) { const double a = vx * t_hit, b = vx * (dt - t_hit); x = x + (a - b); vx = -vx; }
-    else { const double a = vx * dt; x = x + a; }
-    if (vy < 0) t_hit = (y - w.ymin) / fabs(vy);
-    else if (vy > 0) t_hit = (w.ymax - y) / fabs(vy);
-    else t_hit = INFINITY;
-    if (t_hit <= dt) { const double a = vy * t_hit, b = vy * (dt - t_hit); y = y + (a - b); vy = -vy; }
-    else { const double a = vy * dt; y = y + a; }
-}
-
 // Obstacle.predict_trajectory (visualization.py:62-79) for every obstacle of every instance, written straight into the
 // parameter tensor P[B][N+1][n_obst][2] (parameterize_model, robot_ocp_problem.py:154-166).  One thread per obstacle.
 __global__ void predict_kernel(World w, int count, int n_obst, int N, double dt, const double *__restrict__ obst, double *__restrict__ P)
@@ -57,13 +33,7 @@ __global__ void obstacle_step_kernel(World w, int count, double dt, double *__re
     if (t >= count) return;
     double *o = obst + (size_t)t * 4;
     double x = o[0], y = o[1], vx = o[2], vy = o[3];
-    if (noise) {
-        const double nx = noise[(size_t)t * 2], ny = noise[(size_t)t * 2 + 1];
-        const double rx = randomness * nx, ry = randomness * ny;
-        const double fx = 1.0 + rx, fy = 1.0 + ry;
-        vx = fmin(fmax(fx * vx, -vmax), vmax);
-        vy = fmin(fmax(fy * vy, -vmax), vmax);
-    }
+    if (noise) obstacle_noise(randomness, vmax, noise[(size_t)t * 2], noise[(size_t)t * 2 + 1], vx, vy);
     obstacle_advance(w, dt, x, vx, y, vy);
     o[0] = x; o[1] = y; o[2] = vx; o[3] = vy;
 }

@@ -40,6 +40,7 @@ struct mpc_handle {
     int lanes_override;
     int profiling;
     double *d_trace;                  // optional debug trace buffer (mpc_debug_trace)
+    int32_t *d_iters_acc, *d_status_acc;   // optional accumulators (mpc_set_accumulators)
     std::vector<hipEvent_t> ev_start, ev_stop;
     int ev_used;
 };
@@ -101,6 +102,7 @@ int pick_lanes(mpc_handle *h, int batch)
 
 int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
 {
+    p.iters_acc = h->d_iters_acc; p.status_acc = h->d_status_acc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling && h->ev_used < (int)h->ev_start.size()) {   // pool is created by mpc_profile_enable, never here
         e0 = h->ev_start[h->ev_used]; e1 = h->ev_stop[h->ev_used]; h->ev_used++;
@@ -108,7 +110,8 @@ int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
     }
     const int G = pick_lanes(h, p.batch);
     const dim3 grid((p.batch + 64 / G - 1) / (64 / G)), block(64);
-#define MPC_LAUNCH(NO, GG) hipLaunchKernelGGL((mpc::rti_solve_kernel<NO, GG>), grid, block, 0, s, p)
+    const size_t lds = p.obst ? (size_t)(64 / G) * (p.N + 1) * h->cfg.n_obst * 2 * sizeof(double) : 0;   // look-ahead staging
+#define MPC_LAUNCH(NO, GG) hipLaunchKernelGGL((mpc::rti_solve_kernel<NO, GG>), grid, block, lds, s, p)
 #define MPC_LAUNCH_G(NO) do { if (G == 16) MPC_LAUNCH(NO, 16); else if (G == 32) MPC_LAUNCH(NO, 32); else MPC_LAUNCH(NO, 64); } while (0)
     switch (h->cfg.n_obst) {
     case 3: MPC_LAUNCH_G(3); break;
@@ -172,7 +175,7 @@ int mpc_create(const mpc_config *cfg, int device, int max_batch, mpc_handle **ou
     HIPCHK(hipSetDevice(device));
     mpc_handle *h = new mpc_handle();
     h->cfg = *cfg; h->device = device; h->max_batch = max_batch;
-    h->lanes_override = 0; h->profiling = 0; h->ev_used = 0; h->d_trace = nullptr;
+    h->lanes_override = 0; h->profiling = 0; h->ev_used = 0; h->d_trace = nullptr; h->d_iters_acc = nullptr; h->d_status_acc = nullptr;
     const size_t B = (size_t)max_batch, N = (size_t)cfg->N, no = (size_t)cfg->n_obst;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc(&h->dX, B * (N + 1) * 5 * sizeof(double)));
@@ -231,6 +234,29 @@ int mpc_solve_dev(mpc_handle *h, int batch, const double *d_x0, const double *d_
     mpc::KParams p = make_params(h->cfg, batch);
     p.x0 = d_x0; p.P = d_P; p.goal = d_goal; p.X = d_X; p.U = d_U;
     p.u0 = d_u0; p.cost = d_cost; p.status = d_status; p.iters = d_iters; p.trace = h->d_trace;
+    return launch_solve(h, p, pick(h, stream));
+}
+
+int mpc_closed_loop_step_dev(mpc_handle *h, int batch, double *d_x0, double *d_obst, const double *d_goal, double *d_X, double *d_U,
+                             double *d_u0, double *d_cost, int32_t *d_status, int32_t *d_iters, const double *d_noise,
+                             double randomness, double vmax, int flags, double *d_min_margin, int32_t *d_ep_flags, int32_t *d_ep_steps,
+                             void *stream)
+{
+    int rc = check_batch(h, batch); if (rc) return rc;
+    if (batch == 0) return MPC_OK;
+    if (!d_x0 || !d_obst || !d_goal || !d_X || !d_U) return fail(MPC_ERR_ARG, "null device pointer");
+    if ((flags & MPC_STEP_METRICS) && (!d_min_margin || !d_ep_flags || !d_ep_steps)) return fail(MPC_ERR_ARG, "metrics requested without buffers");
+    HIPCHK(hipSetDevice(h->device));
+    mpc::KParams p = make_params(h->cfg, batch);
+    p.x0 = d_x0; p.P = nullptr; p.goal = d_goal; p.X = d_X; p.U = d_U;
+    p.u0 = d_u0; p.cost = d_cost; p.status = d_status; p.iters = d_iters; p.trace = h->d_trace;
+    p.obst = d_obst; p.x0_rw = d_x0; p.obst_rw = d_obst; p.noise = d_noise;
+    p.randomness = randomness; p.vmax = vmax;
+    p.tol_goal = 0.15;               // TOL, src/models/world_specification.py:45
+    p.r_hit = 1.0 + 0.2;             // o.r + R_ROBOT, robot_ocp_problem.py:224
+    p.world = make_world(h->cfg);
+    p.fused = flags;
+    p.ep_min_margin = d_min_margin; p.ep_flags = d_ep_flags; p.ep_steps = d_ep_steps;
     return launch_solve(h, p, pick(h, stream));
 }
 
@@ -453,6 +479,13 @@ int mpc_profile_read(mpc_handle *h, double *sum_ms, int *launches)
     if (sum_ms) *sum_ms = sum;
     if (launches) *launches = h->ev_used;
     h->ev_used = 0;
+    return MPC_OK;
+}
+
+int mpc_set_accumulators(mpc_handle *h, int32_t *d_iters_acc, int32_t *d_status_acc)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    h->d_iters_acc = d_iters_acc; h->d_status_acc = d_status_acc;
     return MPC_OK;
 }
 

@@ -35,6 +35,21 @@
 
 namespace mpc {
 
+struct World {
+    double xmin, xmax, ymin, ymax;
+    int bug_compat_predict;
+};
+
+// fused closed-loop step: what the kernel does after the solve (bit flags of KParams::fused)
+enum : int {
+    kFuseShift = 1,        // store the iterate shifted by one stage (robot_ocp_problem.py:253-258)
+    kFusePlant = 2,        // x0 <- F(x0, u*) in place (:207-212)
+    kFuseObstacles = 4,    // obstacle states advance one step, optional velocity noise (visualization.py:20-33)
+    kFuseResetOnFail = 8,  // status 4 -> set_initial_guess() before the plant step (:203-205)
+    kFuseAliasBug = 16,    // ... which in the reference also zeroes the plant's v, omega (defect D2, :301-302)
+    kFuseMetrics = 32      // episode bookkeeping of RobotOcpProblem.step (:213-250)
+};
+
 struct KParams {
     int N, batch;
     int soft_h, bx_terminal, iter_max;
@@ -50,6 +65,17 @@ struct KParams {
     const double *x0, *P, *goal;
     double *X, *U, *u0, *cost;
     int32_t *status, *iters;
+    int32_t *iters_acc, *status_acc;   // optional running sums over launches (measurement: mean IPM iterations, failures)
+    // ---- fused closed-loop step (all optional; see mpc_closed_loop_step_dev) ----
+    const double *obst;       // [B][n_obst][4]: if set, the look-ahead P is computed in the kernel and p.P is ignored
+    double *x0_rw, *obst_rw;  // in-place plant state / obstacle states
+    const double *noise;      // [B][n_obst][2] standard normals or null
+    double randomness, vmax, tol_goal, r_hit;
+    World world;
+    int fused;
+    double *ep_min_margin;    // [B] running minimum of the margin to the obstacles
+    int32_t *ep_flags;        // [B] bit0 reached goal (episode finished), bit1 left the arena, bit2 hit an obstacle
+    int32_t *ep_steps;        // [B] completed control steps (the reference's `i`)
     double *trace;            // optional [batch][iter_max][4] = (mu, sigma, alpha, cmax) per IPM iteration (debug)
 };
 
@@ -98,6 +124,34 @@ __device__ __forceinline__ void dyn_step(const double x[5], const double u[2], d
     }
 }
 
+// One constant-velocity step with wall reflection, src/utils/visualization.py:35-59.  Plain IEEE operators in the
+// reference's own operation order with FP contraction switched off for this block, so that the look-ahead is bit-exact
+// against numpy (HIP's __dmul_rn/__dadd_rn are inlined plain operators that the backend would still fuse into FMAs).
+__device__ __forceinline__ void obstacle_advance(const World w, double dt, double &x, double &vx, double &y, double &vy)
+{
+#pragma clang fp contract(off)
+    double t_hit;
+    if (vx < 0) t_hit = (x - w.xmin) / fabs(vx);
+    else if (vx > 0) t_hit = (w.xmax - x) / fabs(vx);
+    else t_hit = INFINITY;
+    if (t_hit <= dt) { const double a = vx * t_hit, b = vx * (dt - t_hit); x = x + (a - b); vx = -vx; }
+    else { const double a = vx * dt; x = x + a; }
+    if (vy < 0) t_hit = (y - w.ymin) / fabs(vy);
+    else if (vy > 0) t_hit = (w.ymax - y) / fabs(vy);
+    else t_hit = INFINITY;
+    if (t_hit <= dt) { const double a = vy * t_hit, b = vy * (dt - t_hit); y = y + (a - b); vy = -vy; }
+    else { const double a = vy * dt; y = y + a; }
+}
+// velocity noise of Obstacle.step(), visualization.py:28-33
+__device__ __forceinline__ void obstacle_noise(double randomness, double vmax, double nx, double ny, double &vx, double &vy)
+{
+#pragma clang fp contract(off)
+    const double rx = randomness * nx, ry = randomness * ny;
+    const double fx = 1.0 + rx, fy = 1.0 + ry;
+    vx = fmin(fmax(fx * vx, -vmax), vmax);
+    vy = fmin(fmax(fy * vy, -vmax), vmax);
+}
+
 // Wavefront reductions with DPP (no LDS crossbar, no waits): four row-local butterfly steps, then the four row totals
 // are combined through v_readlane.  The result is wave-uniform.
 template <int CTRL>
@@ -112,6 +166,15 @@ __device__ __forceinline__ double lane_value(double v, int src)
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
+}
+// value held by the first lane (stage 0) of the calling lane's G-lane segment
+template <int G>
+__device__ __forceinline__ double lane_value_seg(double v, int lane)
+{
+    if (G == 64) return lane_value(v, 0);
+    if (G == 32) { const double a = lane_value(v, 0), b = lane_value(v, 32); return lane < 32 ? a : b; }
+    const double a = lane_value(v, 0), b = lane_value(v, 16), c = lane_value(v, 32), d = lane_value(v, 48);
+    return lane < 16 ? a : (lane < 32 ? b : (lane < 48 ? c : d));
 }
 // G = lanes per instance (64, 32 or 16): the reduction is over the G-lane segment the calling lane belongs to.
 template <int G>
@@ -373,7 +436,31 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     for (int c = 0; c < 5; c++) x0v[c] = p.x0[(size_t)inst * 5 + c];
     gl[0] = p.goal[(size_t)inst * 2]; gl[1] = p.goal[(size_t)inst * 2 + 1];
     double *Xg = p.X + (size_t)inst * (N + 1) * 5, *Ug = p.U + (size_t)inst * N * 2;
-    const double *Pg = p.P + ((size_t)inst * (N + 1) + (act ? i : 0)) * NOBST * 2;
+    // episode already finished (goal reached): the instance idles, nothing of it is touched
+    const bool ep_done = (p.fused & kFuseMetrics) && p.ep_flags && (p.ep_flags[inst] & 1);
+    // obstacle parameters of this stage: explicit P (reference API, parameterize_model) or the look-ahead computed here
+    extern __shared__ double lds_P[];
+    double pxy[NOBST][2];
+    if (p.obst) {
+        double *Pl = lds_P + (size_t)slot * (N + 1) * NOBST * 2;
+        if (i < NOBST) {       // lane j = i walks obstacle j through the horizon (Obstacle.predict_trajectory, visualization.py:62-79)
+            const double *o = p.obst + ((size_t)inst * NOBST + i) * 4;
+            double ox = o[0], oy = o[1], ovy = o[3];
+            double ovx = p.world.bug_compat_predict ? o[3] : o[2];
+            Pl[i * 2] = ox; Pl[i * 2 + 1] = oy;
+            for (int k = 1; k <= N; k++) {
+                obstacle_advance(p.world, dt, ox, ovx, oy, ovy);
+                Pl[(k * NOBST + i) * 2] = ox; Pl[(k * NOBST + i) * 2 + 1] = oy;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NOBST; j++) { pxy[j][0] = act ? Pl[(i * NOBST + j) * 2] : 0.0; pxy[j][1] = act ? Pl[(i * NOBST + j) * 2 + 1] : 0.0; }
+    } else {
+        const double *Pg = p.P + ((size_t)inst * (N + 1) + (act ? i : 0)) * NOBST * 2;
+#pragma unroll
+        for (int j = 0; j < NOBST; j++) { pxy[j][0] = act ? Pg[2 * j] : 0.0; pxy[j][1] = act ? Pg[2 * j + 1] : 0.0; }
+    }
     double xi[5] = {0, 0, 0, 0, 0}, ui[2] = {0, 0}, xnext[5] = {0, 0, 0, 0, 0};
     if (act) {
 #pragma unroll
@@ -456,9 +543,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     double hh[NOBST], ax[NOBST], ay[NOBST], sv[NOBST], l1[NOBST], t1[NOBST], l2[NOBST], t2[NOBST], rt1[NOBST], rt2[NOBST], pp1[NOBST], pp2[NOBST];
 #pragma unroll
     for (int j = 0; j < NOBST; j++) {
-        double px = 0, py = 0;
-        if (act) { px = Pg[2 * j]; py = Pg[2 * j + 1]; }
-        const double ex = xi[0] - px, ey = xi[1] - py;
+        const double ex = xi[0] - pxy[j][0], ey = xi[1] - pxy[j][1];
         hh[j] = ex * ex + ey * ey - p.r2; ax[j] = 2 * ex; ay[j] = 2 * ey;
         if (soft) {
             sv[j] = (hh[j] < 0 ? -hh[j] : 0.0) + p.thr0;
@@ -483,7 +568,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     double z[7] = {0, 0, 0, 0, 0, 0, 0};
     double rhoPi = 1.0;
     int status = 2, it = 0, it_done = 0;
-    bool running = true;      // per instance: instances sharing a wavefront stop at their own iteration and then idle
+    bool running = !ep_done;  // per instance: instances sharing a wavefront stop at their own iteration and then idle
 
 #ifdef MPC_PHASE_TIMING
     long long tacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -736,14 +821,74 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #endif
 
     // ---- full step on the iterate; status 4 leaves it unchanged ----
-    if (status != 4 && valid) {
-        if (act) {
+    const bool store = valid && !ep_done;
+    if (status != 4) {
 #pragma unroll
-            for (int c = 0; c < 5; c++) { xi[c] += z[2 + c]; Xg[i * 5 + c] = xi[c]; }
-        }
-        if (has_u) { ui[0] += z[0]; ui[1] += z[1]; Ug[i * 2] = ui[0]; Ug[i * 2 + 1] = ui[1]; }
+        for (int c = 0; c < 5; c++) xi[c] += z[2 + c];
+        ui[0] += z[0]; ui[1] += z[1];
     }
-    if (i == 0 && p.u0 && valid) { p.u0[(size_t)inst * 2] = ui[0]; p.u0[(size_t)inst * 2 + 1] = ui[1]; }
+    const double u_apply[2] = {lane_value_seg<G>(ui[0], lane), lane_value_seg<G>(ui[1], lane)};   // u* = U[0] of this instance
+    if ((p.fused & kFuseResetOnFail) && status == 4) {      // set_initial_guess(), robot_ocp_problem.py:203-205,286-306
+        xi[0] = x0v[0]; xi[1] = x0v[1]; xi[2] = x0v[2]; xi[3] = 0.0; xi[4] = 0.0; ui[0] = ui[1] = 0.0;
+    }
+    if (store && (status != 4 || (p.fused & (kFuseResetOnFail | kFuseShift)))) {
+        if (p.fused & kFuseShift) {                          // X[j] <- X[j+1], U[j] <- U[j+1], U[N-1] <- 0, X[N] kept (:253-258)
+            if (act && i >= 1) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) Xg[(i - 1) * 5 + c] = xi[c];
+            }
+            if (i == N) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) Xg[N * 5 + c] = xi[c];
+            }
+            if (has_u && i >= 1) { Ug[(i - 1) * 2] = ui[0]; Ug[(i - 1) * 2 + 1] = ui[1]; }
+            if (i == 0) { Ug[(N - 1) * 2] = 0.0; Ug[(N - 1) * 2 + 1] = 0.0; }
+        } else {
+            if (act) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) Xg[i * 5 + c] = xi[c];
+            }
+            if (has_u) { Ug[i * 2] = ui[0]; Ug[i * 2 + 1] = ui[1]; }
+        }
+    }
+    // ---- plant, obstacles, episode bookkeeping (fused closed-loop step) ----
+    if (p.fused & (kFusePlant | kFuseObstacles | kFuseMetrics)) {
+        double xp[5] = {x0v[0], x0v[1], x0v[2], x0v[3], x0v[4]};
+        if ((p.fused & kFuseAliasBug) && (p.fused & kFuseResetOnFail) && status == 4) { xp[3] = 0.0; xp[4] = 0.0; }
+        double xnew[5] = {xp[0], xp[1], xp[2], xp[3], xp[4]};
+        if (p.fused & kFusePlant) dyn_step<false>(xp, u_apply, dt, xnew, nullptr, nullptr);     // every lane, same value
+        if ((p.fused & kFusePlant) && i == 0 && store && p.x0_rw) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) p.x0_rw[(size_t)inst * 5 + c] = xnew[c];
+        }
+        double margin = INFINITY;
+        if (p.obst && i < NOBST) {                           // ground-truth motion of obstacle j = i
+            const double *o = p.obst + ((size_t)inst * NOBST + i) * 4;
+            double ox = o[0], oy = o[1], ovx = o[2], ovy = o[3];
+            if (p.fused & kFuseObstacles) {
+                if (p.noise) obstacle_noise(p.randomness, p.vmax, p.noise[((size_t)inst * NOBST + i) * 2], p.noise[((size_t)inst * NOBST + i) * 2 + 1], ovx, ovy);
+                obstacle_advance(p.world, dt, ox, ovx, oy, ovy);
+                if (store && p.obst_rw) { double *w = p.obst_rw + ((size_t)inst * NOBST + i) * 4; w[0] = ox; w[1] = oy; w[2] = ovx; w[3] = ovy; }
+            }
+            const double ddx = xnew[0] - ox, ddy = xnew[1] - oy;
+            margin = sqrt(ddx * ddx + ddy * ddy) - p.r_hit;  // :222-228
+        }
+        if (p.fused & kFuseMetrics) {
+            margin = -seg_max<G>(-margin, lane);
+            if (i == 0 && store) {
+                int fl = p.ep_flags[inst];
+                if (xnew[0] < p.world.xmin || xnew[0] > p.world.xmax || xnew[1] < p.world.ymin || xnew[1] > p.world.ymax) fl |= 2;   // :213-214
+                const double mm = fmin(p.ep_min_margin[inst], margin);
+                p.ep_min_margin[inst] = mm;
+                if (mm <= 0.0) fl |= 4;
+                const double gx_ = xnew[0] - gl[0], gy_ = xnew[1] - gl[1];
+                if (sqrt(gx_ * gx_ + gy_ * gy_) <= p.tol_goal) fl |= 1;      // :247-250: reached, the loop breaks before i += 1
+                else p.ep_steps[inst] += 1;
+                p.ep_flags[inst] = fl;
+            }
+        }
+    }
+    if (i == 0 && p.u0 && store) { p.u0[(size_t)inst * 2] = u_apply[0]; p.u0[(size_t)inst * 2 + 1] = u_apply[1]; }
     // NLP objective at the returned iterate: LS cost + exact penalty of the obstacle violation
     if (p.cost) {
         double J = 0.0;
@@ -754,16 +899,18 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             else J = 0.5 * (p.Weg[0] * ex * ex + p.Weg[1] * ey * ey + p.Weg[2] * xi[3] * xi[3] + p.Weg[3] * xi[4] * xi[4]);
 #pragma unroll
             for (int j = 0; j < NOBST; j++) {
-                const double dx = xi[0] - Pg[2 * j], dy = xi[1] - Pg[2 * j + 1];
+                const double dx = xi[0] - pxy[j][0], dy = xi[1] - pxy[j][1];
                 const double hv = dx * dx + dy * dy - p.r2;
                 const double v = hv < 0 ? -hv : 0.0;
                 J += zpen * (v + 0.5 * v * v);
             }
         }
         J = seg_sum<G>(J, lane);
-        if (i == 0 && valid) p.cost[inst] = J;
+        if (i == 0 && store) p.cost[inst] = J;
     }
-    if (i == 0 && valid) {
+    if (i == 0 && store) {
+        if (p.iters_acc) p.iters_acc[inst] += it_done;
+        if (p.status_acc) p.status_acc[inst] += status;
         if (p.status) p.status[inst] = status;
         if (p.iters) p.iters[inst] = it_done;
     }

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(PKG_ROOT, "libmpcgpu.so")
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 
 MPC_OK, MPC_ERR_ARG, MPC_ERR_HIP, MPC_ERR_NODEVICE = 0, -1, -2, -3
+STEP_SHIFT, STEP_PLANT, STEP_OBSTACLES, STEP_RESET_ON_FAIL, STEP_ALIAS_BUG, STEP_METRICS = 1, 2, 4, 8, 16, 32
 
 _d = C.c_double
 _i32 = C.c_int32
@@ -53,6 +54,7 @@ SYMBOLS = {
     "mpc_plant_step": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "mpc_predict": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "mpc_solve_dev": (C.c_int, [_vp, C.c_int] + [_vp] * 10),
+    "mpc_closed_loop_step_dev": (C.c_int, [_vp, C.c_int] + [_vp] * 10 + [_d, _d, C.c_int, _vp, _vp, _vp, _vp]),
     "mpc_predict_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "mpc_shift_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "mpc_reset_guess_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
@@ -61,6 +63,7 @@ SYMBOLS = {
     "mpc_linearize_dev": (C.c_int, [_vp, C.c_int] + [_vp] * 12),
     "mpc_profile_enable": (C.c_int, [_vp, C.c_int]),
     "mpc_profile_read": (C.c_int, [_vp, C.POINTER(_d), C.POINTER(C.c_int)]),
+    "mpc_set_accumulators": (C.c_int, [_vp, _vp, _vp]),
     "mpc_debug_trace": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "mpc_set_lanes_per_instance": (C.c_int, [_vp, C.c_int]),
     "mpc_get_lanes_per_instance": (C.c_int, [_vp, C.c_int]),

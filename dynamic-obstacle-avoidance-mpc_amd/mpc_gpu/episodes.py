@@ -1,0 +1,68 @@
+"""On-device closed-loop episode harness: `RobotOcpProblem.step` + `experiments.py` semantics for a
+whole batch of scenarios, one kernel launch per control step, everything resident in HBM.
+
+Output table columns are the reference's (src/simulation/robot_ocp_problem.py:277, sliced [1:] at experiments.py:36):
+    [hit, reached_goal, min_margin, dist_to_goal, iters, out_of_bounds]
+and `write_experiment` stores them as `;`-separated CSV + spec JSON like experiments.py:40-43, so tooling written for the
+reference's `test_data/` (evaluate_experiments.py:8-18) reads them.
+"""
+import json
+import os
+import time
+
+import numpy as np
+
+from . import _lib
+from .solver import BatchedMpc
+
+
+def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, init_guess_when_error=True,
+                 bug_compat_alias=True, seed=0, device=0, solver=None, **cfg):
+    """x0 (B,5), goal (B,2), obst (B,n_obst,4).  Returns dict(table (B,6), x_last (B,5), steps_run, solves)."""
+    import torch
+    x0 = np.ascontiguousarray(x0, dtype=np.float64); B = x0.shape[0]
+    obst = np.ascontiguousarray(obst, dtype=np.float64); n_obst = obst.shape[1]
+    goal = np.ascontiguousarray(np.broadcast_to(goal, (B, 2)), dtype=np.float64)
+    dev = torch.device("cuda", device)
+    m = solver or BatchedMpc(N, n_obst, Tf, max_batch=B, device=device, **cfg)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        t = lambda a: torch.from_numpy(a.copy()).to(dev)
+        dx0, dgoal, dobst = t(x0), t(goal), t(obst)
+        if bug_compat_alias:                      # set_initial_guess() aliases self.x0 and zeroes v, omega (defect D2)
+            dx0[:, 3:] = 0.0
+        X = torch.zeros(B, N + 1, 5, dtype=torch.float64, device=dev); U = torch.zeros(B, N, 2, dtype=torch.float64, device=dev)
+        status = torch.zeros(B, dtype=torch.int32, device=dev); iters = torch.zeros(B, dtype=torch.int32, device=dev)
+        margin = torch.full((B,), float("inf"), dtype=torch.float64, device=dev)
+        flags = torch.zeros(B, dtype=torch.int32, device=dev); steps = torch.zeros(B, dtype=torch.int32, device=dev)
+        s = stream.cuda_stream
+        m.reset_guess_dev(B, dx0, X, U, stream=s)            # set_initial_guess() at the start of step(), :180
+        fl = _lib.STEP_SHIFT | _lib.STEP_PLANT | _lib.STEP_OBSTACLES | _lib.STEP_METRICS
+        if init_guess_when_error:
+            fl |= _lib.STEP_RESET_ON_FAIL | (_lib.STEP_ALIAS_BUG if bug_compat_alias else 0)
+        gen = torch.Generator(device=dev); gen.manual_seed(seed)
+        k = 0
+        while k < max_iter:
+            noise = torch.randn(B, n_obst, 2, dtype=torch.float64, device=dev, generator=gen) if random_move else None
+            m.closed_loop_step_dev(B, dx0, dobst, dgoal, X, U, None, None, status, iters, noise, flags=fl,
+                                   min_margin=margin, ep_flags=flags, ep_steps=steps, stream=s)
+            k += 1
+            if k % 25 == 0 and bool((flags & 1).all().item()):     # every instance reached its goal
+                break
+        stream.synchronize()
+        fl_h = flags.cpu().numpy(); xl = dx0.cpu().numpy()
+        table = np.column_stack([(fl_h & 4) != 0, (fl_h & 1) != 0, margin.cpu().numpy(),
+                                 np.linalg.norm(xl[:, :2] - goal, axis=1), steps.cpu().numpy(), (fl_h & 2) != 0]).astype(np.float64)
+    if solver is None:
+        m.close()
+    return dict(table=table, x_last=xl, steps_run=k, solves=int(steps.sum().item()) + int((fl_h & 1).sum()))
+
+
+def write_experiment(table, spec, out_dir, stamp=None):
+    """experiments.py:28-43 file format: `<stamp>_experiment_data.csv` (';' separated) + `<stamp>_experiment_spec.json`."""
+    os.makedirs(out_dir, exist_ok=True)
+    stamp = stamp or time.strftime("%Y%m%d_%H%M%S")
+    np.savetxt(os.path.join(out_dir, f"{stamp}_experiment_data.csv"), table, delimiter=";")
+    with open(os.path.join(out_dir, f"{stamp}_experiment_spec.json"), "w") as f:
+        json.dump(spec, f)
+    return stamp

@@ -121,6 +121,14 @@ class BatchedMpc:
         _lib.check(_lib.lib().mpc_solve_dev(self._h, batch, _ptr(x0), _ptr(P), _ptr(goal), _ptr(X), _ptr(U), _ptr(u0),
                                             _ptr(cost), _ptr(status), _ptr(iters), _ptr(stream)))
 
+    def closed_loop_step_dev(self, batch, x0, obst, goal, X, U, u0=None, cost=None, status=None, iters=None, noise=None,
+                             randomness=0.1, vmax=2.0, flags=_lib.STEP_SHIFT | _lib.STEP_PLANT | _lib.STEP_OBSTACLES,
+                             min_margin=None, ep_flags=None, ep_steps=None, stream=None):
+        """One whole control step (look-ahead, solve, plant, obstacle motion, bookkeeping, shift) in one launch."""
+        _lib.check(_lib.lib().mpc_closed_loop_step_dev(self._h, batch, _ptr(x0), _ptr(obst), _ptr(goal), _ptr(X), _ptr(U), _ptr(u0),
+                                                       _ptr(cost), _ptr(status), _ptr(iters), _ptr(noise), randomness, vmax, flags,
+                                                       _ptr(min_margin), _ptr(ep_flags), _ptr(ep_steps), _ptr(stream)))
+
     def predict_dev(self, batch, obst, P, stream=None):
         _lib.check(_lib.lib().mpc_predict_dev(self._h, batch, _ptr(obst), _ptr(P), _ptr(stream)))
 
@@ -141,6 +149,9 @@ class BatchedMpc:
                                                 _ptr(b), _ptr(q), _ptr(hval), _ptr(dh), _ptr(stream)))
 
     # ------------------------------------------------------------------ measurement
+    def set_accumulators(self, iters_acc=None, status_acc=None):
+        _lib.check(_lib.lib().mpc_set_accumulators(self._h, _ptr(iters_acc), _ptr(status_acc)))
+
     def profile_enable(self, on=True):
         _lib.check(_lib.lib().mpc_profile_enable(self._h, 1 if on else 0))
 

@@ -116,6 +116,24 @@ int mpc_solve_dev(mpc_handle *h, int batch, const double *d_x0, const double *d_
                   double *d_X, double *d_U, double *d_u0, double *d_cost, int32_t *d_status, int32_t *d_iters,
                   void *stream);
 int mpc_predict_dev(mpc_handle *h, int batch, const double *d_obst, double *d_P, void *stream);
+
+/* One whole control step of RobotOcpProblem.step (robot_ocp_problem.py:184-260) in ONE kernel launch, batched:
+ *   look-ahead of the obstacles (visualization.py:62-79) -> RTI solve (:186-198) -> u* -> optional set_initial_guess on
+ *   status 4 (:203-205) -> plant step, x0 updated in place (:207-212) -> obstacle motion with optional noise, obst updated
+ *   in place (:217-218) -> margin / arena / goal bookkeeping (:213-250) -> warm-start shift (:253-258).
+ * flags: OR of MPC_STEP_*.  d_noise: [B][n_obst][2] standard normals or NULL.  Metrics buffers (MPC_STEP_METRICS):
+ * min_margin[B] (initialise to +inf), ep_flags int32[B] (bit0 goal reached -> the instance idles from then on, bit1 left the
+ * arena, bit2 min_margin <= 0), ep_steps int32[B] (the reference's iteration counter i). */
+#define MPC_STEP_SHIFT 1
+#define MPC_STEP_PLANT 2
+#define MPC_STEP_OBSTACLES 4
+#define MPC_STEP_RESET_ON_FAIL 8
+#define MPC_STEP_ALIAS_BUG 16
+#define MPC_STEP_METRICS 32
+int mpc_closed_loop_step_dev(mpc_handle *h, int batch, double *d_x0, double *d_obst, const double *d_goal, double *d_X, double *d_U,
+                             double *d_u0, double *d_cost, int32_t *d_status, int32_t *d_iters, const double *d_noise,
+                             double randomness, double vmax, int flags, double *d_min_margin, int32_t *d_ep_flags,
+                             int32_t *d_ep_steps, void *stream);
 int mpc_shift_dev(mpc_handle *h, int batch, double *d_X, double *d_U, void *stream);
 int mpc_reset_guess_dev(mpc_handle *h, int batch, const double *d_x0, double *d_X, double *d_U, void *stream);
 int mpc_plant_step_dev(mpc_handle *h, int batch, const double *d_x, const double *d_u, double *d_xnext, void *stream);
@@ -132,6 +150,10 @@ int mpc_linearize_dev(mpc_handle *h, int batch, const double *d_x0, const double
 int mpc_profile_enable(mpc_handle *h, int on);
 /* synchronises; returns the summed duration and the number of solve-kernel launches since the last call */
 int mpc_profile_read(mpc_handle *h, double *sum_ms, int *launches);
+
+/* Optional device accumulators int32[max_batch] (NULL = off): every solve launch adds each instance's interior-point
+ * iteration count / status code, so a benchmark loop needs no extra kernels to report mean iterations and failures. */
+int mpc_set_accumulators(mpc_handle *h, int32_t *d_iters_acc, int32_t *d_status_acc);
 
 /* Debug aid for parity work: when enabled, every solve records (mu, sigma, alpha, cmax) of each interior-point
  * iteration into a device buffer [max_batch][qp_iter_max][4]; host_out (may be NULL) receives the first `batch` rows. */

@@ -109,3 +109,62 @@ def test_reference_step_loop_on_the_shims(env):
     Xg, Ug = orc.initial_guess(cfg, x0)
     want = orc.rti_solve(cfg, x0, orc.predict_params(cfg, np.array([[-7.0, 7.0, 0, 0]] * 3)), np.array([6.0, 6.0]), Xg, Ug)["u0"]
     assert np.abs(prob.simU[0] - want).max() < 8e-6
+
+
+def test_fused_closed_loop_step_equals_kernel_sequence(env):
+    """mpc_closed_loop_step_dev (one launch) == predict + solve + plant + obstacle step + shift (five launches), bit for bit,
+    over 12 control steps with obstacle noise, for 1 and 2 instances per wavefront"""
+    import torch
+    mpc_gpu, orc = env
+    from mpc_gpu import _lib
+    N, no, B = 20, 3, 67
+    x0, goal, obst = random_batch(B, no, seed=41)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    z = lambda *s, dt=torch.float64: torch.zeros(*s, dtype=dt, device=dev)
+    noise = torch.from_numpy(np.random.default_rng(0).normal(size=(12, B, no, 2))).to(dev)
+    for lanes in (64, 32):
+        # torch ops (copy_) and the library's kernels must share ONE queue: an explicit, non-default torch stream
+        with mpc_gpu.BatchedMpc(N, no, 2.0, max_batch=B) as s, torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            _lib.check(_lib.lib().mpc_set_lanes_per_instance(s._h, lanes))
+            st = torch.cuda.current_stream().cuda_stream
+            assert st != 0
+            # reference sequence
+            a = dict(x0=t(x0), obst=t(obst), X=z(B, N + 1, 5), U=z(B, N, 2), x1=z(B, 5), P=z(B, N + 1, no, 2), u0=z(B, 2), cost=z(B),
+                     status=z(B, dt=torch.int32), iters=z(B, dt=torch.int32))
+            b = dict(x0=t(x0), obst=t(obst), X=z(B, N + 1, 5), U=z(B, N, 2), u0=z(B, 2), cost=z(B), status=z(B, dt=torch.int32), iters=z(B, dt=torch.int32))
+            g = t(goal)
+            s.reset_guess_dev(B, a["x0"], a["X"], a["U"], stream=st); s.reset_guess_dev(B, b["x0"], b["X"], b["U"], stream=st)
+            for k in range(12):
+                s.predict_dev(B, a["obst"], a["P"], stream=st)
+                s.solve_dev(B, a["x0"], a["P"], g, a["X"], a["U"], a["u0"], a["cost"], a["status"], a["iters"], stream=st)
+                s.plant_step_dev(B, a["x0"], a["u0"], a["x1"], stream=st); a["x0"].copy_(a["x1"])
+                s.obstacle_step_dev(B * no, a["obst"], noise[k], 0.1, 2.0, stream=st)
+                s.shift_dev(B, a["X"], a["U"], stream=st)
+                s.closed_loop_step_dev(B, b["x0"], b["obst"], g, b["X"], b["U"], b["u0"], b["cost"], b["status"], b["iters"], noise[k], stream=st)
+                torch.cuda.synchronize()
+                for key in ("x0", "obst", "X", "U", "u0", "cost", "status", "iters"):
+                    assert torch.equal(a[key], b[key]), (lanes, k, key)
+
+
+def test_episode_harness_free_space_and_table_format(env, tmp_path):
+    """on-device episodes: free-space scenarios all reach the goal without hit/oob in about as many steps as the
+    reference-shaped Python loop; CSV/JSON are written in the reference's format"""
+    mpc_gpu, orc = env
+    B = 16
+    x0 = np.tile([-6.0, -6.0, np.pi / 4, 0, 0], (B, 1)); goal = np.tile([6.0, 6.0], (B, 1))
+    obst = np.tile(np.array([[-7.0, 7.0, 0, 0], [7.0, -7.0, 0, 0], [-7.5, 7.5, 0, 0]]), (B, 1, 1))
+    r = mpc_gpu.run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=300, random_move=False)
+    tb = r["table"]
+    assert tb.shape == (B, 6) and (tb[:, 0] == 0).all() and (tb[:, 1] == 1).all() and (tb[:, 5] == 0).all()
+    assert (tb[:, 3] <= 0.15).all() and (np.abs(tb[:, 4] - tb[0, 4]) == 0).all() and 30 < tb[0, 4] < 200
+    np.random.seed(3)
+    prob = mpc_gpu.RobotOcpProblem(x0[0].copy(), goal[0], scenario="EDGE", N=20, Tf=2.0, n_obst=3, init_guess_when_error=True)
+    for o, st in zip(prob.obstacles, obst[0]):
+        o.x, o.y, o.vx, o.vy = st
+    ref = prob.step(300)
+    assert ref[5] == tb[0, 4] and abs(ref[3] - tb[0, 2]) < 1e-6 and abs(ref[4] - tb[0, 3]) < 1e-6     # iters, min margin, distance
+    stamp = mpc_gpu.write_experiment(tb, {"slack": True, "random_move": False, "init_guess": True, "scenario": "FREE", "TF": 2,
+                                          "N_SOLV": 20, "N_OBST": 3, "QP_ITER": 50}, str(tmp_path))
+    back = np.loadtxt(tmp_path / f"{stamp}_experiment_data.csv", delimiter=";")
+    assert np.array_equal(back, tb)
