@@ -235,7 +235,8 @@ def main():
            "config": {"workload": desc, "per_gpu_batch": batch, "N": N, "n_obst": no, "qp_tol": 1e-8, "qp_iter_max": 50,
                       "step": "one fused launch: obstacle look-ahead + RTI solve + plant step + obstacle motion + warm-start shift, device resident; episodes of 100 control steps",
                       "parallelism": f"replicas x{world}, cost all-gather (RCCL)" if world > 1 else "single GPU"},
-           "mean_ipm_iters": mean_iters, "instances_with_nonzero_status": int((st_acc != 0).sum().item()),
+           "mean_ipm_iters": mean_iters, "qp_failure_frac": float((st_acc % 65536).double().sum().item()) / (batch * args.steps),
+           "qp_iter_cap_frac": float((st_acc // 65536).double().sum().item()) / (batch * args.steps),
            "lanes_per_instance": loop.m.lanes_per_instance(batch), "roofline": roof}
 
     if rank == 0 and world == 1 and not args.no_extra and args.workload == "c2":

@@ -65,7 +65,7 @@ struct KParams {
     const double *x0, *P, *goal;
     double *X, *U, *u0, *cost;
     int32_t *status, *iters;
-    int32_t *iters_acc, *status_acc;   // optional running sums over launches (measurement: mean IPM iterations, failures)
+    int32_t *iters_acc, *status_acc;   // optional running sums over launches: IPM iterations; (status == 4) + 65536 * (status == 2)
     // ---- fused closed-loop step (all optional; see mpc_closed_loop_step_dev) ----
     const double *obst;       // [B][n_obst][4]: if set, the look-ahead P is computed in the kernel and p.P is ignored
     double *x0_rw, *obst_rw;  // in-place plant state / obstacle states
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     }
     if (i == 0 && store) {
         if (p.iters_acc) p.iters_acc[inst] += it_done;
-        if (p.status_acc) p.status_acc[inst] += status;
+        if (p.status_acc) p.status_acc[inst] += (status == 4 ? 1 : 0) + (status == 2 ? 65536 : 0);
         if (p.status) p.status[inst] = status;
         if (p.iters) p.iters[inst] = it_done;
     }

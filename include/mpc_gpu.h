@@ -59,7 +59,7 @@ typedef struct mpc_config {
     /* acados-semantics switches; defaults reproduce 2022-era acados           */
     int32_t cost_scale_dt;  /* stage cost x dt                                      default 1   */
     int32_t slack_scale_dt; /* slack penalties x dt for stages < N                  default 1   */
-    int32_t lm_scaled;      /* LM term x dt                                          default 0   */
+    int32_t lm_scaled;      /* LM term x dt for stages < N  default 1   */
     int32_t bx_terminal;    /* path box also at stage N                              default 0   */
     int32_t soft_h;         /* obstacle rows softened (slack=True, :106)             default 1   */
     double arena[4];        /* X_MIN, X_MAX, Y_MIN, Y_MAX  world_specification.py:7-10           */
@@ -152,7 +152,8 @@ int mpc_profile_enable(mpc_handle *h, int on);
 int mpc_profile_read(mpc_handle *h, double *sum_ms, int *launches);
 
 /* Optional device accumulators int32[max_batch] (NULL = off): every solve launch adds each instance's interior-point
- * iteration count / status code, so a benchmark loop needs no extra kernels to report mean iterations and failures. */
+ * iteration count to iters_acc and (status == 4) + 65536 * (status == 2) to status_acc, so a benchmark loop needs no
+ * extra kernels to report mean iterations, QP failures and iteration-cap hits. */
 int mpc_set_accumulators(mpc_handle *h, int32_t *d_iters_acc, int32_t *d_status_acc);
 
 /* Debug aid for parity work: when enabled, every solve records (mu, sigma, alpha, cmax) of each interior-point

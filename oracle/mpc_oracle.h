@@ -50,7 +50,7 @@ typedef struct orc_config {
     /* acados-semantics switches, SURVEY.md 8(c) (defaults = 2022-era acados)            */
     int cost_scale_dt;  /* stage cost multiplied by dt                                     */
     int slack_scale_dt; /* slack penalties z,Z multiplied by dt for stages < N             */
-    int lm_scaled;      /* LM term multiplied by dt (newer acados); default 0              */
+    int lm_scaled;      /* LM term multiplied by dt for stages < N; default 1 */
     int bx_terminal;    /* path box also on stage N; default 0                             */
     int soft_h;         /* obstacle rows softened (slack=True), robot_ocp_problem.py:106   */
     /* obstacle world, world_specification.py:7-10 and visualization.py:62-79            */

@@ -186,7 +186,7 @@ def test_switches(env):
     """acados-semantics switches are honoured identically on both sides"""
     mpc_gpu, orc = env
     x0, goal, obst = random_batch(32, 3, seed=9)
-    for kw in (dict(cost_scale_dt=0), dict(slack_scale_dt=0), dict(lm_scaled=1), dict(bx_terminal=1), dict(soft_h=0),
+    for kw in (dict(cost_scale_dt=0), dict(slack_scale_dt=0), dict(lm_scaled=0), dict(bx_terminal=1), dict(soft_h=0),
                dict(bug_compat_predict=0)):
         (g, Xg, Ug, o), = run_pair(mpc_gpu, orc, 20, 3, 2.0, x0, goal, obst, **kw)
         assert_close(g, Xg, Ug, o, allow_status_mismatch=1)
