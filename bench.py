@@ -160,11 +160,18 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # MPC_BENCH_ONE_GPU=1: smoke-test the multi-process path on a single-GPU box (all ranks on cuda:0, gloo transport)
+        one_gpu = os.environ.get("MPC_BENCH_ONE_GPU") == "1"
+        dev_index = 0 if one_gpu else local_rank
+        torch.cuda.set_device(dev_index)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
     else:
+        dev_index = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))   # one explicit queue for torch ops AND the library's kernels
 
     import __graft_entry__ as g

@@ -501,46 +501,27 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #pragma unroll
         for (int c = 0; c < 5; c++) { d0[c] = x0v[c] - xi[c]; lin0 = fmax(lin0, fabs(d0[c])); }
     }
-    // Gauss-Newton gradient q and diagonal Hessian, z order (ua, ual, x, y, psi, v, om); robot_ocp_problem.py:59-83
-    double q[7], Hd[7];
-    if (has_u) {
-        q[0] = p.Wg[4] * ui[0]; q[1] = p.Wg[5] * ui[1];
-        q[2] = p.Wg[0] * (xi[0] - gl[0]); q[3] = p.Wg[1] * (xi[1] - gl[1]); q[4] = 0.0;
-        q[5] = p.Wg[2] * xi[3]; q[6] = p.Wg[3] * xi[4];
-#pragma unroll
-        for (int c = 0; c < 7; c++) Hd[c] = p.Hd_stage[c];
-    } else {
-        q[0] = q[1] = 0.0;
-        q[2] = p.Weg[0] * (xi[0] - gl[0]); q[3] = p.Weg[1] * (xi[1] - gl[1]); q[4] = 0.0;
-        q[5] = p.Weg[2] * xi[3]; q[6] = p.Weg[3] * xi[4];
-        Hd[0] = Hd[1] = 0.0;
-#pragma unroll
-        for (int c = 0; c < 5; c++) Hd[2 + c] = p.Hd_term[c];
-    }
-
     // ---- inequality rows of this stage, in registers ----
     // box variables k: 0 ua, 1 ual, 2 x, 3 y, 4 v, 5 om  -> z index {0,1,2,3,5,6} (also the slot in Hq below)
     constexpr int NB = 6;
     const int zidx[NB] = {0, 1, 2, 3, 5, 6};
-    double cl[NB], ch[NB], ll[NB], tl[NB], lh[NB], th[NB], rtl[NB], rth[NB], ppl[NB], pph[NB];
-    bool vb[NB];
+    double ll[NB], tl[NB], lh[NB], th[NB], rtl[NB], rth[NB];
+    const bool vbu = has_u, vbx = xb;            // input-box rows (k < 2) / state-box rows (k >= 2) present at this stage
+    const double lo[NB] = {p.bu_lo[0], p.bu_lo[1], p.bx_lo[0], p.bx_lo[1], p.bx_lo[2], p.bx_lo[3]};
+    const double hi[NB] = {p.bu_hi[0], p.bu_hi[1], p.bx_hi[0], p.bx_hi[1], p.bx_hi[2], p.bx_hi[3]};
     {
         const double val[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
-        const double lo[NB] = {p.bu_lo[0], p.bu_lo[1], p.bx_lo[0], p.bx_lo[1], p.bx_lo[2], p.bx_lo[3]};
-        const double hi[NB] = {p.bu_hi[0], p.bu_hi[1], p.bx_hi[0], p.bx_hi[1], p.bx_hi[2], p.bx_hi[3]};
 #pragma unroll
         for (int k = 0; k < NB; k++) {
-            vb[k] = (k < 2) ? has_u : xb;
-            cl[k] = val[k] - lo[k]; ch[k] = hi[k] - val[k];
-            tl[k] = fmax(cl[k], p.thr0); th[k] = fmax(ch[k], p.thr0);
+            const double cl = val[k] - lo[k], ch = hi[k] - val[k];
+            tl[k] = fmax(cl, p.thr0); th[k] = fmax(ch, p.thr0);
             rtl[k] = rcp_nr(tl[k]); rth[k] = rcp_nr(th[k]);
             ll[k] = p.mu0 * rtl[k]; lh[k] = p.mu0 * rth[k];
-            ppl[k] = pph[k] = 0.0;
-            if (vb[k]) lin0 = fmax(lin0, fmax(tl[k] - cl[k], th[k] - ch[k]));
+            if ((k < 2) ? vbu : vbx) lin0 = fmax(lin0, fmax(tl[k] - cl, th[k] - ch));
         }
     }
     // obstacle rows j: rho1 = h + a'dx + s >= 0 (lam1,t1), rho2 = s >= 0 (lam2,t2); robot_model.py:60-65
-    double hh[NOBST], ax[NOBST], ay[NOBST], sv[NOBST], l1[NOBST], t1[NOBST], l2[NOBST], t2[NOBST], rt1[NOBST], rt2[NOBST], pp1[NOBST], pp2[NOBST];
+    double hh[NOBST], ax[NOBST], ay[NOBST], sv[NOBST], l1[NOBST], t1[NOBST], l2[NOBST], t2[NOBST], rt1[NOBST], rt2[NOBST];
 #pragma unroll
     for (int j = 0; j < NOBST; j++) {
         const double ex = xi[0] - pxy[j][0], ey = xi[1] - pxy[j][1];
@@ -555,11 +536,10 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         }
         rt1[j] = rcp_nr(t1[j]); rt2[j] = rcp_nr(t2[j]);
         l1[j] = p.mu0 * rt1[j]; l2[j] = soft ? p.mu0 * rt2[j] : 0.0;
-        pp1[j] = pp2[j] = 0.0;
     }
     int n_items_lane = 0;
 #pragma unroll
-    for (int k = 0; k < NB; k++) n_items_lane += vb[k] ? 2 : 0;
+    for (int k = 0; k < NB; k++) n_items_lane += ((k < 2) ? vbu : vbx) ? 2 : 0;
     n_items_lane += vs ? (soft ? 2 * NOBST : NOBST) : 0;
     const double n_items = seg_sum<G>((double)n_items_lane, lane);
     const double inv_items = n_items > 0 ? 1.0 / n_items : 0.0;
@@ -574,11 +554,15 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     long long tacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     MPC_T0();
+    // Everything cheap is RECOMPUTED where it is needed instead of being kept in registers across the stage recursions: the
+    // sweeps need ~100 doubles of their own and VALU operands can address only 256 VGPRs.  OPAQUE() hides a value's
+    // history from the optimiser (no instruction is emitted), so that recomputations are neither hoisted nor merged back.
+#define OPAQUE(x) asm volatile("" : "+v"(x))
     for (it = 0;; it++) {
         // ---- complementarity measures ----
         double msum = 0.0, cmax = 0.0;
 #pragma unroll
-        for (int k = 0; k < NB; k++) if (vb[k]) {
+        for (int k = 0; k < NB; k++) if ((k < 2) ? vbu : vbx) {
             const double a = ll[k] * tl[k], b = lh[k] * th[k];
             msum += a + b;
             if (!(tl[k] <= 2 * kTLMin || ll[k] <= 2 * kTLMin)) cmax = fmax(cmax, a);
@@ -609,213 +593,281 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         if (__ballot(running) == 0ull) break;
         MPC_TICK(0);
 
+        // residual r_d = rho(z) - t of the box rows of variable k, from the iterate (never stored)
+        auto box_rd = [&](int k, const double vals[NB], const double zz[7], double &rdl, double &rdh) {
+            const double zk = zz[zidx[k]];
+            rdl = ((vals[k] - lo[k]) + zk) - tl[k];
+            rdh = ((hi[k] - vals[k]) - zk) - th[k];
+        };
+        // weights / residuals of obstacle row pair j at the iterate zz
+        struct SoftT { double w1, w2, rD, be1, be2, rs, rd1, rd2; };
+        auto soft_terms = [&](int j, const double zz[7]) {
+            SoftT o;
+            const double y = ax[j] * zz[2] + ay[j] * zz[3];
+            o.w1 = l1[j] * rt1[j];
+            if (soft) {
+                o.rd1 = (hh[j] + y + sv[j]) - t1[j]; o.rd2 = sv[j] - t2[j];
+                o.be1 = (l1[j] * t1[j] + l1[j] * o.rd1) * rt1[j];
+                o.w2 = l2[j] * rt2[j];
+                o.be2 = (l2[j] * t2[j] + l2[j] * o.rd2) * rt2[j];
+                o.rs = zpen * sv[j] + zpen - l1[j] - l2[j];
+                o.rD = rcp_nr(zpen + o.w1 + o.w2);
+            } else {
+                o.rd1 = (hh[j] + y) - t1[j]; o.rd2 = 0.0;
+                o.be1 = (l1[j] * t1[j] + l1[j] * o.rd1) * rt1[j];
+                o.w2 = 0.0; o.be2 = 0.0; o.rs = 0.0; o.rD = 0.0;
+            }
+            return o;
+        };
+
         // ---- predictor (sigma = 0): local gradient, barrier terms, reduced Hessian ----
-        double Hq[8] = {has_u ? Hd[0] : 1.0, has_u ? Hd[1] : 1.0, Hd[2], Hd[3], Hd[4], Hd[5], Hd[6], 0.0};   // diagonal in z order, then Qxy
-        double gloc[7], cb[7];                                             // (H z + q - C'lam), sum_c c beta_c
+        StageFac F;
+        double za[7] = {0, 0, 0, 0, 0, 0, 0};
+        double bbr[5], x_init[5];
 #pragma unroll
-        for (int c = 0; c < 7; c++) { gloc[c] = Hd[c] * z[c] + q[c]; cb[c] = 0.0; }
-        double rdl[NB], rdh[NB];
+        for (int c = 0; c < 5; c++) { bbr[c] = rhoPi * bb[c]; x_init[c] = rhoPi * d0[c]; }
+        {
+            double vals[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
 #pragma unroll
-        for (int k = 0; k < NB; k++) {
-            rdl[k] = rdh[k] = 0.0;
-            if (vb[k]) {
-                const double zk = z[zidx[k]];
-                rdl[k] = (cl[k] + zk) - tl[k]; rdh[k] = (ch[k] - zk) - th[k];
+            for (int k = 0; k < NB; k++) OPAQUE(vals[k]);
+            // Gauss-Newton gradient q and diagonal Hessian, z order (ua, ual, x, y, psi, v, om); robot_ocp_problem.py:59-83
+            double Hd[7], gloc[7], cb[7];
+            if (has_u) {
+#pragma unroll
+                for (int c = 0; c < 7; c++) Hd[c] = p.Hd_stage[c];
+                gloc[0] = p.Wg[4] * vals[0]; gloc[1] = p.Wg[5] * vals[1];
+                gloc[2] = p.Wg[0] * (vals[2] - gl[0]); gloc[3] = p.Wg[1] * (vals[3] - gl[1]); gloc[4] = 0.0;
+                gloc[5] = p.Wg[2] * vals[4]; gloc[6] = p.Wg[3] * vals[5];
+            } else {
+                Hd[0] = Hd[1] = 0.0;
+#pragma unroll
+                for (int c = 0; c < 5; c++) Hd[2 + c] = p.Hd_term[c];
+                gloc[0] = gloc[1] = 0.0;
+                gloc[2] = p.Weg[0] * (vals[2] - gl[0]); gloc[3] = p.Weg[1] * (vals[3] - gl[1]); gloc[4] = 0.0;
+                gloc[5] = p.Weg[2] * vals[4]; gloc[6] = p.Weg[3] * vals[5];
+            }
+            double Hq[8] = {has_u ? Hd[0] : 1.0, has_u ? Hd[1] : 1.0, Hd[2], Hd[3], Hd[4], Hd[5], Hd[6], 0.0};   // diagonal in z order, then Qxy
+#pragma unroll
+            for (int c = 0; c < 7; c++) { gloc[c] += Hd[c] * z[c]; cb[c] = 0.0; }                              // (H z + q - C'lam), sum_c c beta_c
+#pragma unroll
+            for (int k = 0; k < NB; k++) if ((k < 2) ? vbu : vbx) {
+                double rdl, rdh;
+                box_rd(k, vals, z, rdl, rdh);
                 const double wl = ll[k] * rtl[k], wh = lh[k] * rth[k];
-                const double bl = (ll[k] * tl[k] + ll[k] * rdl[k]) * rtl[k], bh = (lh[k] * th[k] + lh[k] * rdh[k]) * rth[k];
+                const double bl = (ll[k] * tl[k] + ll[k] * rdl) * rtl[k], bh = (lh[k] * th[k] + lh[k] * rdh) * rth[k];
                 Hq[zidx[k]] += wl + wh;
                 gloc[zidx[k]] += lh[k] - ll[k];
                 cb[zidx[k]] += bl - bh;
             }
-        }
-        double w1[NOBST], w2[NOBST], rD[NOBST], be1[NOBST], be2[NOBST], rs_[NOBST], rd1[NOBST], rd2[NOBST];
-#pragma unroll
-        for (int j = 0; j < NOBST; j++) {
-            w1[j] = w2[j] = rD[j] = be1[j] = be2[j] = rs_[j] = rd1[j] = rd2[j] = 0.0;
             if (vs) {
-                const double y = ax[j] * z[2] + ay[j] * z[3];
-                w1[j] = l1[j] * rt1[j];
-                double weff, geff;
-                if (soft) {
-                    rd1[j] = (hh[j] + y + sv[j]) - t1[j]; rd2[j] = sv[j] - t2[j];
-                    be1[j] = (l1[j] * t1[j] + l1[j] * rd1[j]) * rt1[j];
-                    w2[j] = l2[j] * rt2[j];
-                    be2[j] = (l2[j] * t2[j] + l2[j] * rd2[j]) * rt2[j];
-                    rs_[j] = zpen * sv[j] + zpen - l1[j] - l2[j];
-                    const double D = zpen + w1[j] + w2[j];
-                    rD[j] = rcp_nr(D);
-                    weff = w1[j] * (zpen + w2[j]) * rD[j];
-                    geff = (be1[j] * (zpen + w2[j]) - w1[j] * (rs_[j] + be2[j])) * rD[j];
-                } else {
-                    rd1[j] = (hh[j] + y) - t1[j];
-                    be1[j] = (l1[j] * t1[j] + l1[j] * rd1[j]) * rt1[j];
-                    weff = w1[j]; geff = be1[j];
+#pragma unroll
+                for (int j = 0; j < NOBST; j++) {
+                    const SoftT o = soft_terms(j, z);
+                    double weff, geff;
+                    if (soft) {
+                        weff = o.w1 * (zpen + o.w2) * o.rD;
+                        geff = (o.be1 * (zpen + o.w2) - o.w1 * (o.rs + o.be2)) * o.rD;
+                    } else { weff = o.w1; geff = o.be1; }
+                    Hq[2] += weff * ax[j] * ax[j]; Hq[3] += weff * ay[j] * ay[j]; Hq[7] += weff * ax[j] * ay[j];
+                    gloc[2] -= l1[j] * ax[j]; gloc[3] -= l1[j] * ay[j];
+                    cb[2] += geff * ax[j]; cb[3] += geff * ay[j];
                 }
-                Hq[2] += weff * ax[j] * ax[j]; Hq[3] += weff * ay[j] * ay[j]; Hq[7] += weff * ax[j] * ay[j];
-                gloc[2] -= l1[j] * ax[j]; gloc[3] -= l1[j] * ay[j];
-                cb[2] += geff * ax[j]; cb[3] += geff * ay[j];
             }
+            MPC_TICK(1);
+            double gxs[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) gxs[c] = gloc[2 + c] + cb[2 + c];
+            systolic_factor(i, N, S, Hq, gloc[0] + cb[0], gloc[1] + cb[1], gxs, bbr, rhoPi != 0.0, F);
         }
-        MPC_TICK(1);
-        double bbr[5];
-#pragma unroll
-        for (int c = 0; c < 5; c++) bbr[c] = rhoPi * bb[c];
-        double x_init[5];
-#pragma unroll
-        for (int c = 0; c < 5; c++) x_init[c] = rhoPi * d0[c];
-        StageFac F;
-        double gxs[5];
-#pragma unroll
-        for (int c = 0; c < 5; c++) gxs[c] = gloc[2 + c] + cb[2 + c];
-        systolic_factor(i, N, S, Hq, gloc[0] + cb[0], gloc[1] + cb[1], gxs, bbr, rhoPi != 0.0, F);
         MPC_TICK(2);
-        double za[7] = {0, 0, 0, 0, 0, 0, 0};
         systolic_rollout<true>(i, N, S, F, x_init, bbr, za);
         MPC_TICK(3);
-        // affine step: dt, dlam per row, step ratios, products
-        double rmax = 0.0, maff = 0.0;
-        double dtl_[NB], dth_[NB], dll_[NB], dlh_[NB];
+
+        // ---- affine step: dt, dlam per row, step ratios, products dlam_aff * dt_aff ----
+        double ppl[NB], pph[NB], pp1[NOBST], pp2[NOBST];
+        double smu;
+        {
 #pragma unroll
-        for (int k = 0; k < NB; k++) {
-            dtl_[k] = dth_[k] = dll_[k] = dlh_[k] = 0.0;
-            if (vb[k]) {
-                const double dzk = za[zidx[k]];
-                dtl_[k] = dzk + rdl[k]; dth_[k] = -dzk + rdh[k];
-                dll_[k] = -(ll[k] * tl[k] + ll[k] * dtl_[k]) * rtl[k]; dlh_[k] = -(lh[k] * th[k] + lh[k] * dth_[k]) * rth[k];
-                ppl[k] = dll_[k] * dtl_[k]; pph[k] = dlh_[k] * dth_[k];
-                rmax = fmax(rmax, fmax(-dtl_[k] * rtl[k], -dth_[k] * rth[k]));
-                rmax = fmax(rmax, fmax(-dll_[k] * rcp_nr(ll[k]), -dlh_[k] * rcp_nr(lh[k])));
+            for (int c = 0; c < 7; c++) OPAQUE(z[c]);
+#pragma unroll
+            for (int j = 0; j < NOBST; j++) { OPAQUE(l1[j]); OPAQUE(l2[j]); }
+            double vals[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
+#pragma unroll
+            for (int k = 0; k < NB; k++) OPAQUE(vals[k]);
+            double rmax = 0.0;
+            double dtl_[NB], dth_[NB], dll_[NB], dlh_[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                dtl_[k] = dth_[k] = dll_[k] = dlh_[k] = 0.0; ppl[k] = pph[k] = 0.0;
+                if ((k < 2) ? vbu : vbx) {
+                    double rdl, rdh;
+                    box_rd(k, vals, z, rdl, rdh);
+                    const double dzk = za[zidx[k]];
+                    dtl_[k] = dzk + rdl; dth_[k] = -dzk + rdh;
+                    dll_[k] = -(ll[k] * tl[k] + ll[k] * dtl_[k]) * rtl[k]; dlh_[k] = -(lh[k] * th[k] + lh[k] * dth_[k]) * rth[k];
+                    ppl[k] = dll_[k] * dtl_[k]; pph[k] = dlh_[k] * dth_[k];
+                    rmax = fmax(rmax, fmax(-dtl_[k] * rtl[k], -dth_[k] * rth[k]));
+                    rmax = fmax(rmax, fmax(-dll_[k] * rcp_nr(ll[k]), -dlh_[k] * rcp_nr(lh[k])));
+                }
             }
-        }
-        double dt1_[NOBST], dl1_[NOBST], dt2_[NOBST], dl2_[NOBST], ds_[NOBST];
-#pragma unroll
-        for (int j = 0; j < NOBST; j++) {
-            dt1_[j] = dl1_[j] = dt2_[j] = dl2_[j] = ds_[j] = 0.0;
-            if (vs) {
-                const double y = ax[j] * za[2] + ay[j] * za[3];
-                if (soft) {
-                    const double rsum = rs_[j] + be1[j] + be2[j];
-                    ds_[j] = -(rsum + w1[j] * y) * rD[j];
-                    dt1_[j] = rd1[j] + (y * (zpen + w2[j]) - rsum) * rD[j];     // y + ds without cancellation
-                    dt2_[j] = rd2[j] + ds_[j];
-                    dl2_[j] = -(l2[j] * t2[j] + l2[j] * dt2_[j]) * rt2[j];
-                    pp2[j] = dl2_[j] * dt2_[j];
-                    rmax = fmax(rmax, fmax(-dt2_[j] * rt2[j], -dl2_[j] * rcp_nr(l2[j])));
-                } else dt1_[j] = rd1[j] + y;
-                dl1_[j] = -(l1[j] * t1[j] + l1[j] * dt1_[j]) * rt1[j];
-                pp1[j] = dl1_[j] * dt1_[j];
-                rmax = fmax(rmax, fmax(-dt1_[j] * rt1[j], -dl1_[j] * rcp_nr(l1[j])));
-            }
-        }
-        rmax = seg_max<G>(rmax, lane);
-        const double a_aff = rmax > 1.0 ? 1.0 / rmax : 1.0;
-#pragma unroll
-        for (int k = 0; k < NB; k++) if (vb[k])
-            maff += (ll[k] + a_aff * dll_[k]) * (tl[k] + a_aff * dtl_[k]) + (lh[k] + a_aff * dlh_[k]) * (th[k] + a_aff * dth_[k]);
-        if (vs) {
+            double dt1_[NOBST], dl1_[NOBST], dt2_[NOBST], dl2_[NOBST];
 #pragma unroll
             for (int j = 0; j < NOBST; j++) {
-                maff += (l1[j] + a_aff * dl1_[j]) * (t1[j] + a_aff * dt1_[j]);
-                if (soft) maff += (l2[j] + a_aff * dl2_[j]) * (t2[j] + a_aff * dt2_[j]);
+                dt1_[j] = dl1_[j] = dt2_[j] = dl2_[j] = 0.0; pp1[j] = pp2[j] = 0.0;
+                if (vs) {
+                    const SoftT o = soft_terms(j, z);
+                    const double y = ax[j] * za[2] + ay[j] * za[3];
+                    if (soft) {
+                        const double rsum = o.rs + o.be1 + o.be2;
+                        const double ds = -(rsum + o.w1 * y) * o.rD;
+                        dt1_[j] = o.rd1 + (y * (zpen + o.w2) - rsum) * o.rD;     // y + ds without cancellation
+                        dt2_[j] = o.rd2 + ds;
+                        dl2_[j] = -(l2[j] * t2[j] + l2[j] * dt2_[j]) * rt2[j];
+                        pp2[j] = dl2_[j] * dt2_[j];
+                        rmax = fmax(rmax, fmax(-dt2_[j] * rt2[j], -dl2_[j] * rcp_nr(l2[j])));
+                    } else dt1_[j] = o.rd1 + y;
+                    dl1_[j] = -(l1[j] * t1[j] + l1[j] * dt1_[j]) * rt1[j];
+                    pp1[j] = dl1_[j] * dt1_[j];
+                    rmax = fmax(rmax, fmax(-dt1_[j] * rt1[j], -dl1_[j] * rcp_nr(l1[j])));
+                }
             }
+            rmax = seg_max<G>(rmax, lane);
+            const double a_aff = rmax > 1.0 ? 1.0 / rmax : 1.0;
+            double maff = 0.0;
+#pragma unroll
+            for (int k = 0; k < NB; k++) if ((k < 2) ? vbu : vbx)
+                maff += (ll[k] + a_aff * dll_[k]) * (tl[k] + a_aff * dtl_[k]) + (lh[k] + a_aff * dlh_[k]) * (th[k] + a_aff * dth_[k]);
+            if (vs) {
+#pragma unroll
+                for (int j = 0; j < NOBST; j++) {
+                    maff += (l1[j] + a_aff * dl1_[j]) * (t1[j] + a_aff * dt1_[j]);
+                    if (soft) maff += (l2[j] + a_aff * dl2_[j]) * (t2[j] + a_aff * dt2_[j]);
+                }
+            }
+            maff = seg_sum<G>(maff, lane) * inv_items;
+            double sigma = mu > 0 ? maff / mu : 0.0;
+            sigma = sigma * sigma * sigma;
+            if (sigma > 1.0) sigma = 1.0;
+            smu = sigma * mu;
+#ifndef MPC_PHASE_TIMING
+            if (p.trace && i == 0 && valid && running) {
+                double *tr = p.trace + ((size_t)inst * p.iter_max + it) * 4;
+                tr[0] = mu; tr[1] = sigma; tr[3] = cmax;
+            }
+#endif
         }
-        maff = seg_sum<G>(maff, lane) * inv_items;
-        double sigma = mu > 0 ? maff / mu : 0.0;
-        sigma = sigma * sigma * sigma;
-        if (sigma > 1.0) sigma = 1.0;
-        const double smu = sigma * mu;
         MPC_TICK(4);
 
         // ---- corrector: homogeneous system for the change of right-hand side, d beta_c = (dlam_aff dt_aff - sigma mu) / t ----
-        double gc[7] = {0, 0, 0, 0, 0, 0, 0};
-        double db1[NOBST], db2[NOBST];
-#pragma unroll
-        for (int k = 0; k < NB; k++) if (vb[k]) {
-            const double dbl = (ppl[k] - smu) * rtl[k], dbh = (pph[k] - smu) * rth[k];
-            gc[zidx[k]] += dbl - dbh;
-        }
-#pragma unroll
-        for (int j = 0; j < NOBST; j++) {
-            db1[j] = db2[j] = 0.0;
-            if (vs) {
-                db1[j] = (pp1[j] - smu) * rt1[j];
-                double geff;
-                if (soft) {
-                    db2[j] = (pp2[j] - smu) * rt2[j];
-                    geff = (db1[j] * (zpen + w2[j]) - w1[j] * db2[j]) * rD[j];
-                } else geff = db1[j];
-                gc[2] += geff * ax[j]; gc[3] += geff * ay[j];
-            }
-        }
-        MPC_TICK(5);
-        systolic_corrector(i, N, S, gc, F);
-        MPC_TICK(6);
         double dz[7] = {0, 0, 0, 0, 0, 0, 0};
+        {
+            double gc[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < NB; k++) if ((k < 2) ? vbu : vbx) {
+                const double dbl = (ppl[k] - smu) * rtl[k], dbh = (pph[k] - smu) * rth[k];
+                gc[zidx[k]] += dbl - dbh;
+            }
+            if (vs) {
+#pragma unroll
+                for (int j = 0; j < NOBST; j++) {
+                    const double db1 = (pp1[j] - smu) * rt1[j];
+                    double geff;
+                    if (soft) {
+                        const double w1 = l1[j] * rt1[j], w2 = l2[j] * rt2[j];
+                        const double db2 = (pp2[j] - smu) * rt2[j];
+                        geff = (db1 * (zpen + w2) - w1 * db2) * rcp_nr(zpen + w1 + w2);
+                    } else geff = db1;
+                    gc[2] += geff * ax[j]; gc[3] += geff * ay[j];
+                }
+            }
+            MPC_TICK(5);
+            systolic_corrector(i, N, S, gc, F);
+        }
+        MPC_TICK(6);
         systolic_rollout<false>(i, N, S, F, x_init, bbr, dz);
 #pragma unroll
         for (int c = 0; c < 7; c++) dz[c] += za[c];
         MPC_TICK(7);
-        // ---- combined step ----
-        rmax = 0.0;
+
+        // ---- combined step: ratios, step length, update (instances that have stopped keep their state) ----
+        {
 #pragma unroll
-        for (int k = 0; k < NB; k++) if (vb[k]) {
-            const double dzk = dz[zidx[k]];
-            dtl_[k] = dzk + rdl[k]; dth_[k] = -dzk + rdh[k];
-            dll_[k] = -(ll[k] * tl[k] - smu + ppl[k] + ll[k] * dtl_[k]) * rtl[k];
-            dlh_[k] = -(lh[k] * th[k] - smu + pph[k] + lh[k] * dth_[k]) * rth[k];
-            rmax = fmax(rmax, fmax(-dtl_[k] * rtl[k], -dth_[k] * rth[k]));
-            rmax = fmax(rmax, fmax(-dll_[k] * rcp_nr(ll[k]), -dlh_[k] * rcp_nr(lh[k])));
-        }
+            for (int c = 0; c < 7; c++) OPAQUE(z[c]);
 #pragma unroll
-        for (int j = 0; j < NOBST; j++) if (vs) {
-            const double y = ax[j] * dz[2] + ay[j] * dz[3];
-            if (soft) {
-                const double rsum = rs_[j] + (be1[j] + db1[j]) + (be2[j] + db2[j]);
-                ds_[j] = -(rsum + w1[j] * y) * rD[j];
-                dt1_[j] = rd1[j] + (y * (zpen + w2[j]) - rsum) * rD[j];
-                dt2_[j] = rd2[j] + ds_[j];
-                dl2_[j] = -(l2[j] * t2[j] - smu + pp2[j] + l2[j] * dt2_[j]) * rt2[j];
-                rmax = fmax(rmax, fmax(-dt2_[j] * rt2[j], -dl2_[j] * rcp_nr(l2[j])));
-            } else dt1_[j] = rd1[j] + y;
-            dl1_[j] = -(l1[j] * t1[j] - smu + pp1[j] + l1[j] * dt1_[j]) * rt1[j];
-            rmax = fmax(rmax, fmax(-dt1_[j] * rt1[j], -dl1_[j] * rcp_nr(l1[j])));
-        }
-        rmax = seg_max<G>(rmax, lane);
-        const double amax = rmax > 1.0 ? 1.0 / rmax : 1.0;
-        const double alpha = (amax >= 1.0) ? 1.0 : 0.995 * amax;
-#ifndef MPC_PHASE_TIMING
-        if (p.trace && i == 0 && valid && running) {
-            double *tr = p.trace + ((size_t)inst * p.iter_max + it) * 4;
-            tr[0] = mu; tr[1] = sigma; tr[2] = alpha; tr[3] = cmax;
-        }
-#endif
-        if (running && !(alpha > 1e-14)) { status = 4; running = false; it_done = it; }
-        // ---- update (instances that have stopped keep their state) ----
-        if (running) {
+            for (int j = 0; j < NOBST; j++) { OPAQUE(l1[j]); OPAQUE(l2[j]); }
+            double vals[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
 #pragma unroll
-        for (int c = 0; c < 7; c++) z[c] += alpha * dz[c];
+            for (int k = 0; k < NB; k++) OPAQUE(vals[k]);
+            double rmax = 0.0;
+            double dtl_[NB], dth_[NB], dll_[NB], dlh_[NB];
 #pragma unroll
-        for (int k = 0; k < NB; k++) if (vb[k]) {
-            tl[k] = fmax(tl[k] + alpha * dtl_[k], kTLMin); th[k] = fmax(th[k] + alpha * dth_[k], kTLMin);
-            ll[k] = fmax(ll[k] + alpha * dll_[k], kTLMin); lh[k] = fmax(lh[k] + alpha * dlh_[k], kTLMin);
-            rtl[k] = rcp_nr(tl[k]); rth[k] = rcp_nr(th[k]);
-        }
-        if (vs) {
-#pragma unroll
-            for (int j = 0; j < NOBST; j++) {
-                t1[j] = fmax(t1[j] + alpha * dt1_[j], kTLMin); l1[j] = fmax(l1[j] + alpha * dl1_[j], kTLMin);
-                rt1[j] = rcp_nr(t1[j]);
-                if (soft) {
-                    sv[j] += alpha * ds_[j];
-                    t2[j] = fmax(t2[j] + alpha * dt2_[j], kTLMin); l2[j] = fmax(l2[j] + alpha * dl2_[j], kTLMin);
-                    rt2[j] = rcp_nr(t2[j]);
+            for (int k = 0; k < NB; k++) {
+                dtl_[k] = dth_[k] = dll_[k] = dlh_[k] = 0.0;
+                if ((k < 2) ? vbu : vbx) {
+                    double rdl, rdh;
+                    box_rd(k, vals, z, rdl, rdh);
+                    const double dzk = dz[zidx[k]];
+                    dtl_[k] = dzk + rdl; dth_[k] = -dzk + rdh;
+                    dll_[k] = -(ll[k] * tl[k] - smu + ppl[k] + ll[k] * dtl_[k]) * rtl[k];
+                    dlh_[k] = -(lh[k] * th[k] - smu + pph[k] + lh[k] * dth_[k]) * rth[k];
+                    rmax = fmax(rmax, fmax(-dtl_[k] * rtl[k], -dth_[k] * rth[k]));
+                    rmax = fmax(rmax, fmax(-dll_[k] * rcp_nr(ll[k]), -dlh_[k] * rcp_nr(lh[k])));
                 }
             }
-        }
-        rhoPi *= (1.0 - alpha);
+            double dt1_[NOBST], dl1_[NOBST], dt2_[NOBST], dl2_[NOBST], ds_[NOBST];
+#pragma unroll
+            for (int j = 0; j < NOBST; j++) {
+                dt1_[j] = dl1_[j] = dt2_[j] = dl2_[j] = ds_[j] = 0.0;
+                if (vs) {
+                    const SoftT o = soft_terms(j, z);
+                    const double y = ax[j] * dz[2] + ay[j] * dz[3];
+                    if (soft) {
+                        const double db1 = (pp1[j] - smu) * rt1[j], db2 = (pp2[j] - smu) * rt2[j];
+                        const double rsum = o.rs + (o.be1 + db1) + (o.be2 + db2);
+                        ds_[j] = -(rsum + o.w1 * y) * o.rD;
+                        dt1_[j] = o.rd1 + (y * (zpen + o.w2) - rsum) * o.rD;
+                        dt2_[j] = o.rd2 + ds_[j];
+                        dl2_[j] = -(l2[j] * t2[j] - smu + pp2[j] + l2[j] * dt2_[j]) * rt2[j];
+                        rmax = fmax(rmax, fmax(-dt2_[j] * rt2[j], -dl2_[j] * rcp_nr(l2[j])));
+                    } else dt1_[j] = o.rd1 + y;
+                    dl1_[j] = -(l1[j] * t1[j] - smu + pp1[j] + l1[j] * dt1_[j]) * rt1[j];
+                    rmax = fmax(rmax, fmax(-dt1_[j] * rt1[j], -dl1_[j] * rcp_nr(l1[j])));
+                }
+            }
+            rmax = seg_max<G>(rmax, lane);
+            const double amax = rmax > 1.0 ? 1.0 / rmax : 1.0;
+            const double alpha = (amax >= 1.0) ? 1.0 : 0.995 * amax;
+#ifndef MPC_PHASE_TIMING
+            if (p.trace && i == 0 && valid && running) p.trace[((size_t)inst * p.iter_max + it) * 4 + 2] = alpha;
+#endif
+            if (running && !(alpha > 1e-14)) { status = 4; running = false; it_done = it; }
+            if (running) {
+#pragma unroll
+                for (int c = 0; c < 7; c++) z[c] += alpha * dz[c];
+#pragma unroll
+                for (int k = 0; k < NB; k++) if ((k < 2) ? vbu : vbx) {
+                    tl[k] = fmax(tl[k] + alpha * dtl_[k], kTLMin); th[k] = fmax(th[k] + alpha * dth_[k], kTLMin);
+                    ll[k] = fmax(ll[k] + alpha * dll_[k], kTLMin); lh[k] = fmax(lh[k] + alpha * dlh_[k], kTLMin);
+                    rtl[k] = rcp_nr(tl[k]); rth[k] = rcp_nr(th[k]);
+                }
+                if (vs) {
+#pragma unroll
+                    for (int j = 0; j < NOBST; j++) {
+                        t1[j] = fmax(t1[j] + alpha * dt1_[j], kTLMin); l1[j] = fmax(l1[j] + alpha * dl1_[j], kTLMin);
+                        rt1[j] = rcp_nr(t1[j]);
+                        if (soft) {
+                            sv[j] += alpha * ds_[j];
+                            t2[j] = fmax(t2[j] + alpha * dt2_[j], kTLMin); l2[j] = fmax(l2[j] + alpha * dl2_[j], kTLMin);
+                            rt2[j] = rcp_nr(t2[j]);
+                        }
+                    }
+                }
+                rhoPi *= (1.0 - alpha);
+            }
         }
         MPC_TICK(8);
     }
+#undef OPAQUE
 #ifdef MPC_PHASE_TIMING
     if (p.trace && i == 0 && valid) { for (int k = 0; k < 10; k++) p.trace[((size_t)inst * p.iter_max) * 4 + k] = (double)tacc_[k]; }
 #endif
