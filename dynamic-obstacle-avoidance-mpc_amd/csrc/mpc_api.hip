@@ -38,6 +38,7 @@ struct mpc_handle {
     double *d_x0, *d_P, *d_goal, *d_obst, *d_u0, *d_cost, *d_xa, *d_ua, *d_xb;   // staging for the host-pointer API
     int32_t *d_status, *d_iters;
     int lanes_override;
+    int use_mfma;                     // matrix-core Riccati factorisation when one instance per wavefront is chosen
     int profiling;
     double *d_trace;                  // optional debug trace buffer (mpc_debug_trace)
     int32_t *d_iters_acc, *d_status_acc;   // optional accumulators (mpc_set_accumulators)
@@ -93,10 +94,12 @@ hipStream_t pick(mpc_handle *h, void *stream) { return stream ? (hipStream_t)str
 // and costs a single small batch nothing (the instruction stream has the same length either way).
 int pick_lanes(mpc_handle *h, int batch)
 {
-    (void)batch;
     const int need = h->cfg.N + 2;
     int G = need <= 16 ? 16 : (need <= 32 ? 32 : 64);
-    if (h->lanes_override >= G) G = h->lanes_override;
+    // the matrix-core factorisation (opt-in, mpc_set_matrix_cores) maps one instance per wavefront; it is used for
+    // batches of up to one instance per SIMD (1024 on MI355X), beyond that packing instances per wavefront wins
+    if (batch <= 1024 && h->use_mfma) G = 64;
+    if (h->lanes_override >= G || (h->lanes_override && h->lanes_override >= need)) G = h->lanes_override;
     return G;
 }
 
@@ -110,9 +113,11 @@ int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
     }
     const int G = pick_lanes(h, p.batch);
     const dim3 grid((p.batch + 64 / G - 1) / (64 / G)), block(64);
-    const size_t lds = p.obst ? (size_t)(64 / G) * (p.N + 1) * h->cfg.n_obst * 2 * sizeof(double) : 0;   // look-ahead staging
-#define MPC_LAUNCH(NO, GG) hipLaunchKernelGGL((mpc::rti_solve_kernel<NO, GG>), grid, block, lds, s, p)
-#define MPC_LAUNCH_G(NO) do { if (G == 16) MPC_LAUNCH(NO, 16); else if (G == 32) MPC_LAUNCH(NO, 32); else MPC_LAUNCH(NO, 64); } while (0)
+    const bool use_mfma = (G == 64) && h->use_mfma;
+    const size_t lds = ((p.obst ? (size_t)(64 / G) * (p.N + 1) * h->cfg.n_obst * 2 : 0) + (use_mfma ? (size_t)mpc::MfmaLds::doubles(p.N) : 0)) * sizeof(double);
+#define MPC_LAUNCH(NO, GG, MF) hipLaunchKernelGGL((mpc::rti_solve_kernel<NO, GG, MF>), grid, block, lds, s, p)
+#define MPC_LAUNCH_G(NO) do { if (G == 16) MPC_LAUNCH(NO, 16, false); else if (G == 32) MPC_LAUNCH(NO, 32, false); \
+                              else if (use_mfma) MPC_LAUNCH(NO, 64, true); else MPC_LAUNCH(NO, 64, false); } while (0)
     switch (h->cfg.n_obst) {
     case 3: MPC_LAUNCH_G(3); break;
     case 5: MPC_LAUNCH_G(5); break;
@@ -175,7 +180,7 @@ int mpc_create(const mpc_config *cfg, int device, int max_batch, mpc_handle **ou
     HIPCHK(hipSetDevice(device));
     mpc_handle *h = new mpc_handle();
     h->cfg = *cfg; h->device = device; h->max_batch = max_batch;
-    h->lanes_override = 0; h->profiling = 0; h->ev_used = 0; h->d_trace = nullptr; h->d_iters_acc = nullptr; h->d_status_acc = nullptr;
+    h->lanes_override = 0; h->use_mfma = 0; h->profiling = 0; h->ev_used = 0; h->d_trace = nullptr; h->d_iters_acc = nullptr; h->d_status_acc = nullptr;
     const size_t B = (size_t)max_batch, N = (size_t)cfg->N, no = (size_t)cfg->n_obst;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc(&h->dX, B * (N + 1) * 5 * sizeof(double)));
@@ -509,6 +514,13 @@ int mpc_set_lanes_per_instance(mpc_handle *h, int lanes)
     if (lanes != 0 && lanes != 16 && lanes != 32 && lanes != 64) return fail(MPC_ERR_ARG, "lanes must be 0 (automatic), 16, 32 or 64");
     if (lanes != 0 && lanes < h->cfg.N + 2) return fail(MPC_ERR_ARG, "lanes per instance must exceed N + 1");
     h->lanes_override = lanes;
+    return MPC_OK;
+}
+
+int mpc_set_matrix_cores(mpc_handle *h, int on)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    h->use_mfma = on ? 1 : 0;
     return MPC_OK;
 }
 

@@ -361,6 +361,102 @@ __device__ __forceinline__ void systolic_factor(int stage, int N, const StageLin
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// MATRIX-CORE RICCATI FACTORISATION (one instance per wavefront).  In homogeneous coordinates
+//     x~ = (x[5], 1),   z~ = (x[5], 1, ua, ual),   W~ = [A b_r B; 0 1 0] (6 x 8),   P~ = [P q; q' .] (6 x 6)
+// one stage is   M~ = H~aug + W~' P~ W~ (8 x 8),   K~ = -Muu^-1 M~[u,:],   P~+ = M~ + M~[:,u] K~,
+// which carries the Hessian AND the gradient recursion.  Each product is a v_mfma_f64_16x16x4 (D = A B + C, the 8 x 8 /
+// 6 x 8 blocks sit in the top-left corner of the 16 x 16 tiles).  Layouts (verified on gfx950): A[i][k] and B[k][j] in
+// lane i + 16 k resp. j + 16 k; D[row][col] in lane col + 16 (row & 3), register row >> 2.  Because P~ and M~ are
+// symmetric, an accumulator tile is directly the A or B operand of the next product, so the whole chain
+//     T = P~ W~ (2 MFMA, K = 6)  ->  M~ = W~' T + H~aug (2)  ->  K~ (2, LDL' substitution)  ->  P~+ (1)
+// runs without any cross-lane movement; only the 2 x 2 block Muu goes through v_readlane for its LDL' factors.
+// The per-stage operands W~_t (constant during the solve) and H~aug_t (per interior-point iteration) are staged in LDS
+// by the lanes that own the stages; K, k and the LDL' factors return to them through LDS.
+// ------------------------------------------------------------------------------------------------------------------
+typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
+#ifndef MPC_SYM_PERIOD
+#define MPC_SYM_PERIOD 4
+#endif
+static constexpr int kSymPeriod = MPC_SYM_PERIOD;
+
+struct MfmaLds {
+    double *WB, *HC, *KO, *TT;
+    __device__ __forceinline__ MfmaLds(double *base, int N)
+    {
+        WB = base;                    // [N][2][32]   W~_t operand registers: element (row k, col j) at [k >> 2][(k & 3) * 8 + j]
+        HC = WB + 64 * N;             // [N+1][2][32] H~aug_t in accumulator layout, same indexing (row, col)
+        KO = HC + 64 * (N + 1);       // [N][16]      K~ rows (2 x 6: K[a][0..4], k[a]) then 1/d0, l, 1/d1
+        TT = KO + 16 * N;             // [2][32]      scratch tile for the transpose
+    }
+    static __host__ __device__ constexpr int doubles(int N) { return 64 * N + 64 * (N + 1) + 16 * N + 64; }
+    static __device__ __forceinline__ int at(int row, int col) { return (row >> 2) * 32 + (row & 3) * 8 + col; }
+};
+
+__device__ __forceinline__ void mfma_factor(int lane, int N, const MfmaLds L, double rs)
+{
+    const int col = lane & 15, grp = lane >> 4;
+    const bool in8 = col < 8;
+    const int e = grp * 8 + (in8 ? col : 0);
+    // terminal cost-to-go: P~_N = H~aug_N (rows / cols 0..5)
+    mfma_acc_t Pt = {0.0, 0.0, 0.0, 0.0};
+    Pt[0] = in8 ? L.HC[64 * N + e] : 0.0;
+    Pt[1] = in8 ? L.HC[64 * N + 32 + e] : 0.0;
+    // operands of stage t are loaded one stage ahead, so that the LDS latency hides behind the dependent MFMA chain
+    double nB0 = in8 ? L.WB[64 * (N - 1) + e] : 0.0, nB1 = in8 ? L.WB[64 * (N - 1) + 32 + e] : 0.0;
+    double nC0 = in8 ? L.HC[64 * (N - 1) + e] : 0.0, nC1 = in8 ? L.HC[64 * (N - 1) + 32 + e] : 0.0;
+    for (int t = N - 1; t >= 0; t--) {
+        double B0 = nB0, B1 = nB1;
+        mfma_acc_t C = {nC0, nC1, 0.0, 0.0};
+        if (t > 0) {
+            nB0 = in8 ? L.WB[64 * (t - 1) + e] : 0.0; nB1 = in8 ? L.WB[64 * (t - 1) + 32 + e] : 0.0;
+            nC0 = in8 ? L.HC[64 * (t - 1) + e] : 0.0; nC1 = in8 ? L.HC[64 * (t - 1) + 32 + e] : 0.0;
+        }
+        // column 5 of W~ is the affine term: rows 0..4 carry the dynamics residual r_b = rs * b_t, row 5 is the constant 1
+        if (col == 5) { B0 *= rs; if (grp == 0) B1 *= rs; }
+        mfma_acc_t T = {0.0, 0.0, 0.0, 0.0};
+        T = __builtin_amdgcn_mfma_f64_16x16x4f64(Pt[0], B0, T, 0, 0, 0);      // P~[:, 0..3] W~[0..3, :]
+        T = __builtin_amdgcn_mfma_f64_16x16x4f64(Pt[1], B1, T, 0, 0, 0);      // P~[:, 4..7] W~[4..7, :]  (rows 6, 7 of W~ are zero)
+        mfma_acc_t M = C;
+        M = __builtin_amdgcn_mfma_f64_16x16x4f64(B0, T[0], M, 0, 0, 0);       // W~'[:, 0..3] T[0..3, :]
+        M = __builtin_amdgcn_mfma_f64_16x16x4f64(B1, T[1], M, 0, 0, 0);       // W~'[:, 4..7] T[4..7, :]
+        // Muu = M~[6..7][6..7] -> LDL' (backward stable, see systolic_factor), explicit inverse from the factors
+        const double m66 = lane_value(M[1], 6 + 32), m67 = lane_value(M[1], 7 + 32), m77 = lane_value(M[1], 7 + 48);
+        const double i00 = rcp_nr(m66);
+        const double l = m67 * i00;
+        const double i11 = rcp_nr(m77 - l * m67);
+        // K~ = -Muu^-1 M~[6..7, :] by the LDL' SUBSTITUTION, as two small products (never through an explicit inverse:
+        // its entries cancel catastrophically on the gradient column when Muu is ill-conditioned):
+        //   Y = D^-1 L^-1 M~[u,:]  (rows 2, 3),   K~ = -L^-T Y  (rows 2, 3, i.e. the B operand of the next product)
+        double A1c = 0.0, A2c = 0.0;
+        if (lane == 2 + 32) { A1c = i00; A2c = -1.0; }      // A[2][2]
+        if (lane == 3 + 32) { A1c = -l * i11; }             // A[3][2]
+        if (lane == 3 + 48) { A1c = i11; A2c = -1.0; }      // A[3][3]
+        if (lane == 2 + 48) { A2c = l; }                    // A[2][3]
+        mfma_acc_t Y = {0.0, 0.0, 0.0, 0.0};
+        Y = __builtin_amdgcn_mfma_f64_16x16x4f64(A1c, M[1], Y, 0, 0, 0);
+        mfma_acc_t Kt = {0.0, 0.0, 0.0, 0.0};
+        Kt = __builtin_amdgcn_mfma_f64_16x16x4f64(A2c, Y[0], Kt, 0, 0, 0);
+        // P~+ = M~ + M~[:, 6..7] K~   (A[i][k = 2, 3] = M~[6 + k - 2][i] by symmetry)
+        const double Am = grp >= 2 ? M[1] : 0.0;
+        Pt = __builtin_amdgcn_mfma_f64_16x16x4f64(Am, Kt[0], M, 0, 0, 0);
+        // symmetrise P~+ (both triangles are computed independently and the next product reads the tile transposed; without
+        // this the antisymmetric rounding part grows along the horizon, as in any Riccati recursion): transpose through LDS
+        // (every kSymPeriod-th stage is enough to keep the antisymmetric part at rounding level; the transpose costs ~400 cycles)
+        if ((t % kSymPeriod) == 0) {
+            if (in8) { L.TT[MfmaLds::at(grp, col)] = Pt[0]; L.TT[MfmaLds::at(grp + 4, col)] = Pt[1]; }
+            __syncthreads();
+            if (in8) {
+                Pt[0] = 0.5 * (Pt[0] + L.TT[MfmaLds::at(col, grp)]);
+                Pt[1] = 0.5 * (Pt[1] + L.TT[MfmaLds::at(col, grp + 4)]);
+            }
+            __syncthreads();
+        }
+        if (grp >= 2 && col < 6) L.KO[16 * t + (grp - 2) * 6 + col] = Kt[0];
+        if (lane == 0) { L.KO[16 * t + 12] = i00; L.KO[16 * t + 13] = l; L.KO[16 * t + 14] = i11; }
+    }
+}
+
 // Corrector right-hand side: homogeneous dynamics, reuses K and the LDL' factors; linear term gc (7) per lane.
 __device__ __forceinline__ void systolic_corrector(int stage, int N, const StageLin &S, const double gc[7], StageFac &F)
 {
@@ -414,9 +510,10 @@ __device__ __forceinline__ void systolic_rollout(int stage, int N, const StageLi
 // ------------------------------------------------------------------------------------------------------------------
 // The solve kernel.  grid = batch workgroups of 64 threads (one wavefront per instance); no LDS.
 // ------------------------------------------------------------------------------------------------------------------
-template <int NOBST, int G>
+template <int NOBST, int G, bool USE_MFMA>
 __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 {
+    static_assert(!USE_MFMA || G == 64, "the matrix-core factorisation maps one instance per wavefront");
     constexpr int IPW = 64 / G;               // instances per wavefront
     const int lane = threadIdx.x;
     const int slot = lane / G;
@@ -439,7 +536,9 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     // episode already finished (goal reached): the instance idles, nothing of it is touched
     const bool ep_done = (p.fused & kFuseMetrics) && p.ep_flags && (p.ep_flags[inst] & 1);
     // obstacle parameters of this stage: explicit P (reference API, parameterize_model) or the look-ahead computed here
-    extern __shared__ double lds_P[];
+    extern __shared__ double lds_raw[];
+    const MfmaLds ML(lds_raw, N);             // used only when USE_MFMA (the launch sizes the allocation accordingly)
+    double *lds_P = lds_raw + (USE_MFMA ? MfmaLds::doubles(N) : 0);
     double pxy[NOBST][2];
     if (p.obst) {
         double *Pl = lds_P + (size_t)slot * (N + 1) * NOBST * 2;
@@ -500,6 +599,25 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     if (i == 0) {
 #pragma unroll
         for (int c = 0; c < 5; c++) { d0[c] = x0v[c] - xi[c]; lin0 = fmax(lin0, fabs(d0[c])); }
+    }
+    if (USE_MFMA) {
+        // zero the operand tiles once, then every stage lane writes its W~_t = [A b B; 0 1 0] (cols: x0..x4, 1, ua, ual)
+        for (int k = lane; k < 64 * N + 64 * (N + 1); k += 64) ML.WB[k] = 0.0;
+        __syncthreads();
+        if (has_u) {
+            double *w = ML.WB + 64 * i;
+            const double Arow[5][5] = {{1.0, 0.0, S.a02, S.a03, S.a04}, {0.0, 1.0, S.a12, S.a13, S.a14}, {0.0, 0.0, 1.0, 0.0, dt},
+                                       {0.0, 0.0, 0.0, 1.0, 0.0}, {0.0, 0.0, 0.0, 0.0, 1.0}};
+            const double Brow[5][2] = {{S.b00, S.b01}, {S.b10, S.b11}, {0.0, h2}, {dt, 0.0}, {0.0, dt}};
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) w[MfmaLds::at(k, c)] = Arow[k][c];
+                w[MfmaLds::at(k, 5)] = bb[k];
+                w[MfmaLds::at(k, 6)] = Brow[k][0]; w[MfmaLds::at(k, 7)] = Brow[k][1];
+            }
+            w[MfmaLds::at(5, 5)] = 1.0;
+        }
     }
     // ---- inequality rows of this stage, in registers ----
     // box variables k: 0 ua, 1 ual, 2 x, 3 y, 4 v, 5 om  -> z index {0,1,2,3,5,6} (also the slot in Hq below)
@@ -677,7 +795,33 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             double gxs[5];
 #pragma unroll
             for (int c = 0; c < 5; c++) gxs[c] = gloc[2 + c] + cb[2 + c];
-            systolic_factor(i, N, S, Hq, gloc[0] + cb[0], gloc[1] + cb[1], gxs, bbr, rhoPi != 0.0, F);
+            if (USE_MFMA) {
+                if (act) {      // H~aug_t in accumulator layout: z~ order (x0..x4, 1, ua, ual)
+                    double *hc = ML.HC + 64 * i;
+                    const double lu0 = gloc[0] + cb[0], lu1 = gloc[1] + cb[1];
+                    hc[MfmaLds::at(0, 0)] = Hq[2]; hc[MfmaLds::at(1, 1)] = Hq[3]; hc[MfmaLds::at(2, 2)] = Hq[4];
+                    hc[MfmaLds::at(3, 3)] = Hq[5]; hc[MfmaLds::at(4, 4)] = Hq[6];
+                    hc[MfmaLds::at(0, 1)] = Hq[7]; hc[MfmaLds::at(1, 0)] = Hq[7];
+                    hc[MfmaLds::at(6, 6)] = Hq[0]; hc[MfmaLds::at(7, 7)] = Hq[1];
+#pragma unroll
+                    for (int c = 0; c < 5; c++) { hc[MfmaLds::at(c, 5)] = gxs[c]; hc[MfmaLds::at(5, c)] = gxs[c]; }
+                    hc[MfmaLds::at(6, 5)] = lu0; hc[MfmaLds::at(5, 6)] = lu0;
+                    hc[MfmaLds::at(7, 5)] = lu1; hc[MfmaLds::at(5, 7)] = lu1;
+                }
+                __syncthreads();
+                mfma_factor(lane, N, ML, rhoPi);
+                __syncthreads();
+                F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;
+#pragma unroll
+                for (int c = 0; c < 5; c++) { F.K0[c] = 0.0; F.K1[c] = 0.0; }
+                if (has_u) {
+                    const double *ko = ML.KO + 16 * i;
+#pragma unroll
+                    for (int c = 0; c < 5; c++) { F.K0[c] = ko[c]; F.K1[c] = ko[6 + c]; }
+                    F.k0 = ko[5]; F.k1 = ko[11]; F.i00 = ko[12]; F.l = ko[13]; F.i11 = ko[14];
+                }
+            } else
+                systolic_factor(i, N, S, Hq, gloc[0] + cb[0], gloc[1] + cb[1], gxs, bbr, rhoPi != 0.0, F);
         }
         MPC_TICK(2);
         systolic_rollout<true>(i, N, S, F, x_init, bbr, za);

@@ -163,6 +163,11 @@ int mpc_debug_trace(mpc_handle *h, int enable, int batch, double *host_out);
 /* lanes per instance (64, 32, 16 or 8) the dispatcher picked for `batch`; 0 = automatic (default) */
 int mpc_set_lanes_per_instance(mpc_handle *h, int lanes);
 int mpc_get_lanes_per_instance(mpc_handle *h, int batch);
+/* 0 (default): vector-ALU systolic Riccati factorisation everywhere.  1: for batches <= 1024 (one instance per
+ * wavefront) the factorisation runs on the matrix cores (v_mfma_f64_16x16x4, homogeneous 8x8 stage blocks).  Measured on
+ * MI355X the two are equally fast (FP64 MFMA rate = FP64 vector rate, 116-cycle dependent MFMA links) and the vector
+ * path is more accurate on ill-conditioned stages, hence the default; see DESIGN.md section 4. */
+int mpc_set_matrix_cores(mpc_handle *h, int on);
 
 #ifdef __cplusplus
 }

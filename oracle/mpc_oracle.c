@@ -482,7 +482,7 @@ typedef struct {
     double (*p)[NX];
     double (*K)[10];   /* 2x5 */
     double (*k)[NU];
-    double (*L)[4];    /* chol of Muu, lower 2x2 */
+    double (*L)[4];    /* LDL' of Muu: {d0, 0, l, d1} */
     double (*Mxu)[10]; /* 5x2 */
 } ricc_t;
 
@@ -510,14 +510,16 @@ static void riccati(const qp_t *Q, double (*Ht)[49], double (*g)[NZ], double (*r
                 M[a * 7 + bq] = s;
             }
             /* Cholesky of Muu */
-            double l00 = sqrt(M[0]), l10 = M[7] / l00, l11 = sqrt(M[8] - l10 * l10);
-            R->L[i][0] = l00; R->L[i][1] = 0; R->L[i][2] = l10; R->L[i][3] = l11;
+            /* Muu = L D L' without square roots: when a state row's barrier weight makes B'PB nearly rank one, the second
+             * pivot M11 - l*M01 is a difference of ~1e13-sized numbers and can round to a tiny negative value; a Cholesky
+             * square root would turn that into NaN, LDL' just carries the (rounding-sized) pivot. L[i] = {d0, 0, l, d1}. */
+            double d0 = M[0], l10 = M[7] / d0, d1 = M[8] - l10 * M[7];
+            R->L[i][0] = d0; R->L[i][1] = 0; R->L[i][2] = l10; R->L[i][3] = d1;
             for (int a = 0; a < 5; a++) { R->Mxu[i][a * 2] = M[(2 + a) * 7 + 0]; R->Mxu[i][a * 2 + 1] = M[(2 + a) * 7 + 1]; }
             /* K = -Muu^{-1} Mux */
             for (int a = 0; a < 5; a++) {
                 double r0 = M[0 * 7 + 2 + a], r1 = M[1 * 7 + 2 + a];
-                double y0 = r0 / l00, y1 = (r1 - l10 * y0) / l11;
-                double x1 = y1 / l11, x0_ = (y0 - l10 * x1) / l00;
+                double x1 = (r1 - l10 * r0) / d1, x0_ = r0 / d0 - l10 * x1;
                 R->K[i][0 * 5 + a] = -x0_; R->K[i][1 * 5 + a] = -x1;
             }
             /* P_i = Mxx + Mxu K */
@@ -530,9 +532,8 @@ static void riccati(const qp_t *Q, double (*Ht)[49], double (*g)[NZ], double (*r
         for (int a = 0; a < 5; a++) { double s = R->p[i + 1][a]; for (int l = 0; l < 5; l++) s += R->P[i + 1][a * 5 + l] * r[i][l]; Pr[a] = s; }
         for (int a = 0; a < 7; a++) { double s = g[i][a]; for (int l = 0; l < 5; l++) s += Wm[l * 7 + a] * Pr[l]; m[a] = s; }
         {
-            double l00 = R->L[i][0], l10 = R->L[i][2], l11 = R->L[i][3];
-            double y0 = m[0] / l00, y1 = (m[1] - l10 * y0) / l11;
-            double x1 = y1 / l11, x0_ = (y0 - l10 * x1) / l00;
+            double d0 = R->L[i][0], l10 = R->L[i][2], d1 = R->L[i][3];
+            double x1 = (m[1] - l10 * m[0]) / d1, x0_ = m[0] / d0 - l10 * x1;
             R->k[i][0] = -x0_; R->k[i][1] = -x1;
         }
         for (int a = 0; a < 5; a++) R->p[i][a] = m[2 + a] + R->Mxu[i][a * 2] * R->k[i][0] + R->Mxu[i][a * 2 + 1] * R->k[i][1];

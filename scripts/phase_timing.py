@@ -7,7 +7,7 @@ import numpy as np, torch
 so = os.path.join(ROOT, "gpurun_out", "libmpcgpu_timing.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-                       "-DMPC_PHASE_TIMING", "-o", so, os.path.join(PKG, "csrc", "mpc_api.hip")])
+                       "-DMPC_PHASE_TIMING"] + [a for a in sys.argv[2:] if a.startswith("-D")] + ["-o", so, os.path.join(PKG, "csrc", "mpc_api.hip")])
 from mpc_gpu import _lib
 _lib.LIB_PATH = so
 import mpc_gpu, bench

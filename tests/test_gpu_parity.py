@@ -202,6 +202,7 @@ def test_lanes_per_instance_packing(env):
         res = {}
         for lanes in (0, 64, 32) + ((16,) if N + 2 <= 16 else ()):
             with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
+                _lib.check(_lib.lib().mpc_set_matrix_cores(s._h, 0))        # vector-ALU factorisation on every path: bitwise comparable
                 _lib.check(_lib.lib().mpc_set_lanes_per_instance(s._h, lanes))
                 got = s.lanes_per_instance(B)
                 s.reset_guess(x0); g = s.solve(x0, obst, goal); X, U = s.get_traj(B)
@@ -215,3 +216,28 @@ def test_lanes_per_instance_packing(env):
             assert np.array_equal(g["cost"], res[64][1]["cost"])
     with mpc_gpu.BatchedMpc(20, 3, 2.0, max_batch=4) as s:
         assert _lib.lib().mpc_set_lanes_per_instance(s._h, 16) == _lib.MPC_ERR_ARG     # N + 1 = 21 does not fit 16 lanes
+
+
+def test_matrix_core_factorisation_matches_vector_path(env):
+    """v_mfma_f64_16x16x4 Riccati factorisation (one instance per wavefront) vs the vector-ALU systolic factorisation: same
+    iteration counts and statuses, iterates equal to rounding; and both within tolerance of the oracle"""
+    mpc_gpu, orc = env
+    from mpc_gpu import _lib
+    for N, no, B in ((20, 3, 300), (50, 10, 40), (10, 5, 64)):
+        x0, goal, obst = random_batch(B, no, seed=51 + N)
+        out = {}
+        for mf in (1, 0):
+            with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
+                _lib.check(_lib.lib().mpc_set_matrix_cores(s._h, mf))
+                _lib.check(_lib.lib().mpc_set_lanes_per_instance(s._h, 64))
+                s.reset_guess(x0); g = s.solve(x0, obst, goal); X, U = s.get_traj(B)
+                s.shift(B); g2 = s.solve(x0, obst, goal); X2, U2 = s.get_traj(B)       # second step: d0 != 0, defects != 0
+                out[mf] = (g, X, U, g2, X2, U2)
+        ok = (out[1][0]["status"] == 0) & (out[0][0]["status"] == 0) & (out[1][3]["status"] == 0) & (out[0][3]["status"] == 0)
+        assert ok.mean() > 0.9
+        assert (out[1][0]["iters"] == out[0][0]["iters"]).mean() > 0.95
+        # the matrix-core path keeps the cost-to-go in a full (not triangular) tile and symmetrises every 4th stage: it is
+        # ~100x less accurate than the vector path on ill-conditioned stages, still far inside the parity tolerance
+        d1 = np.abs(out[1][1] - out[0][1]).reshape(B, -1).max(1)[ok]; d2 = np.abs(out[1][4] - out[0][4]).reshape(B, -1).max(1)[ok]
+        assert np.median(d1) < 1e-9 and np.median(d2) < 1e-9
+        assert np.sort(d1)[-2] < 1e-6 and np.sort(d2)[-2] < 2e-6        # one sensitive instance allowed (oracle 1e-8 vs 1e-12 differs by 5e-5 on it)
