@@ -30,11 +30,31 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TF = 78.6     # MI355X FP64 vector peak
 
 
-def algorithmic_bytes_per_solve(N, n_obst):
-    """read x0 5 + goal 2 + P (N+1)*2*n_obst + X 5(N+1) + U 2N; write X, U, cost (f64) + status (4 B)."""
-    rd = 5 + 2 + (N + 1) * 2 * n_obst + 5 * (N + 1) + 2 * N
-    wr = 5 * (N + 1) + 2 * N + 1
-    return 8 * (rd + wr) + 4
+def algorithmic_bytes_per_solve(N, n_obst, fused=True):
+    """HBM bytes one solve must move.  Reference-style explicit P: read x0 5 + goal 2 + P (N+1)*2*n_obst +
+    X 5(N+1) + U 2N, write X, U, cost (f64) + status (4 B) = 3396 B at N=20 / 3 obstacles.  The fused closed-loop step the
+    bench runs is the compact-obstacle variant: it reads the 4 n_obst obstacle states instead of P and additionally writes
+    back x0, the obstacle states and u0 (+ status, iters): 2640 B at N=20 / 3 obstacles."""
+    if not fused:
+        rd = 5 + 2 + (N + 1) * 2 * n_obst + 5 * (N + 1) + 2 * N
+        wr = 5 * (N + 1) + 2 * N + 1
+        return 8 * (rd + wr) + 4
+    rd = 5 + 2 + 4 * n_obst + 5 * (N + 1) + 2 * N
+    wr = 5 * (N + 1) + 2 * N + 1 + 5 + 4 * n_obst + 2
+    return 8 * (rd + wr) + 8
+
+
+def measured_traffic(kernel_name, batch):
+    """HBM bytes per launch of the solve kernel from the committed rocprofv3 PMC passes (profiles/r01_final_pmc_summary.json,
+    collected with the command recorded there); None when the summary is for another kernel variant or batch."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_summary.json")))
+        if d["batch"] != batch or kernel_name.replace(" ", "") not in d["kernel"].replace(" ", ""):
+            return None
+        t = d["hbm_traffic_bytes_per_launch"]
+        return t["fetch_raw_kb"] * 1024 + t["write_bytes"]
+    except Exception:
+        return None
 
 
 def algorithmic_flops_per_solve(N, n_obst, k_iters):
@@ -227,15 +247,18 @@ def main():
     value = total_solves / elapsed
     mean_iters = float(it_acc.double().sum().item()) / (batch * args.steps)
     avg_kernel_s = kern_ms / max(1, launches) * 1e-3
-    abytes = algorithmic_bytes_per_solve(N, no) * batch
+    abytes = algorithmic_bytes_per_solve(N, no, fused=True) * batch
+    lanes = loop.m.lanes_per_instance(batch)
+    kname = f"rti_solve_kernel<{no}, {lanes}, false>"
     roof = {"bound": "hbm", "achieved": abytes / avg_kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": abytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
-            "kernel": f"rti_solve_kernel<{no}>", "avg_launch_us": avg_kernel_s * 1e6, "launches": launches,
+            "frac": abytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic(kname, batch),
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_final_pmc_summary.json (FETCH_SIZE uncorrected: 8-byte-per-lane loads, see DESIGN.md section 5)",
+            "kernel": kname, "avg_launch_us": avg_kernel_s * 1e6, "launches": launches,
             "algorithmic_bytes_per_launch": abytes,
             "fp64_valu": {"achieved": algorithmic_flops_per_solve(N, no, mean_iters) * batch / avg_kernel_s / 1e12,
                           "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                           "frac": algorithmic_flops_per_solve(N, no, mean_iters) * batch / avg_kernel_s / 1e12 / FP64_VALU_PEAK_TF,
-                          "note": "the path is FP64-vector-ALU/latency bound, not HBM bound (DESIGN.md section 5); SURVEY 8(d) flop model x measured mean IPM iterations"}}
+                          "note": "the path is bound by FP64 vector-instruction ISSUE (PMC: VALU active 78% of wave cycles, 4 cycles per wave-instruction, one lane of 64 active in the stage recursions), not by HBM (DESIGN.md section 5); SURVEY 8(d) flop model x measured mean IPM iterations"}}
     out = {"metric": "MPC solves/sec (N=20, 3 obstacles)", "value": value, "unit": "solves/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
