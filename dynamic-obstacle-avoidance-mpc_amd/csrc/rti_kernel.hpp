@@ -16,7 +16,7 @@
 //     computes, hand-expanded for the sparsity of A_i = I + E_i (6 non-trivial entries) and B_i (4 non-trivial entries).
 // HBM traffic is therefore the algorithmic minimum: read x0, goal, P, X, U once, write X, U, u0, cost, status once.
 //
-// Interior point method: Mehrotra predictor-corrector in residual ("delta") form.  The costates the stationarity
+// Interior point method: Mehrotra predictor-corrector (separate primal / dual step lengths) in residual ("delta") form.  The costates the stationarity
 // residual needs come from the adjoint recursion pi_i = (H z + q - C'lam)_x + A_i' pi_{i+1}, fused into the backward
 // Riccati sweep (it zeroes the state blocks of the residual exactly).  The corrector solves only the homogeneous
 // system for the difference of right-hand sides.  Dynamics / initial-condition residuals decay by prod(1 - alpha_k).
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             double vals[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
 #pragma unroll
             for (int k = 0; k < NB; k++) OPAQUE(vals[k]);
-            double rmax = 0.0;
+            double rmax = 0.0, rmaxd = 0.0;      // largest -dt/t (primal) and -dlam/lam (dual) ratios
             double dtl_[NB], dth_[NB], dll_[NB], dlh_[NB];
 #pragma unroll
             for (int k = 0; k < NB; k++) {
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                     dll_[k] = -(ll[k] * tl[k] + ll[k] * dtl_[k]) * rtl[k]; dlh_[k] = -(lh[k] * th[k] + lh[k] * dth_[k]) * rth[k];
                     ppl[k] = dll_[k] * dtl_[k]; pph[k] = dlh_[k] * dth_[k];
                     rmax = fmax(rmax, fmax(-dtl_[k] * rtl[k], -dth_[k] * rth[k]));
-                    rmax = fmax(rmax, fmax(-dll_[k] * rcp_nr(ll[k]), -dlh_[k] * rcp_nr(lh[k])));
+                    rmaxd = fmax(rmaxd, fmax(-dll_[k] * rcp_nr(ll[k]), -dlh_[k] * rcp_nr(lh[k])));
                 }
             }
             double dt1_[NOBST], dl1_[NOBST], dt2_[NOBST], dl2_[NOBST];
@@ -868,24 +868,24 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                         dt2_[j] = o.rd2 + ds;
                         dl2_[j] = -(l2[j] * t2[j] + l2[j] * dt2_[j]) * rt2[j];
                         pp2[j] = dl2_[j] * dt2_[j];
-                        rmax = fmax(rmax, fmax(-dt2_[j] * rt2[j], -dl2_[j] * rcp_nr(l2[j])));
+                        rmax = fmax(rmax, -dt2_[j] * rt2[j]); rmaxd = fmax(rmaxd, -dl2_[j] * rcp_nr(l2[j]));
                     } else dt1_[j] = o.rd1 + y;
                     dl1_[j] = -(l1[j] * t1[j] + l1[j] * dt1_[j]) * rt1[j];
                     pp1[j] = dl1_[j] * dt1_[j];
-                    rmax = fmax(rmax, fmax(-dt1_[j] * rt1[j], -dl1_[j] * rcp_nr(l1[j])));
+                    rmax = fmax(rmax, -dt1_[j] * rt1[j]); rmaxd = fmax(rmaxd, -dl1_[j] * rcp_nr(l1[j]));
                 }
             }
-            rmax = seg_max<G>(rmax, lane);
-            const double a_aff = rmax > 1.0 ? 1.0 / rmax : 1.0;
+            rmax = seg_max<G>(rmax, lane); rmaxd = seg_max<G>(rmaxd, lane);
+            const double a_aff = rmax > 1.0 ? 1.0 / rmax : 1.0, a_affd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;
             double maff = 0.0;
 #pragma unroll
             for (int k = 0; k < NB; k++) if ((k < 2) ? vbu : vbx)
-                maff += (ll[k] + a_aff * dll_[k]) * (tl[k] + a_aff * dtl_[k]) + (lh[k] + a_aff * dlh_[k]) * (th[k] + a_aff * dth_[k]);
+                maff += (ll[k] + a_affd * dll_[k]) * (tl[k] + a_aff * dtl_[k]) + (lh[k] + a_affd * dlh_[k]) * (th[k] + a_aff * dth_[k]);
             if (vs) {
 #pragma unroll
                 for (int j = 0; j < NOBST; j++) {
-                    maff += (l1[j] + a_aff * dl1_[j]) * (t1[j] + a_aff * dt1_[j]);
-                    if (soft) maff += (l2[j] + a_aff * dl2_[j]) * (t2[j] + a_aff * dt2_[j]);
+                    maff += (l1[j] + a_affd * dl1_[j]) * (t1[j] + a_aff * dt1_[j]);
+                    if (soft) maff += (l2[j] + a_affd * dl2_[j]) * (t2[j] + a_aff * dt2_[j]);
                 }
             }
             maff = seg_sum<G>(maff, lane) * inv_items;
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             double vals[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
 #pragma unroll
             for (int k = 0; k < NB; k++) OPAQUE(vals[k]);
-            double rmax = 0.0;
+            double rmax = 0.0, rmaxd = 0.0;
             double dtl_[NB], dth_[NB], dll_[NB], dlh_[NB];
 #pragma unroll
             for (int k = 0; k < NB; k++) {
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                     dll_[k] = -(ll[k] * tl[k] - smu + ppl[k] + ll[k] * dtl_[k]) * rtl[k];
                     dlh_[k] = -(lh[k] * th[k] - smu + pph[k] + lh[k] * dth_[k]) * rth[k];
                     rmax = fmax(rmax, fmax(-dtl_[k] * rtl[k], -dth_[k] * rth[k]));
-                    rmax = fmax(rmax, fmax(-dll_[k] * rcp_nr(ll[k]), -dlh_[k] * rcp_nr(lh[k])));
+                    rmaxd = fmax(rmaxd, fmax(-dll_[k] * rcp_nr(ll[k]), -dlh_[k] * rcp_nr(lh[k])));
                 }
             }
             double dt1_[NOBST], dl1_[NOBST], dt2_[NOBST], dl2_[NOBST], ds_[NOBST];
@@ -972,36 +972,37 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                         dt1_[j] = o.rd1 + (y * (zpen + o.w2) - rsum) * o.rD;
                         dt2_[j] = o.rd2 + ds_[j];
                         dl2_[j] = -(l2[j] * t2[j] - smu + pp2[j] + l2[j] * dt2_[j]) * rt2[j];
-                        rmax = fmax(rmax, fmax(-dt2_[j] * rt2[j], -dl2_[j] * rcp_nr(l2[j])));
+                        rmax = fmax(rmax, -dt2_[j] * rt2[j]); rmaxd = fmax(rmaxd, -dl2_[j] * rcp_nr(l2[j]));
                     } else dt1_[j] = o.rd1 + y;
                     dl1_[j] = -(l1[j] * t1[j] - smu + pp1[j] + l1[j] * dt1_[j]) * rt1[j];
-                    rmax = fmax(rmax, fmax(-dt1_[j] * rt1[j], -dl1_[j] * rcp_nr(l1[j])));
+                    rmax = fmax(rmax, -dt1_[j] * rt1[j]); rmaxd = fmax(rmaxd, -dl1_[j] * rcp_nr(l1[j]));
                 }
             }
-            rmax = seg_max<G>(rmax, lane);
-            const double amax = rmax > 1.0 ? 1.0 / rmax : 1.0;
-            const double alpha = (amax >= 1.0) ? 1.0 : 0.995 * amax;
+            rmax = seg_max<G>(rmax, lane); rmaxd = seg_max<G>(rmaxd, lane);
+            const double amax = rmax > 1.0 ? 1.0 / rmax : 1.0, amaxd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;
+            const double alpha = (amax >= 1.0) ? 1.0 : 0.995 * amax;        // primal step: z, s, t
+            const double alphad = (amaxd >= 1.0) ? 1.0 : 0.995 * amaxd;     // dual step: lam
 #ifndef MPC_PHASE_TIMING
             if (p.trace && i == 0 && valid && running) p.trace[((size_t)inst * p.iter_max + it) * 4 + 2] = alpha;
 #endif
-            if (running && !(alpha > 1e-14)) { status = 4; running = false; it_done = it; }
+            if (running && (!(alpha > 1e-14) || !(alphad > 1e-14))) { status = 4; running = false; it_done = it; }
             if (running) {
 #pragma unroll
                 for (int c = 0; c < 7; c++) z[c] += alpha * dz[c];
 #pragma unroll
                 for (int k = 0; k < NB; k++) if ((k < 2) ? vbu : vbx) {
                     tl[k] = fmax(tl[k] + alpha * dtl_[k], kTLMin); th[k] = fmax(th[k] + alpha * dth_[k], kTLMin);
-                    ll[k] = fmax(ll[k] + alpha * dll_[k], kTLMin); lh[k] = fmax(lh[k] + alpha * dlh_[k], kTLMin);
+                    ll[k] = fmax(ll[k] + alphad * dll_[k], kTLMin); lh[k] = fmax(lh[k] + alphad * dlh_[k], kTLMin);
                     rtl[k] = rcp_nr(tl[k]); rth[k] = rcp_nr(th[k]);
                 }
                 if (vs) {
 #pragma unroll
                     for (int j = 0; j < NOBST; j++) {
-                        t1[j] = fmax(t1[j] + alpha * dt1_[j], kTLMin); l1[j] = fmax(l1[j] + alpha * dl1_[j], kTLMin);
+                        t1[j] = fmax(t1[j] + alpha * dt1_[j], kTLMin); l1[j] = fmax(l1[j] + alphad * dl1_[j], kTLMin);
                         rt1[j] = rcp_nr(t1[j]);
                         if (soft) {
                             sv[j] += alpha * ds_[j];
-                            t2[j] = fmax(t2[j] + alpha * dt2_[j], kTLMin); l2[j] = fmax(l2[j] + alpha * dl2_[j], kTLMin);
+                            t2[j] = fmax(t2[j] + alpha * dt2_[j], kTLMin); l2[j] = fmax(l2[j] + alphad * dl2_[j], kTLMin);
                             rt2[j] = rcp_nr(t2[j]);
                         }
                     }

@@ -614,7 +614,7 @@ static void residuals(const qp_t *Q, iter_t *I, double (*rg)[NZ], double *rs, do
 }
 
 /*
- * Mehrotra predictor-corrector primal-dual IPM, cold-started, single step length for primal and dual,
+ * Mehrotra predictor-corrector primal-dual IPM, cold-started, separate step lengths for primal and dual,
  * Riccati factorisation of the reduced KKT system [acados-knowledge: this is the structure of HPIPM's
  * OCP-QP solver, which robot_ocp_problem.py:126 selects; tolerance/caps are ours].
  * Returns 0 converged, 2 max-iter, 4 failure (NaN / step collapse).
@@ -666,7 +666,7 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
         if (res[1] <= c->qp_tol && res[2] <= c->qp_tol && res[3] <= c->qp_tol) { status = 0; break; }
         if (it >= c->qp_iter_max) { status = 2; break; }
 
-        double sigma = 0.0; double alpha = 1.0;
+        double sigma = 0.0; double alpha = 1.0, alphad = 1.0;
         for (int pass = 0; pass < 2; pass++) {
             /* reduced Hessian / gradient */
             for (int i = 0; i <= N; i++) {
@@ -705,7 +705,7 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
                 /* y + ds without the cancellation it suffers when w1 >> Z + w2 (active row late in the iteration) */
                 yds[j] = (y * (Q->Zs[j] + w2[j]) - (rs[j] + be1[j] + be2[j])) / D;
             }
-            double amax = 1.0;
+            double amax = 1.0, amaxd = 1.0;   /* largest primal (t) and dual (lam) steps that keep positivity */
             for (int e = 0; e < ni; e++) {
                 item_t *q = &Q->it[e];
                 double rd = q->c0; for (int a = 0; a < 7; a++) rd += q->cz[a] * I->z[q->stage][a];
@@ -718,26 +718,28 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
                 double dl = -(rm + q->lam * dt_) / q->t;
                 q->dt_ = dt_; q->dlam = dl;
                 if (dt_ < 0) { double a_ = -q->t / dt_; if (a_ < amax) amax = a_; }
-                if (dl < 0) { double a_ = -q->lam / dl; if (a_ < amax) amax = a_; }
+                if (dl < 0) { double a_ = -q->lam / dl; if (a_ < amaxd) amaxd = a_; }
             }
             if (pass == 0) {
                 double mu_aff = 0;
-                for (int e = 0; e < ni; e++) { item_t *q = &Q->it[e]; mu_aff += (q->lam + amax * q->dlam) * (q->t + amax * q->dt_); q->dlam_aff = q->dlam; q->dt_aff = q->dt_; }
+                for (int e = 0; e < ni; e++) { item_t *q = &Q->it[e]; mu_aff += (q->lam + amaxd * q->dlam) * (q->t + amax * q->dt_); q->dlam_aff = q->dlam; q->dt_aff = q->dt_; }
                 mu_aff = ni ? mu_aff / ni : 0.0;
                 double ratio = mu > 0 ? mu_aff / mu : 0.0;
                 sigma = ratio * ratio * ratio;
                 if (sigma > 1.0) sigma = 1.0;
                 if (ni == 0) { alpha = 1.0; break; }
             } else {
+                /* separate primal and dual step lengths (z, s, t move by alpha; lam by alphad) */
                 alpha = 0.995 * amax; if (amax >= 1.0) alpha = 1.0; if (alpha > 1.0) alpha = 1.0;
+                alphad = 0.995 * amaxd; if (amaxd >= 1.0) alphad = 1.0;
             }
         }
         if (g_trace && it < g_trace_cap) { g_trace[4 * it] = mu; g_trace[4 * it + 1] = sigma; g_trace[4 * it + 2] = alpha; g_trace[4 * it + 3] = res[3]; }
-        if (!(alpha > 1e-14)) { status = 4; break; }
+        if (!(alpha > 1e-14) || !(alphad > 1e-14)) { status = 4; break; }
         for (int i = 0; i <= N; i++) { for (int a = 0; a < 7; a++) I->z[i][a] += alpha * dz[i][a]; }
         for (int j = 0; j < ns; j++) I->s[j] += alpha * ds[j];
         for (int e = 0; e < ni; e++) {
-            item_t *q = &Q->it[e]; q->t += alpha * q->dt_; q->lam += alpha * q->dlam;
+            item_t *q = &Q->it[e]; q->t += alpha * q->dt_; q->lam += alphad * q->dlam;
             if (q->t < TL_MIN) q->t = TL_MIN;      /* floors as in HPIPM's t_min / lam_min [acados-knowledge]: keep */
             if (q->lam < TL_MIN) q->lam = TL_MIN;  /* lam/t finite once a pair has collapsed below rounding        */
         }
