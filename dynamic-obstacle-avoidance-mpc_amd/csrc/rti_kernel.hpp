@@ -980,8 +980,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             }
             rmax = seg_max<G>(rmax, lane); rmaxd = seg_max<G>(rmaxd, lane);
             const double amax = rmax > 1.0 ? 1.0 / rmax : 1.0, amaxd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;
-            const double alpha = (amax >= 1.0) ? 1.0 : 0.995 * amax;        // primal step: z, s, t
-            const double alphad = (amaxd >= 1.0) ? 1.0 : 0.995 * amaxd;     // dual step: lam
+            const double alpha = (amax >= 1.0) ? 1.0 : 0.9995 * amax;        // primal step: z, s, t
+            const double alphad = (amaxd >= 1.0) ? 1.0 : 0.9995 * amaxd;     // dual step: lam
 #ifndef MPC_PHASE_TIMING
             if (p.trace && i == 0 && valid && running) p.trace[((size_t)inst * p.iter_max + it) * 4 + 2] = alpha;
 #endif

@@ -730,8 +730,8 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
                 if (ni == 0) { alpha = 1.0; break; }
             } else {
                 /* separate primal and dual step lengths (z, s, t move by alpha; lam by alphad) */
-                alpha = 0.995 * amax; if (amax >= 1.0) alpha = 1.0; if (alpha > 1.0) alpha = 1.0;
-                alphad = 0.995 * amaxd; if (amaxd >= 1.0) alphad = 1.0;
+                alpha = 0.9995 * amax; if (amax >= 1.0) alpha = 1.0; if (alpha > 1.0) alpha = 1.0;
+                alphad = 0.9995 * amaxd; if (amaxd >= 1.0) alphad = 1.0;
             }
         }
         if (g_trace && it < g_trace_cap) { g_trace[4 * it] = mu; g_trace[4 * it + 1] = sigma; g_trace[4 * it + 2] = alpha; g_trace[4 * it + 3] = res[3]; }

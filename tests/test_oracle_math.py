@@ -139,7 +139,7 @@ def test_tighter_tolerance_moves_the_solution_little(orc):
     P = oracle_P(orc, c8, obst); X, U = oracle_guess(orc, c8, x0)
     a, b = orc.rti_solve_batch(c8, x0, P, goal, X, U), orc.rti_solve_batch(c11, x0, P, goal, X, U)
     ok = (a["status"] == 0) & (b["status"] == 0)
-    assert ok.sum() >= 30 and np.abs(a["X"][ok] - b["X"][ok]).max() < 1e-7
+    assert ok.sum() >= 30 and np.abs(a["X"][ok] - b["X"][ok]).max() < 1e-6      # = the GPU parity tolerance
 
 
 def test_closed_loop_reaches_goal_in_free_space(orc):
