@@ -251,10 +251,10 @@ struct StageFac {
 };
 
 // SYSTOLIC STAGE RECURSIONS.  The lane with stage index t (lane = slot * G + t when several instances share a wavefront) owns
-// stage t and holds that stage's blocks in registers.  N + 1 < G guarantees an idle lane (all-zero outgoing state) between
-// the last stage of one instance and stage 0 of the next, so the shifts never leak state across instances.  The recursion state
-// (cost-to-go Hessian P and gradient q going backward; the state step dx going forward) travels from lane to lane by a
-// one-lane DPP wave shift per stage: in step t only lane t computes (exec-masked), then everything shifts by one lane.
+// stage t and holds that stage's blocks in registers.  The recursion state (cost-to-go Hessian P and gradient q going
+// backward; the state step dx going forward) travels from lane to lane by a one-lane DPP wave shift per stage: the value lane t
+// computes in step t is the one lane t-1 (t+1) consumes in the next step.  Whatever the other lanes (idle lanes, the
+// neighbouring instance) push into the chain arrives at a lane only AFTER that lane's own step, so it is never consumed.
 // No LDS, no barriers, no global traffic inside the interior-point loop.
 //
 // Backward Riccati factorisation + predictor right-hand side.
@@ -265,98 +265,102 @@ struct StageFac {
 __device__ __forceinline__ void systolic_factor(int stage, int N, const StageLin &S, const double Hq[8], double lu0, double lu1,
                                                 const double gxs[5], const double bbr[5], bool affine, StageFac &F)
 {
+    // Every lane executes the stage arithmetic in every step (a wave instruction costs the same for 1 or 64 active lanes);
+    // only lane t holds a meaningful incoming state in step t, and only lane t keeps the factors it computed.  Computing
+    // unconditionally lets the results flow through fresh registers straight into the DPP shift, without the masked copies
+    // into loop-carried registers that an `if (stage == t)` around the arithmetic costs (~12 % of this loop).
     double P[5][5], qv[5];       // incoming state (valid in lane t at step t); symmetric entries share one value
-    double M[5][5], qo[5];       // outgoing state (upper triangle of M is overwritten with the new P)
 #pragma unroll
     for (int r = 0; r < 5; r++) {
-        qv[r] = 0.0; qo[r] = 0.0;
+        qv[r] = 0.0;
 #pragma unroll
-        for (int c = 0; c < 5; c++) { P[r][c] = 0.0; M[r][c] = 0.0; }
+        for (int c = 0; c < 5; c++) P[r][c] = 0.0;
     }
     const double dt = S.dt, h2 = S.h2;
     for (int t = N; t >= 0; t--) {
-        if (stage == t) {
-            double mu0[5], mu1[5];
-            // columns x, y of P W are columns 0, 1 of P
-            mu0[0] = S.b00 * P[0][0] + S.b10 * P[1][0] + dt * P[3][0];
-            mu0[1] = S.b00 * P[0][1] + S.b10 * P[1][1] + dt * P[3][1];
-            mu1[0] = S.b01 * P[0][0] + S.b11 * P[1][0] + h2 * P[2][0] + dt * P[4][0];
-            mu1[1] = S.b01 * P[0][1] + S.b11 * P[1][1] + h2 * P[2][1] + dt * P[4][1];
-            M[0][0] = Hq[2] + P[0][0]; M[0][1] = Hq[7] + P[0][1]; M[1][1] = Hq[3] + P[1][1];
-            double m00, m01, m11;
-            {   // column ua
-                double T[5];
+        double M[5][5], qo[5], mu0[5], mu1[5];
+        // columns x, y of P W are columns 0, 1 of P
+        mu0[0] = S.b00 * P[0][0] + S.b10 * P[1][0] + dt * P[3][0];
+        mu0[1] = S.b00 * P[0][1] + S.b10 * P[1][1] + dt * P[3][1];
+        mu1[0] = S.b01 * P[0][0] + S.b11 * P[1][0] + h2 * P[2][0] + dt * P[4][0];
+        mu1[1] = S.b01 * P[0][1] + S.b11 * P[1][1] + h2 * P[2][1] + dt * P[4][1];
+        M[0][0] = Hq[2] + P[0][0]; M[0][1] = Hq[7] + P[0][1]; M[1][1] = Hq[3] + P[1][1];
+        double m00, m01, m11;
+        {   // column ua
+            double T[5];
 #pragma unroll
-                for (int k = 0; k < 5; k++) T[k] = P[k][0] * S.b00 + P[k][1] * S.b10 + P[k][3] * dt;
-                m00 = Hq[0] + S.dua(T);
-            }
-            {   // column ual
-                double T[5];
-#pragma unroll
-                for (int k = 0; k < 5; k++) T[k] = P[k][0] * S.b01 + P[k][1] * S.b11 + P[k][2] * h2 + P[k][4] * dt;
-                m01 = S.dua(T); m11 = Hq[1] + S.dual(T);
-            }
-            {   // column psi
-                double T[5];
-#pragma unroll
-                for (int k = 0; k < 5; k++) T[k] = P[k][0] * S.a02 + P[k][1] * S.a12 + P[k][2];
-                mu0[2] = S.dua(T); mu1[2] = S.dual(T);
-                M[0][2] = T[0]; M[1][2] = T[1]; M[2][2] = Hq[4] + S.dpsi(T);
-            }
-            {   // column v
-                double T[5];
-#pragma unroll
-                for (int k = 0; k < 5; k++) T[k] = P[k][0] * S.a03 + P[k][1] * S.a13 + P[k][3];
-                mu0[3] = S.dua(T); mu1[3] = S.dual(T);
-                M[0][3] = T[0]; M[1][3] = T[1]; M[2][3] = S.dpsi(T); M[3][3] = Hq[5] + S.dv(T);
-            }
-            {   // column om
-                double T[5];
-#pragma unroll
-                for (int k = 0; k < 5; k++) T[k] = P[k][0] * S.a04 + P[k][1] * S.a14 + P[k][2] * dt + P[k][4];
-                mu0[4] = S.dua(T); mu1[4] = S.dual(T);
-                M[0][4] = T[0]; M[1][4] = T[1]; M[2][4] = S.dpsi(T); M[3][4] = S.dv(T); M[4][4] = Hq[6] + S.dom(T);
-            }
-            // Muu = L D L' (backward stable; the closed-form inverse through det cancels catastrophically when a state
-            // row's barrier weight makes B'PB nearly rank one)
-            F.i00 = rcp_nr(m00);
-            F.l = m01 * F.i00;
-            F.i11 = rcp_nr(m11 - F.l * m01);
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                const double x1 = (mu1[c] - F.l * mu0[c]) * F.i11;
-                F.K1[c] = -x1;
-                F.K0[c] = -(mu0[c] * F.i00 - F.l * x1);
-            }
-            // gradient part (needs the OLD P): qb = q+ + P+ r_b
-            double qb[5];
-            if (affine) {
-#pragma unroll
-                for (int k = 0; k < 5; k++) qb[k] = qv[k] + P[k][0] * bbr[0] + P[k][1] * bbr[1] + P[k][2] * bbr[2] + P[k][3] * bbr[3] + P[k][4] * bbr[4];
-            } else {
-#pragma unroll
-                for (int k = 0; k < 5; k++) qb[k] = qv[k];
-            }
-            const double m0 = lu0 + S.dua(qb), m1 = lu1 + S.dual(qb);
-            const double x1 = (m1 - F.l * m0) * F.i11;
-            F.k1 = -x1; F.k0 = -(m0 * F.i00 - F.l * x1);
-            qo[0] = gxs[0] + qb[0] + F.K0[0] * m0 + F.K1[0] * m1;
-            qo[1] = gxs[1] + qb[1] + F.K0[1] * m0 + F.K1[1] * m1;
-            qo[2] = gxs[2] + S.dpsi(qb) + F.K0[2] * m0 + F.K1[2] * m1;
-            qo[3] = gxs[3] + S.dv(qb) + F.K0[3] * m0 + F.K1[3] * m1;
-            qo[4] = gxs[4] + S.dom(qb) + F.K0[4] * m0 + F.K1[4] * m1;
-            // new cost-to-go Hessian in place: P = Mxx + K'Mux (upper triangle)
-#pragma unroll
-            for (int r = 0; r < 5; r++)
-#pragma unroll
-                for (int c = r; c < 5; c++) M[r][c] += F.K0[r] * mu0[c] + F.K1[r] * mu1[c];
+            for (int k = 0; k < 5; k++) T[k] = P[k][0] * S.b00 + P[k][1] * S.b10 + P[k][3] * dt;
+            m00 = Hq[0] + S.dua(T);
         }
-        // hand the state to the lane on the left (stage t-1)
+        {   // column ual
+            double T[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) T[k] = P[k][0] * S.b01 + P[k][1] * S.b11 + P[k][2] * h2 + P[k][4] * dt;
+            m01 = S.dua(T); m11 = Hq[1] + S.dual(T);
+        }
+        {   // column psi
+            double T[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) T[k] = P[k][0] * S.a02 + P[k][1] * S.a12 + P[k][2];
+            mu0[2] = S.dua(T); mu1[2] = S.dual(T);
+            M[0][2] = T[0]; M[1][2] = T[1]; M[2][2] = Hq[4] + S.dpsi(T);
+        }
+        {   // column v
+            double T[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) T[k] = P[k][0] * S.a03 + P[k][1] * S.a13 + P[k][3];
+            mu0[3] = S.dua(T); mu1[3] = S.dual(T);
+            M[0][3] = T[0]; M[1][3] = T[1]; M[2][3] = S.dpsi(T); M[3][3] = Hq[5] + S.dv(T);
+        }
+        {   // column om
+            double T[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) T[k] = P[k][0] * S.a04 + P[k][1] * S.a14 + P[k][2] * dt + P[k][4];
+            mu0[4] = S.dua(T); mu1[4] = S.dual(T);
+            M[0][4] = T[0]; M[1][4] = T[1]; M[2][4] = S.dpsi(T); M[3][4] = S.dv(T); M[4][4] = Hq[6] + S.dom(T);
+        }
+        // Muu = L D L' (backward stable; the closed-form inverse through det cancels catastrophically when a state
+        // row's barrier weight makes B'PB nearly rank one)
+        const double i00 = rcp_nr(m00);
+        const double l = m01 * i00;
+        const double i11 = rcp_nr(m11 - l * m01);
+        double K0[5], K1[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            K1[c] = fma(l, mu0[c], -mu1[c]) * i11;            // -(mu1 - l mu0) / d1
+            K0[c] = fma(-l, K1[c], -(mu0[c] * i00));          // -(mu0 / d0 + l K1)
+        }
+        // gradient part (needs the OLD P): qb = q+ + P+ r_b
+        double qb[5];
+        if (affine) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) qb[k] = qv[k] + P[k][0] * bbr[0] + P[k][1] * bbr[1] + P[k][2] * bbr[2] + P[k][3] * bbr[3] + P[k][4] * bbr[4];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 5; k++) qb[k] = qv[k];
+        }
+        const double m0 = lu0 + S.dua(qb), m1 = lu1 + S.dual(qb);
+        const double k1 = fma(l, m0, -m1) * i11;
+        const double k0 = fma(-l, k1, -(m0 * i00));
+        qo[0] = gxs[0] + qb[0] + K0[0] * m0 + K1[0] * m1;
+        qo[1] = gxs[1] + qb[1] + K0[1] * m0 + K1[1] * m1;
+        qo[2] = gxs[2] + S.dpsi(qb) + K0[2] * m0 + K1[2] * m1;
+        qo[3] = gxs[3] + S.dv(qb) + K0[3] * m0 + K1[3] * m1;
+        qo[4] = gxs[4] + S.dom(qb) + K0[4] * m0 + K1[4] * m1;
+        if (stage == t) {      // the lane that owns stage t keeps its factors
+            F.i00 = i00; F.l = l; F.i11 = i11; F.k0 = k0; F.k1 = k1;
+#pragma unroll
+            for (int c = 0; c < 5; c++) { F.K0[c] = K0[c]; F.K1[c] = K1[c]; }
+        }
+        // new cost-to-go Hessian P = Mxx + K'Mux (upper triangle), handed with q to the lane on the left (stage t-1)
 #pragma unroll
         for (int r = 0; r < 5; r++) {
             qv[r] = from_right(qo[r]);
 #pragma unroll
-            for (int c = r; c < 5; c++) { const double v = from_right(M[r][c]); P[r][c] = v; P[c][r] = v; }
+            for (int c = r; c < 5; c++) {
+                const double v = from_right(fma(K1[r], mu1[c], fma(K0[r], mu0[c], M[r][c])));
+                P[r][c] = v; P[c][r] = v;
+            }
         }
     }
 }
@@ -460,18 +464,15 @@ __device__ __forceinline__ void mfma_factor(int lane, int N, const MfmaLds L, do
 // Corrector right-hand side: homogeneous dynamics, reuses K and the LDL' factors; linear term gc (7) per lane.
 __device__ __forceinline__ void systolic_corrector(int stage, int N, const StageLin &S, const double gc[7], StageFac &F)
 {
-    double pv[5] = {0, 0, 0, 0, 0}, pvo[5] = {0, 0, 0, 0, 0};
-    for (int t = N; t >= 0; t--) {
-        if (stage == t) {
-            const double m0 = gc[0] + S.dua(pv), m1 = gc[1] + S.dual(pv);
-            const double mx[5] = {gc[2] + pv[0], gc[3] + pv[1], gc[4] + S.dpsi(pv), gc[5] + S.dv(pv), gc[6] + S.dom(pv)};
-            const double x1 = (m1 - F.l * m0) * F.i11;
-            F.k1 = -x1; F.k0 = -(m0 * F.i00 - F.l * x1);
+    double pv[5] = {0, 0, 0, 0, 0};
+    for (int t = N; t >= 0; t--) {      // unconditional arithmetic, masked keep: see systolic_factor
+        const double m0 = gc[0] + S.dua(pv), m1 = gc[1] + S.dual(pv);
+        const double mx[5] = {gc[2] + pv[0], gc[3] + pv[1], gc[4] + S.dpsi(pv), gc[5] + S.dv(pv), gc[6] + S.dom(pv)};
+        const double k1 = fma(F.l, m0, -m1) * F.i11;
+        const double k0 = fma(-F.l, k1, -(m0 * F.i00));
+        if (stage == t) { F.k0 = k0; F.k1 = k1; }
 #pragma unroll
-            for (int c = 0; c < 5; c++) pvo[c] = mx[c] + F.K0[c] * m0 + F.K1[c] * m1;
-        }
-#pragma unroll
-        for (int r = 0; r < 5; r++) pv[r] = from_right(pvo[r]);
+        for (int c = 0; c < 5; c++) pv[c] = from_right(mx[c] + F.K0[c] * m0 + F.K1[c] * m1);
     }
 }
 
@@ -481,26 +482,26 @@ template <bool AFFINE>
 __device__ __forceinline__ void systolic_rollout(int stage, int N, const StageLin &S, const StageFac &F, const double x_init[5],
                                                  const double bbr[5], double dz[7])
 {
-    double x[5], xo[5] = {0, 0, 0, 0, 0};
+    double x[5];
 #pragma unroll
     for (int c = 0; c < 5; c++) x[c] = AFFINE ? x_init[c] : 0.0;
-    for (int t = 0; t <= N; t++) {
-        if (stage == t) {
-            double u0 = F.k0, u1 = F.k1;
+    for (int t = 0; t <= N; t++) {      // unconditional arithmetic, masked keep: see systolic_factor
+        double u0 = F.k0, u1 = F.k1, xo[5];
 #pragma unroll
-            for (int c = 0; c < 5; c++) { u0 += F.K0[c] * x[c]; u1 += F.K1[c] * x[c]; }
+        for (int c = 0; c < 5; c++) { u0 += F.K0[c] * x[c]; u1 += F.K1[c] * x[c]; }
+        if (stage == t) {
             dz[0] = u0; dz[1] = u1;
 #pragma unroll
             for (int c = 0; c < 5; c++) dz[2 + c] = x[c];
-            xo[0] = x[0] + S.a02 * x[2] + S.a03 * x[3] + S.a04 * x[4] + S.b00 * u0 + S.b01 * u1;
-            xo[1] = x[1] + S.a12 * x[2] + S.a13 * x[3] + S.a14 * x[4] + S.b10 * u0 + S.b11 * u1;
-            xo[2] = x[2] + S.dt * x[4] + S.h2 * u1;
-            xo[3] = x[3] + S.dt * u0;
-            xo[4] = x[4] + S.dt * u1;
-            if (AFFINE) {
+        }
+        xo[0] = x[0] + S.a02 * x[2] + S.a03 * x[3] + S.a04 * x[4] + S.b00 * u0 + S.b01 * u1;
+        xo[1] = x[1] + S.a12 * x[2] + S.a13 * x[3] + S.a14 * x[4] + S.b10 * u0 + S.b11 * u1;
+        xo[2] = x[2] + S.dt * x[4] + S.h2 * u1;
+        xo[3] = x[3] + S.dt * u0;
+        xo[4] = x[4] + S.dt * u1;
+        if (AFFINE) {
 #pragma unroll
-                for (int c = 0; c < 5; c++) xo[c] += bbr[c];
-            }
+            for (int c = 0; c < 5; c++) xo[c] += bbr[c];
         }
 #pragma unroll
         for (int c = 0; c < 5; c++) x[c] = from_left(xo[c]);
