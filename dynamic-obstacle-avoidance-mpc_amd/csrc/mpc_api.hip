@@ -39,6 +39,7 @@ struct mpc_handle {
     int32_t *d_status, *d_iters;
     int lanes_override;
     int use_mfma;                     // matrix-core Riccati factorisation when one instance per wavefront is chosen
+    int row_parallel;                 // row-parallel (64-bit DPP) Riccati factorisation instead of the one-lane systolic sweep
     int profiling;
     double *d_trace;                  // optional debug trace buffer (mpc_debug_trace)
     int32_t *d_iters_acc, *d_status_acc;   // optional accumulators (mpc_set_accumulators)
@@ -114,10 +115,13 @@ int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
     const int G = pick_lanes(h, p.batch);
     const dim3 grid((p.batch + 64 / G - 1) / (64 / G)), block(64);
     const bool use_mfma = (G == 64) && h->use_mfma;
-    const size_t lds = ((p.obst ? (size_t)(64 / G) * (p.N + 1) * h->cfg.n_obst * 2 : 0) + (use_mfma ? (size_t)mpc::MfmaLds::doubles(p.N) : 0)) * sizeof(double);
+    const bool rowpar = !use_mfma && h->row_parallel;
+    const size_t lds = ((p.obst ? (size_t)(64 / G) * (p.N + 1) * h->cfg.n_obst * 2 : 0) + (use_mfma ? (size_t)mpc::MfmaLds::doubles(p.N) : 0) +
+                        (rowpar ? (size_t)(64 / G) * mpc::RowLds::per_instance(p.N) : 0)) * sizeof(double);
 #define MPC_LAUNCH(NO, GG, MF) hipLaunchKernelGGL((mpc::rti_solve_kernel<NO, GG, MF>), grid, block, lds, s, p)
-#define MPC_LAUNCH_G(NO) do { if (G == 16) MPC_LAUNCH(NO, 16, false); else if (G == 32) MPC_LAUNCH(NO, 32, false); \
-                              else if (use_mfma) MPC_LAUNCH(NO, 64, true); else MPC_LAUNCH(NO, 64, false); } while (0)
+#define MPC_LAUNCH_G(NO) do { if (G == 16) { if (rowpar) MPC_LAUNCH(NO, 16, 2); else MPC_LAUNCH(NO, 16, 0); } \
+                              else if (G == 32) { if (rowpar) MPC_LAUNCH(NO, 32, 2); else MPC_LAUNCH(NO, 32, 0); } \
+                              else if (use_mfma) MPC_LAUNCH(NO, 64, 1); else if (rowpar) MPC_LAUNCH(NO, 64, 2); else MPC_LAUNCH(NO, 64, 0); } while (0)
     switch (h->cfg.n_obst) {
     case 3: MPC_LAUNCH_G(3); break;
     case 5: MPC_LAUNCH_G(5); break;
@@ -180,7 +184,7 @@ int mpc_create(const mpc_config *cfg, int device, int max_batch, mpc_handle **ou
     HIPCHK(hipSetDevice(device));
     mpc_handle *h = new mpc_handle();
     h->cfg = *cfg; h->device = device; h->max_batch = max_batch;
-    h->lanes_override = 0; h->use_mfma = 0; h->profiling = 0; h->ev_used = 0; h->d_trace = nullptr; h->d_iters_acc = nullptr; h->d_status_acc = nullptr;
+    h->lanes_override = 0; h->use_mfma = 0; h->row_parallel = 1; h->profiling = 0; h->ev_used = 0; h->d_trace = nullptr; h->d_iters_acc = nullptr; h->d_status_acc = nullptr;
     const size_t B = (size_t)max_batch, N = (size_t)cfg->N, no = (size_t)cfg->n_obst;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc(&h->dX, B * (N + 1) * 5 * sizeof(double)));
@@ -521,6 +525,13 @@ int mpc_set_matrix_cores(mpc_handle *h, int on)
 {
     if (!h) return fail(MPC_ERR_ARG, "null handle");
     h->use_mfma = on ? 1 : 0;
+    return MPC_OK;
+}
+
+int mpc_set_row_parallel(mpc_handle *h, int on)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    h->row_parallel = on ? 1 : 0;
     return MPC_OK;
 }
 

@@ -366,6 +366,174 @@ __device__ __forceinline__ void systolic_factor(int stage, int N, const StageLin
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// ROW-PARALLEL RICCATI FACTORISATION (vector ALU + 64-bit DPP).  Same homogeneous formulation as the matrix-core variant
+// below (z~ = (x[5], 1, ua, ual), W~ = [A b_r B; 0 1 0], P~ = [P q; q' .]), but the 8 columns of one stage's matrices are
+// spread over lanes 0..7 of the first 16-lane row of the instance's lane group: lane j holds column j of P~, W~_t, H~aug_t,
+// T = P~ W~ and M~ = H~aug + W~' T.  A product A B then is one  v_fmac_f64_dpp acc_r, A_r(row_newbcast:k), B_k  per (r, k)
+// for ALL columns at once -- the DPP operand reads lane k's register, i.e. an element of the left factor, at full FP64 rate.
+// Per stage: 30 + 40 + 12 DPP FMAs and ~35 ordinary instructions, against ~330 for the one-lane systolic sweep.
+//   * only upper-triangle entries of P~ are ever read (element (r, k), r <= k, is lane k's register r), so the cost-to-go
+//     stays symmetric by construction, exactly as in systolic_factor;
+//   * the per-stage operands come from LDS, staged there by the lanes that own the stages (W~ once per solve, its affine
+//     column and H~aug once per interior-point iteration) and fetched one stage ahead; K~, k and the LDL' factors return
+//     through LDS (they overlay rows 0, 1 of the consumed H~aug_t);
+//   * hazards: a DPP read of a VGPR needs 2 wait states after the VALU write (5 after an EXEC write); every block starts
+//     with the s_nop that covers whatever the compiler scheduled in front of it, inside a block no DPP source is written.
+// ------------------------------------------------------------------------------------------------------------------
+struct RowLds {
+    // per-stage strides are odd: the owning lanes (stage t in lane t) write their blocks in parallel, stride t * WS / t * HS
+    // doubles between lanes, which an even stride would put on one LDS bank
+    static constexpr int WS = 41, HS = 65;
+    static __host__ __device__ constexpr int per_instance(int N) { return WS * N + HS * (N + 1); }   // doubles
+    double *W, *H;     // W[t][k][j] (5 x 8 per stage, t < N), H[t][i][j] (8 x 8 per stage, t <= N)
+    __device__ __forceinline__ RowLds(double *base, int N) : W(base), H(base + WS * N) {}
+};
+
+__device__ __forceinline__ void rowpar_factor(int lane, int N, const RowLds L, bool worker_row)
+{
+    const int j = lane & 7;                     // column; lanes 8..15 of a row mirror 0..7 and store nothing
+    const bool store = worker_row && (lane & 15) < 6;
+    const bool store0 = worker_row && (lane & 15) == 0;
+    const double d5 = (j == 5) ? 1.0 : 0.0;     // row 5 of W~ is e_5'
+    double Pc[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) Pc[r] = L.H[RowLds::HS * N + r * 8 + j];      // P~_N = H~aug_N[0..5][0..5]
+    auto fetch = [&](int t, double Wc[5], double Hc[8]) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) Wc[k] = L.W[RowLds::WS * t + k * 8 + j];
+#pragma unroll
+        for (int i = 0; i < 8; i++) Hc[i] = L.H[RowLds::HS * t + i * 8 + j];
+    };
+    auto step = [&](int t, double Wc[5], double M[8]) {
+        double T[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++) T[r] = Pc[r] * d5;                 // k = 5 term of T = P~ W~
+        asm volatile(
+            "s_nop 4\n"
+            "v_fmac_f64_dpp %0, %6, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %6, %12 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %6, %12 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %6, %12 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %6, %12 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %6, %12 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %0, %6, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %7, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %7, %13 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %7, %13 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %7, %13 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %7, %13 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %0, %6, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %7, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %8, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %8, %14 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %8, %14 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %8, %14 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %0, %6, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %7, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %8, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %9, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %9, %15 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %9, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %0, %6, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %7, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %8, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %9, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %10, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %10, %16 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5])
+            : "v"(Pc[0]), "v"(Pc[1]), "v"(Pc[2]), "v"(Pc[3]), "v"(Pc[4]), "v"(Pc[5]), "v"(Wc[0]), "v"(Wc[1]), "v"(Wc[2]), "v"(Wc[3]), "v"(Wc[4]));
+        // M~ = H~aug + W~' T over the structural non-zeros of W~ (A = I + E, B: 24 of 40 products), rows 6, 7 (the input block) first; then Muu = M~[6..7][6..7] -> L D L' (backward stable, see
+        // systolic_factor) and column j of K~ = -Muu^-1 M~[u, :], computed in every lane and hand-interleaved with the remaining
+        // rows of M~ so that the serial reciprocal / Newton chain (~15 dependent instructions) hides behind independent FMAs
+        double K0, K1, i00, l, i11, m66, m67, m77, e_, r_;
+        asm volatile(
+            "s_nop 1\n"
+            "v_fmac_f64_dpp %6, %18, %23 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %7, %18, %23 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %6, %19, %24 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %7, %19, %24 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %7, %20, %25 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %6, %21, %26 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %7, %22, %27 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %0, %18, %23 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %18, %23 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_mov_b64_dpp %13, %6 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+            "v_mov_b64_dpp %14, %6 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+            "v_mov_b64_dpp %15, %7 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %18, %23 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_rcp_f64_e32 %17, %13\n"
+            "v_fmac_f64_dpp %4, %18, %23 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fma_f64 %16, -%13, %17, 1.0\n"
+            "v_fmac_f64_dpp %5, %18, %23 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fma_f64 %17, %16, %17, %17\n"
+            "v_fmac_f64_dpp %1, %19, %24 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+            "v_fma_f64 %16, -%13, %17, 1.0\n"
+            "v_fmac_f64_dpp %2, %19, %24 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fma_f64 %10, %16, %17, %17\n"
+            "v_fmac_f64_dpp %3, %19, %24 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_mul_f64 %11, %14, %10\n"
+            "v_fmac_f64_dpp %4, %19, %24 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fma_f64 %15, -%11, %14, %15\n"
+            "v_fmac_f64_dpp %5, %19, %24 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_rcp_f64_e32 %17, %15\n"
+            "v_fmac_f64_dpp %2, %20, %25 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fma_f64 %16, -%15, %17, 1.0\n"
+            "v_fmac_f64_dpp %4, %20, %25 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fma_f64 %17, %16, %17, %17\n"
+            "v_fmac_f64_dpp %5, %20, %25 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fma_f64 %16, -%15, %17, 1.0\n"
+            "v_fmac_f64_dpp %3, %21, %26 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fma_f64 %12, %16, %17, %17\n"
+            "v_fmac_f64_dpp %5, %21, %26 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fma_f64 %16, %11, %6, -%7\n"
+            "v_fmac_f64_dpp %4, %22, %27 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_mul_f64 %9, %16, %12\n"
+            "v_mul_f64 %16, %6, %10\n"
+            "v_fmac_f64_dpp %5, %22, %27 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fma_f64 %8, -%11, %9, -%16\n"
+            : "+v"(M[0]), "+v"(M[1]), "+v"(M[2]), "+v"(M[3]), "+v"(M[4]), "+v"(M[5]), "+v"(M[6]), "+v"(M[7]),
+              "=&v"(K0), "=&v"(K1), "=&v"(i00), "=&v"(l), "=&v"(i11), "=&v"(m66), "=&v"(m67), "=&v"(m77), "=&v"(e_), "=&v"(r_)
+            : "v"(Wc[0]), "v"(Wc[1]), "v"(Wc[2]), "v"(Wc[3]), "v"(Wc[4]), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]), "v"(T[4]));
+        M[5] += T[5];                                                  // r = 5 term of W~' T
+        // results go out before the last block, so that the LDS writes have drained when the next operands are waited for
+        double *ko = L.H + RowLds::HS * t;
+        if (store) { ko[j] = K0; ko[8 + j] = K1; }
+        if (store0) { ko[6] = i00; ko[7] = l; ko[14] = i11; }
+        // P~+ = M~[0..5][0..5] + M~[0..5][u] K~   (M~[i][6] = M~[6][i] is lane i's register 6)
+        asm volatile(
+            "s_nop 4\n"
+            "v_fmac_f64_dpp %0, %6, %8 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %6, %8 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %6, %8 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %6, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %6, %8 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %6, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %0, %7, %9 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %7, %9 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %7, %9 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %7, %9 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %7, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %7, %9 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            : "+v"(M[0]), "+v"(M[1]), "+v"(M[2]), "+v"(M[3]), "+v"(M[4]), "+v"(M[5])
+            : "v"(M[6]), "v"(M[7]), "v"(K0), "v"(K1));
+#pragma unroll
+        for (int r = 0; r < 6; r++) Pc[r] = M[r];
+    };
+    // operands of stage t-1 are requested before stage t is computed and moved into place after it, so that the LDS latency
+    // (long for a lone wavefront) hides behind ~500 cycles of arithmetic
+    double Wc[5], Hc[8], Wn[5], Hn[8];
+    fetch(N - 1, Wc, Hc);
+    for (int t = N - 1; t >= 0; t--) {
+        fetch(t > 0 ? t - 1 : 0, Wn, Hn);
+        step(t, Wc, Hc);
+#pragma unroll
+        for (int k = 0; k < 5; k++) Wc[k] = Wn[k];
+#pragma unroll
+        for (int i = 0; i < 8; i++) Hc[i] = Hn[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // MATRIX-CORE RICCATI FACTORISATION (one instance per wavefront).  In homogeneous coordinates
 //     x~ = (x[5], 1),   z~ = (x[5], 1, ua, ual),   W~ = [A b_r B; 0 1 0] (6 x 8),   P~ = [P q; q' .] (6 x 6)
 // one stage is   M~ = H~aug + W~' P~ W~ (8 x 8),   K~ = -Muu^-1 M~[u,:],   P~+ = M~ + M~[:,u] K~,
@@ -511,9 +679,11 @@ __device__ __forceinline__ void systolic_rollout(int stage, int N, const StageLi
 // ------------------------------------------------------------------------------------------------------------------
 // The solve kernel.  grid = batch workgroups of 64 threads (one wavefront per instance); no LDS.
 // ------------------------------------------------------------------------------------------------------------------
-template <int NOBST, int G, bool USE_MFMA>
+// FACT selects the Riccati factorisation sweep: 0 one-lane systolic, 1 matrix cores (G = 64 only), 2 row-parallel DPP.
+template <int NOBST, int G, int FACT>
 __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 {
+    constexpr bool USE_MFMA = FACT == 1, ROWPAR = FACT == 2;
     static_assert(!USE_MFMA || G == 64, "the matrix-core factorisation maps one instance per wavefront");
     constexpr int IPW = 64 / G;               // instances per wavefront
     const int lane = threadIdx.x;
@@ -539,7 +709,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     // obstacle parameters of this stage: explicit P (reference API, parameterize_model) or the look-ahead computed here
     extern __shared__ double lds_raw[];
     const MfmaLds ML(lds_raw, N);             // used only when USE_MFMA (the launch sizes the allocation accordingly)
-    double *lds_P = lds_raw + (USE_MFMA ? MfmaLds::doubles(N) : 0);
+    const RowLds RL(lds_raw + (ROWPAR ? slot * RowLds::per_instance(N) : 0), N);     // used only when ROWPAR
+    double *lds_P = lds_raw + (USE_MFMA ? MfmaLds::doubles(N) : (ROWPAR ? IPW * RowLds::per_instance(N) : 0));
     double pxy[NOBST][2];
     if (p.obst) {
         double *Pl = lds_P + (size_t)slot * (N + 1) * NOBST * 2;
@@ -619,6 +790,15 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             }
             w[MfmaLds::at(5, 5)] = 1.0;
         }
+    }
+    if (ROWPAR && has_u) {      // W~_t = [A b B] rows 0..4 (cols: x0..x4, b, ua, ual); column 5 is rewritten every iteration
+        double *w = RL.W + RowLds::WS * i;
+        const double Wrow[5][8] = {{1.0, 0.0, S.a02, S.a03, S.a04, 0.0, S.b00, S.b01}, {0.0, 1.0, S.a12, S.a13, S.a14, 0.0, S.b10, S.b11},
+                                   {0.0, 0.0, 1.0, 0.0, dt, 0.0, 0.0, h2}, {0.0, 0.0, 0.0, 1.0, 0.0, 0.0, dt, 0.0}, {0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, dt}};
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) w[k * 8 + c] = Wrow[k][c];
     }
     // ---- inequality rows of this stage, in registers ----
     // box variables k: 0 ua, 1 ual, 2 x, 3 y, 4 v, 5 om  -> z index {0,1,2,3,5,6} (also the slot in Hq below)
@@ -820,6 +1000,36 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #pragma unroll
                     for (int c = 0; c < 5; c++) { F.K0[c] = ko[c]; F.K1[c] = ko[6 + c]; }
                     F.k0 = ko[5]; F.k1 = ko[11]; F.i00 = ko[12]; F.l = ko[13]; F.i11 = ko[14];
+                }
+            } else if (ROWPAR) {
+                if (act) {      // H~aug_t, dense 8 x 8, z~ order (x0..x4, 1, ua, ual); affine column of W~_t
+                    const double lu0 = gloc[0] + cb[0], lu1 = gloc[1] + cb[1];
+                    const double Hrow[8][8] = {{Hq[2], Hq[7], 0.0, 0.0, 0.0, gxs[0], 0.0, 0.0}, {Hq[7], Hq[3], 0.0, 0.0, 0.0, gxs[1], 0.0, 0.0},
+                                               {0.0, 0.0, Hq[4], 0.0, 0.0, gxs[2], 0.0, 0.0}, {0.0, 0.0, 0.0, Hq[5], 0.0, gxs[3], 0.0, 0.0},
+                                               {0.0, 0.0, 0.0, 0.0, Hq[6], gxs[4], 0.0, 0.0}, {gxs[0], gxs[1], gxs[2], gxs[3], gxs[4], 0.0, lu0, lu1},
+                                               {0.0, 0.0, 0.0, 0.0, 0.0, lu0, Hq[0], 0.0}, {0.0, 0.0, 0.0, 0.0, 0.0, lu1, 0.0, Hq[1]}};
+                    double *hc = RL.H + RowLds::HS * i;
+#pragma unroll
+                    for (int r = 0; r < 8; r++)
+#pragma unroll
+                        for (int c = 0; c < 8; c++) hc[r * 8 + c] = Hrow[r][c];
+                    if (has_u) {
+#pragma unroll
+                        for (int k = 0; k < 5; k++) RL.W[RowLds::WS * i + k * 8 + 5] = bbr[k];
+                    }
+                }
+                __syncthreads();
+                MPC_TICK(9);
+                rowpar_factor(lane, N, RL, i < 16);
+                __syncthreads();
+                F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;
+#pragma unroll
+                for (int c = 0; c < 5; c++) { F.K0[c] = 0.0; F.K1[c] = 0.0; }
+                if (has_u) {
+                    const double *ko = RL.H + RowLds::HS * i;
+#pragma unroll
+                    for (int c = 0; c < 5; c++) { F.K0[c] = ko[c]; F.K1[c] = ko[8 + c]; }
+                    F.k0 = ko[5]; F.k1 = ko[13]; F.i00 = ko[6]; F.l = ko[7]; F.i11 = ko[14];
                 }
             } else
                 systolic_factor(i, N, S, Hq, gloc[0] + cb[0], gloc[1] + cb[1], gxs, bbr, rhoPi != 0.0, F);

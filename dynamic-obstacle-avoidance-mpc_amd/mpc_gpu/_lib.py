@@ -68,6 +68,7 @@ SYMBOLS = {
     "mpc_set_lanes_per_instance": (C.c_int, [_vp, C.c_int]),
     "mpc_get_lanes_per_instance": (C.c_int, [_vp, C.c_int]),
     "mpc_set_matrix_cores": (C.c_int, [_vp, C.c_int]),
+    "mpc_set_row_parallel": (C.c_int, [_vp, C.c_int]),
 }
 
 _LIB = None

@@ -160,5 +160,15 @@ class BatchedMpc:
         _lib.check(_lib.lib().mpc_profile_read(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def set_row_parallel(self, on=True):
+        """Riccati factorisation sweep: row-parallel 64-bit-DPP variant (True) or one-lane systolic sweep (False)."""
+        _lib.check(_lib.lib().mpc_set_row_parallel(self._h, 1 if on else 0))
+
+    def set_matrix_cores(self, on=True):
+        _lib.check(_lib.lib().mpc_set_matrix_cores(self._h, 1 if on else 0))
+
+    def set_lanes_per_instance(self, lanes):
+        _lib.check(_lib.lib().mpc_set_lanes_per_instance(self._h, int(lanes)))
+
     def lanes_per_instance(self, batch):
         return _lib.lib().mpc_get_lanes_per_instance(self._h, batch)

@@ -168,6 +168,11 @@ int mpc_get_lanes_per_instance(mpc_handle *h, int batch);
  * MI355X the two are equally fast (FP64 MFMA rate = FP64 vector rate, 116-cycle dependent MFMA links) and the vector
  * path is more accurate on ill-conditioned stages, hence the default; see DESIGN.md section 4. */
 int mpc_set_matrix_cores(mpc_handle *h, int on);
+/* Riccati factorisation sweep of the interior point (same arithmetic specification, different lane mapping).
+ * 1: row-parallel -- the 8 columns of a stage's homogeneous blocks sit in 8 lanes of a 16-lane DPP row and the
+ * products run as v_fmac_f64_dpp row_newbcast chains (~130 instead of ~330 wave instructions per stage).
+ * 0: one-lane systolic sweep.  No reference counterpart (tuning / test hook). */
+int mpc_set_row_parallel(mpc_handle *h, int on);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ for _ in range(10): loop.step()
 torch.cuda.synchronize()
 tr = np.zeros((B, 50, 4)); _lib.check(_lib.lib().mpc_debug_trace(loop.m._h, 1, B, tr.ctypes.data))
 t = tr.reshape(B, -1)[:, :10]
-names = ["mu/conv check", "predictor assemble", "factor sweep", "rollout (affine)", "affine step + sigma", "corrector rhs", "corrector sweep", "rollout", "combined step + update", "-"]
+names = ["mu/conv check", "predictor assemble", "factor sweep", "rollout (affine)", "affine step + sigma", "corrector rhs", "corrector sweep", "rollout", "combined step + update", "(row-parallel: stage operands -> LDS)"]
 tot = t.sum(1).mean(); it = loop.iters.double().mean().item()
 print(f"B={B} mean IPM iters {it:.2f}  total cycles/solve (IPM loop) {tot:.0f}  per iteration {tot/it:.0f}")
-for k, n in enumerate(names[:9]): print(f"  {n:24s} {t[:,k].mean():10.0f} cycles  {100*t[:,k].mean()/tot:5.1f}%   per iter {t[:,k].mean()/it:8.0f}")
+for k, n in enumerate(names[:10]): print(f"  {n:24s} {t[:,k].mean():10.0f} cycles  {100*t[:,k].mean()/tot:5.1f}%   per iter {t[:,k].mean()/it:8.0f}")

@@ -229,6 +229,7 @@ def test_matrix_core_factorisation_matches_vector_path(env):
         for mf in (1, 0):
             with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
                 _lib.check(_lib.lib().mpc_set_matrix_cores(s._h, mf))
+                s.set_row_parallel(False)      # the comparison is against the one-lane systolic sweep
                 _lib.check(_lib.lib().mpc_set_lanes_per_instance(s._h, 64))
                 s.reset_guess(x0); g = s.solve(x0, obst, goal); X, U = s.get_traj(B)
                 s.shift(B); g2 = s.solve(x0, obst, goal); X2, U2 = s.get_traj(B)       # second step: d0 != 0, defects != 0
@@ -241,3 +242,37 @@ def test_matrix_core_factorisation_matches_vector_path(env):
         d1 = np.abs(out[1][1] - out[0][1]).reshape(B, -1).max(1)[ok]; d2 = np.abs(out[1][4] - out[0][4]).reshape(B, -1).max(1)[ok]
         assert np.median(d1) < 1e-9 and np.median(d2) < 1e-9
         assert np.sort(d1)[-2] < 1e-6 and np.sort(d2)[-2] < 1e-5 and np.quantile(d2, 0.9) < 1e-6   # a sensitive instance or two allowed (on one the oracle at 1e-8 and 1e-12 differ by 5e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,no,B,lanes", [(20, 3, 300, 0), (20, 3, 65, 64), (10, 5, 130, 0), (50, 10, 40, 0), (5, 3, 77, 0)])
+def test_row_parallel_factorisation_matches_systolic_and_oracle(env, N, no, B, lanes):
+    """row-parallel (v_fmac_f64_dpp row_newbcast) Riccati factorisation vs the one-lane systolic sweep and vs the oracle:
+    same statuses and iteration counts, iterates equal to rounding; every lanes-per-instance packing"""
+    mpc_gpu, orc = env
+    x0, goal, obst = random_batch(B, no, seed=71 + N)
+    out = {}
+    for rp in (1, 0):
+        with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
+            s.set_row_parallel(rp)
+            if lanes:
+                s.set_lanes_per_instance(lanes)
+            s.reset_guess(x0); g = s.solve(x0, obst, goal); X, U = s.get_traj(B)
+            s.shift(B); g2 = s.solve(x0, obst, goal); X2, U2 = s.get_traj(B)       # second step: d0 != 0, defects != 0
+            out[rp] = (g, X, U, g2, X2, U2)
+    for a, b in ((0, 1), (3, 4)):
+        assert (out[1][a]["status"] == out[0][a]["status"]).mean() > 0.98
+        ok = (out[1][a]["status"] == 0) & (out[0][a]["status"] == 0)
+        assert ok.mean() > 0.9
+        assert (out[1][a]["iters"][ok] == out[0][a]["iters"][ok]).mean() > 0.95
+        d = np.abs(out[1][b] - out[0][b]).reshape(B, -1).max(1)[ok]
+        # both paths are equally close to the oracle (debug_rowpar.py); ill-conditioned long horizons move by ~1e-5 under rounding
+        assert np.median(d) < 1e-10 and np.quantile(d, 0.95) < (1e-7 if N <= 20 else 2e-6) and d.max() < (1e-6 if N <= 20 else 1e-4)
+    # against the oracle on the first solve
+    cfg = orc.config(N, no, 0.1 * N)
+    P = oracle_P(orc, cfg, obst); Xg, Ug = oracle_guess(orc, cfg, x0)
+    o = orc.rti_solve_batch(cfg, x0, P, goal, Xg, Ug)
+    ok = (o["status"] == 0) & (out[1][0]["status"] == 0)
+    assert ok.mean() > 0.9 and (o["status"] == out[1][0]["status"]).mean() > 0.98
+    assert np.abs(out[1][1] - o["X"])[ok].max() < (1e-6 if N <= 20 else 5e-5)
+    assert (o["iters"][ok] == out[1][0]["iters"][ok]).mean() > 0.95
