@@ -117,7 +117,7 @@ int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
     const bool use_mfma = (G == 64) && h->use_mfma;
     const bool rowpar = !use_mfma && h->row_parallel;
     const size_t lds = ((p.obst ? (size_t)(64 / G) * (p.N + 1) * h->cfg.n_obst * 2 : 0) + (use_mfma ? (size_t)mpc::MfmaLds::doubles(p.N) : 0) +
-                        (rowpar ? (size_t)(64 / G) * mpc::RowLds::per_instance(p.N) : 0)) * sizeof(double);
+                        (rowpar ? (size_t)mpc::RowLds::total(p.N, 64 / G) : 0)) * sizeof(double);
 #define MPC_LAUNCH(NO, GG, MF) hipLaunchKernelGGL((mpc::rti_solve_kernel<NO, GG, MF>), grid, block, lds, s, p)
 #define MPC_LAUNCH_G(NO) do { if (G == 16) { if (rowpar) MPC_LAUNCH(NO, 16, 2); else MPC_LAUNCH(NO, 16, 0); } \
                               else if (G == 32) { if (rowpar) MPC_LAUNCH(NO, 32, 2); else MPC_LAUNCH(NO, 32, 0); } \

@@ -384,7 +384,14 @@ struct RowLds {
     // per-stage strides are odd: the owning lanes (stage t in lane t) write their blocks in parallel, stride t * WS / t * HS
     // doubles between lanes, which an even stride would put on one LDS bank
     static constexpr int WS = 41, HS = 65;
+    // The vector recursions request operands AHEAD stage blocks in advance without clamping the stage index: behind the last
+    // instance's H that lands in a rear padding, in front of H in the instance's own W region (plus a front padding when
+    // W is shorter than that).  Lanes that have nothing to store write into the unused tail [TAIL..HS) of the stage blocks.
+    static constexpr int AHEAD = 3, TAIL = 48;
     static __host__ __device__ constexpr int per_instance(int N) { return WS * N + HS * (N + 1); }   // doubles
+    static __host__ __device__ constexpr int pad_front(int N) { return AHEAD * HS > WS * N ? AHEAD * HS - WS * N : 0; }
+    static __host__ __device__ constexpr int pad_rear() { return AHEAD * HS; }
+    static __host__ __device__ constexpr int total(int N, int instances) { return pad_front(N) + instances * per_instance(N) + pad_rear(); }
     double *W, *H;     // W[t][k][j] (5 x 8 per stage, t < N), H[t][i][j] (8 x 8 per stage, t <= N)
     __device__ __forceinline__ RowLds(double *base, int N) : W(base), H(base + WS * N) {}
 };
@@ -530,6 +537,79 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const RowLds L, b
         for (int k = 0; k < 5; k++) Wc[k] = Wn[k];
 #pragma unroll
         for (int i = 0; i < 8; i++) Hc[i] = Hn[i];
+    }
+}
+
+// ROW-PARALLEL VECTOR RECURSIONS.  With the closed-loop matrix Acl_t = A_t + B_t K_t (5 x 5, computed by the lane that owns
+// stage t, for all stages at once) in LDS, the forward rollout  dx_{t+1} = Acl_t dx_t + c_t  and the backward (adjoint)
+// recursion  p_t = c~_t + Acl_t' p_{t+1}  are 5 x 5 matrix-vector products per stage: lane r of the instance's first DPP row
+// holds row r (forward) resp. column r (backward) of Acl_t and element r of the travelling vector, and one product is five
+// v_fmac_f64_dpp with the vector element broadcast from lane j (~20 wave instructions per stage instead of ~60 for the
+// one-lane systolic sweeps).  Every stage's vector is left in LDS for the lane that owns the stage.
+// LDS use (per stage, inside the H~aug_t block that is dead after the factorisation): [0..29] rows [Acl[r][0..4], c[r]],
+// [30..34] c~, [35..39] dx_t, [40..44] p_t.
+struct RowVec { static constexpr int ACL = 0, RS = 6, CT = 30, X = 35, P = 40; };
+
+// FWD: dx_{t+1} = Acl_t dx_t + c_t for t = 0..N-1 (dx_0 from the stage-0 block).  !FWD: p_t = c~_t + Acl_t' p_{t+1} for
+// t = N-1..1 (p_N = c~_N; p_0, the multiplier of the fixed initial state, is not needed).  A stage costs ~13 instructions, far
+// less than the LDS latency of a lone wavefront, so the operands travel through a ring of four register sets and are requested
+// three stages ahead (RowLds::AHEAD; running past the ends is harmless); stores are unconditional (idle lanes hit block tails).
+template <bool FWD>
+__device__ __forceinline__ void rowpar_vector(int lane, int N, const RowLds L, bool worker_row)
+{
+    constexpr int D = 4, HS = RowLds::HS;
+    const int r = lane & 7, rc = r < 5 ? r : 0;
+    const bool store = worker_row && (lane & 15) < 5;
+    const int Q = FWD ? N : N - 1;                                  // number of stage steps
+    double v = FWD ? L.H[RowVec::X + r] : L.H[HS * N + RowVec::CT + r];
+    if (!FWD && store) L.H[HS * N + RowVec::P + r] = v;
+    // step q works on stage t = q (FWD) / N-1-q (!FWD); src points at the lane's operands of step 0, dst at the place of
+    // the vector produced by step 0; both move by one stage block per step (dst of an idle lane stays in the rear padding)
+    const double *src = L.H + (FWD ? 0 : HS * (N - 1)) + RowVec::ACL + (FWD ? rc * RowVec::RS : rc);
+    double *dst = L.H + (FWD ? HS : HS * (N - 1)) + (store ? (FWD ? RowVec::X : RowVec::P) + r : RowLds::TAIL + (lane & 15));   // idle lanes: block tail
+    constexpr int dstep = FWD ? HS : -HS;
+    double A[D][5], c[D];
+    auto fetch = [&](const double *blk, double a[5], double &cc) {
+        if (FWD) {          // row r of Acl_t and c_t[r]: six consecutive doubles
+#pragma unroll
+            for (int k = 0; k < 5; k++) a[k] = blk[k];
+            cc = blk[5];
+        } else {            // column r of Acl_t, and c~_t[r]
+#pragma unroll
+            for (int k = 0; k < 5; k++) a[k] = blk[k * RowVec::RS];
+            cc = blk[RowVec::CT];
+        }
+    };
+    auto stage = [&](double a[5], double &cc, double *out) {
+        asm volatile(
+                "s_nop 1\n"
+                "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f64_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f64_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+                : "+v"(cc) : "v"(v), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]));
+        v = cc;
+        *out = v;
+    };
+    constexpr int SS = FWD ? HS : -HS;                              // stage stride of src
+#pragma unroll
+    for (int u = 0; u < D - 1; u++) fetch(src + u * SS, A[u], c[u]);
+    int qb = 0;
+    for (; qb + D <= Q; qb += D) {
+#pragma unroll
+        for (int u = 0; u < D; u++) {
+            fetch(src + (u + D - 1) * SS, A[(u + D - 1) % D], c[(u + D - 1) % D]);
+            stage(A[u], c[u], dst + u * SS);
+        }
+        src += D * SS; dst += D * dstep;
+    }
+#pragma unroll
+    for (int u = 0; u < D - 1; u++) {
+        if (qb + u < Q) {
+            fetch(src + (u + D - 1) * SS, A[(u + D - 1) % D], c[(u + D - 1) % D]);
+            stage(A[u], c[u], dst + u * SS);
+        }
     }
 }
 
@@ -709,8 +789,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     // obstacle parameters of this stage: explicit P (reference API, parameterize_model) or the look-ahead computed here
     extern __shared__ double lds_raw[];
     const MfmaLds ML(lds_raw, N);             // used only when USE_MFMA (the launch sizes the allocation accordingly)
-    const RowLds RL(lds_raw + (ROWPAR ? slot * RowLds::per_instance(N) : 0), N);     // used only when ROWPAR
-    double *lds_P = lds_raw + (USE_MFMA ? MfmaLds::doubles(N) : (ROWPAR ? IPW * RowLds::per_instance(N) : 0));
+    const RowLds RL(lds_raw + (ROWPAR ? RowLds::pad_front(N) + slot * RowLds::per_instance(N) : 0), N);     // used only when ROWPAR
+    double *lds_P = lds_raw + (USE_MFMA ? MfmaLds::doubles(N) : (ROWPAR ? RowLds::total(N, IPW) : 0));
     double pxy[NOBST][2];
     if (p.obst) {
         double *Pl = lds_P + (size_t)slot * (N + 1) * NOBST * 2;
@@ -1031,11 +1111,46 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                     for (int c = 0; c < 5; c++) { F.K0[c] = ko[c]; F.K1[c] = ko[8 + c]; }
                     F.k0 = ko[5]; F.k1 = ko[13]; F.i00 = ko[6]; F.l = ko[7]; F.i11 = ko[14];
                 }
+                __syncthreads();
+                if (has_u) {    // closed-loop matrix Acl = A + B K of this stage, row-major, for the row-parallel vector recursions
+                    double *acl = RL.H + RowLds::HS * i + RowVec::ACL;
+                    const double Ar[2][5] = {{1.0, 0.0, S.a02, S.a03, S.a04}, {0.0, 1.0, S.a12, S.a13, S.a14}};
+                    const double Br[2][2] = {{S.b00, S.b01}, {S.b10, S.b11}};
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        acl[0 * RowVec::RS + c] = Ar[0][c] + Br[0][0] * F.K0[c] + Br[0][1] * F.K1[c];
+                        acl[1 * RowVec::RS + c] = Ar[1][c] + Br[1][0] * F.K0[c] + Br[1][1] * F.K1[c];
+                        acl[2 * RowVec::RS + c] = (c == 2 ? 1.0 : (c == 4 ? dt : 0.0)) + h2 * F.K1[c];
+                        acl[3 * RowVec::RS + c] = (c == 3 ? 1.0 : 0.0) + dt * F.K0[c];
+                        acl[4 * RowVec::RS + c] = (c == 4 ? 1.0 : 0.0) + dt * F.K1[c];
+                    }
+                }
             } else
                 systolic_factor(i, N, S, Hq, gloc[0] + cb[0], gloc[1] + cb[1], gxs, bbr, rhoPi != 0.0, F);
         }
         MPC_TICK(2);
-        systolic_rollout<true>(i, N, S, F, x_init, bbr, za);
+        if (ROWPAR) {
+            if (has_u) {        // c_t = r_b + B k
+                double *cc = RL.H + RowLds::HS * i + RowVec::ACL + 5;      // c[r] closes row r
+                cc[0 * RowVec::RS] = bbr[0] + S.b00 * F.k0 + S.b01 * F.k1; cc[1 * RowVec::RS] = bbr[1] + S.b10 * F.k0 + S.b11 * F.k1;
+                cc[2 * RowVec::RS] = bbr[2] + h2 * F.k1; cc[3 * RowVec::RS] = bbr[3] + dt * F.k0; cc[4 * RowVec::RS] = bbr[4] + dt * F.k1;
+            }
+            if (i == 0) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = x_init[c];
+            }
+            __syncthreads();
+            rowpar_vector<true>(lane, N, RL, i < 16);
+            __syncthreads();
+            if (act) {
+                const double *xx = RL.H + RowLds::HS * i + RowVec::X;
+                double u0 = F.k0, u1 = F.k1;
+#pragma unroll
+                for (int c = 0; c < 5; c++) { za[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }
+                za[0] = u0; za[1] = u1;
+            }
+        } else
+            systolic_rollout<true>(i, N, S, F, x_init, bbr, za);
         MPC_TICK(3);
 
         // ---- affine step: dt, dlam per row, step ratios, products dlam_aff * dt_aff ----
@@ -1136,10 +1251,49 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 }
             }
             MPC_TICK(5);
-            systolic_corrector(i, N, S, gc, F);
+            if (ROWPAR) {
+                if (act) {      // c~_t = gc_x + K' gc_u  (K = 0 in the terminal lane)
+                    double *cc = RL.H + RowLds::HS * i + RowVec::CT;
+#pragma unroll
+                    for (int c = 0; c < 5; c++) cc[c] = gc[2 + c] + F.K0[c] * gc[0] + F.K1[c] * gc[1];
+                }
+                __syncthreads();
+                rowpar_vector<false>(lane, N, RL, i < 16);
+                __syncthreads();
+                if (has_u) {    // feed-forward of the corrector right-hand side: k = -Muu^-1 (gc_u + B' p_{t+1})
+                    const double *pp = RL.H + RowLds::HS * (i + 1) + RowVec::P;
+                    const double pv[5] = {pp[0], pp[1], pp[2], pp[3], pp[4]};
+                    const double m0 = gc[0] + S.dua(pv), m1 = gc[1] + S.dual(pv);
+                    F.k1 = fma(F.l, m0, -m1) * F.i11;
+                    F.k0 = fma(-F.l, F.k1, -(m0 * F.i00));
+                }
+            } else
+                systolic_corrector(i, N, S, gc, F);
         }
         MPC_TICK(6);
-        systolic_rollout<false>(i, N, S, F, x_init, bbr, dz);
+        if (ROWPAR) {
+            __syncthreads();
+            if (has_u) {        // homogeneous dynamics: c_t = B k
+                double *cc = RL.H + RowLds::HS * i + RowVec::ACL + 5;
+                cc[0 * RowVec::RS] = S.b00 * F.k0 + S.b01 * F.k1; cc[1 * RowVec::RS] = S.b10 * F.k0 + S.b11 * F.k1;
+                cc[2 * RowVec::RS] = h2 * F.k1; cc[3 * RowVec::RS] = dt * F.k0; cc[4 * RowVec::RS] = dt * F.k1;
+            }
+            if (i == 0) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = 0.0;
+            }
+            __syncthreads();
+            rowpar_vector<true>(lane, N, RL, i < 16);
+            __syncthreads();
+            if (act) {
+                const double *xx = RL.H + RowLds::HS * i + RowVec::X;
+                double u0 = F.k0, u1 = F.k1;
+#pragma unroll
+                for (int c = 0; c < 5; c++) { dz[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }
+                dz[0] = u0; dz[1] = u1;
+            }
+        } else
+            systolic_rollout<false>(i, N, S, F, x_init, bbr, dz);
 #pragma unroll
         for (int c = 0; c < 7; c++) dz[c] += za[c];
         MPC_TICK(7);
