@@ -389,7 +389,7 @@ struct RowLds {
     // W is shorter than that).  Lanes that have nothing to store write into the unused tail [TAIL..HS) of the stage blocks.
     static constexpr int AHEAD = 3, TAIL = 48;
     static __host__ __device__ constexpr int per_instance(int N) { return WS * N + HS * (N + 1); }   // doubles
-    static __host__ __device__ constexpr int pad_front(int N) { return AHEAD * HS > WS * N ? AHEAD * HS - WS * N : 0; }
+    static __host__ __device__ constexpr int pad_front(int N) { return AHEAD * HS > WS * (N - 1) ? AHEAD * HS - WS * (N - 1) : WS; }   // >= one W block
     static __host__ __device__ constexpr int pad_rear() { return AHEAD * HS; }
     static __host__ __device__ constexpr int total(int N, int instances) { return pad_front(N) + instances * per_instance(N) + pad_rear(); }
     double *W, *H;     // W[t][k][j] (5 x 8 per stage, t < N), H[t][i][j] (8 x 8 per stage, t <= N)
@@ -398,21 +398,23 @@ struct RowLds {
 
 __device__ __forceinline__ void rowpar_factor(int lane, int N, const RowLds L, bool worker_row)
 {
-    const int j = lane & 7;                     // column; lanes 8..15 of a row mirror 0..7 and store nothing
-    const bool store = worker_row && (lane & 15) < 6;
-    const bool store0 = worker_row && (lane & 15) == 0;
+    constexpr int WS = RowLds::WS, HS = RowLds::HS;
+    const int j = lane & 7, l15 = lane & 15;    // column; lanes 8..15 of a row mirror 0..7
+    const bool store = worker_row && l15 < 6, store0 = worker_row && l15 == 0;
     const double d5 = (j == 5) ? 1.0 : 0.0;     // row 5 of W~ is e_5'
-    double Pc[6];
-#pragma unroll
-    for (int r = 0; r < 6; r++) Pc[r] = L.H[RowLds::HS * N + r * 8 + j];      // P~_N = H~aug_N[0..5][0..5]
+    // Results overlay rows 0, 1 of the consumed H~aug_t: K~[0][j] at [j], K~[1][j] at [8 + j], 1/d0, l, 1/d1 at [6], [7], [14].
+    // Stores are unconditional: lanes with nothing to store write into dead parts of the same block ([16..63]).
+    double *k0p = L.H + (store ? j : 48), *k1p = L.H + (store ? 8 + j : 49);
+    double *f0p = L.H + (store0 ? 6 : 50), *f1p = L.H + (store0 ? 7 : 50), *f2p = L.H + (store0 ? 14 : 50);
+    const double *wp = L.W + j, *hp = L.H + j;
     auto fetch = [&](int t, double Wc[5], double Hc[8]) {
 #pragma unroll
-        for (int k = 0; k < 5; k++) Wc[k] = L.W[RowLds::WS * t + k * 8 + j];
+        for (int k = 0; k < 5; k++) Wc[k] = wp[WS * t + k * 8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) Hc[i] = L.H[RowLds::HS * t + i * 8 + j];
+        for (int i = 0; i < 8; i++) Hc[i] = hp[HS * t + i * 8];
     };
-    auto step = [&](int t, double Wc[5], double M[8]) {
-        double T[6];
+    // first half of a stage: T = P~ W~ from the previous stage's P~ (the upper-left 6 x 6 of its M registers)
+    auto stepT = [&](const double Wc[5], const double Pc[8], double T[6]) {
 #pragma unroll
         for (int r = 0; r < 6; r++) T[r] = Pc[r] * d5;                 // k = 5 term of T = P~ W~
         asm volatile(
@@ -449,9 +451,13 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const RowLds L, b
             "v_fmac_f64_dpp %5, %10, %16 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
             : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5])
             : "v"(Pc[0]), "v"(Pc[1]), "v"(Pc[2]), "v"(Pc[3]), "v"(Pc[4]), "v"(Pc[5]), "v"(Wc[0]), "v"(Wc[1]), "v"(Wc[2]), "v"(Wc[3]), "v"(Wc[4]));
-        // M~ = H~aug + W~' T over the structural non-zeros of W~ (A = I + E, B: 24 of 40 products), rows 6, 7 (the input block) first; then Muu = M~[6..7][6..7] -> L D L' (backward stable, see
-        // systolic_factor) and column j of K~ = -Muu^-1 M~[u, :], computed in every lane and hand-interleaved with the remaining
-        // rows of M~ so that the serial reciprocal / Newton chain (~15 dependent instructions) hides behind independent FMAs
+    };
+    // second half: M~ (accumulated onto the H~aug column in M), L D L' of Muu, column j of K~, P~+ in M[0..5]
+    auto stepM = [&](int t, const double Wc[5], double M[8], const double T[6]) {
+        // M~ = H~aug + W~' T over the structural non-zeros of W~ (A = I + E, B: 24 of 40 products), rows 6, 7 (the input block) first;
+        // then Muu = M~[6..7][6..7] -> L D L' (backward stable, see systolic_factor) and column j of K~ = -Muu^-1 M~[u, :],
+        // computed in every lane and hand-interleaved with the remaining rows of M~ so that the serial reciprocal / Newton
+        // chain (~15 dependent instructions) hides behind independent FMAs
         double K0, K1, i00, l, i11, m66, m67, m77, e_, r_;
         asm volatile(
             "s_nop 1\n"
@@ -502,10 +508,8 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const RowLds L, b
               "=&v"(K0), "=&v"(K1), "=&v"(i00), "=&v"(l), "=&v"(i11), "=&v"(m66), "=&v"(m67), "=&v"(m77), "=&v"(e_), "=&v"(r_)
             : "v"(Wc[0]), "v"(Wc[1]), "v"(Wc[2]), "v"(Wc[3]), "v"(Wc[4]), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]), "v"(T[4]));
         M[5] += T[5];                                                  // r = 5 term of W~' T
-        // results go out before the last block, so that the LDS writes have drained when the next operands are waited for
-        double *ko = L.H + RowLds::HS * t;
-        if (store) { ko[j] = K0; ko[8 + j] = K1; }
-        if (store0) { ko[6] = i00; ko[7] = l; ko[14] = i11; }
+        k0p[HS * t] = K0; k1p[HS * t] = K1;
+        f0p[HS * t] = i00; f1p[HS * t] = l; f2p[HS * t] = i11;
         // P~+ = M~[0..5][0..5] + M~[0..5][u] K~   (M~[i][6] = M~[6][i] is lane i's register 6)
         asm volatile(
             "s_nop 4\n"
@@ -523,21 +527,20 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const RowLds L, b
             "v_fmac_f64_dpp %5, %7, %9 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
             : "+v"(M[0]), "+v"(M[1]), "+v"(M[2]), "+v"(M[3]), "+v"(M[4]), "+v"(M[5])
             : "v"(M[6]), "v"(M[7]), "v"(K0), "v"(K1));
-#pragma unroll
-        for (int r = 0; r < 6; r++) Pc[r] = M[r];
     };
-    // operands of stage t-1 are requested before stage t is computed and moved into place after it, so that the LDS latency
-    // (long for a lone wavefront) hides behind ~500 cycles of arithmetic
-    double Wc[5], Hc[8], Wn[5], Hn[8];
-    fetch(N - 1, Wc, Hc);
-    for (int t = N - 1; t >= 0; t--) {
-        fetch(t > 0 ? t - 1 : 0, Wn, Hn);
-        step(t, Wc, Hc);
+    // Two register sets alternate: while stage t runs on (Wa, Ma) with P~ taken from Mb, the operands of stage t-1 are
+    // requested into (Wb, Mb) as soon as the T block has consumed Mb -- a stage is ~600 cycles of arithmetic, far more than
+    // the LDS latency of a lone wavefront -- and the stage's result P~+ stays in Ma for the next stage.  No register copies.
+    double Wa[5], Ma[8], Wb[5], Mb[8], T[6];
 #pragma unroll
-        for (int k = 0; k < 5; k++) Wc[k] = Wn[k];
-#pragma unroll
-        for (int i = 0; i < 8; i++) Hc[i] = Hn[i];
+    for (int r = 0; r < 6; r++) Mb[r] = hp[HS * N + r * 8];           // P~_N = H~aug_N[0..5][0..5]
+    fetch(N - 1, Wa, Ma);
+    int t = N - 1;
+    for (; t >= 1; t -= 2) {
+        stepT(Wa, Mb, T); fetch(t - 1, Wb, Mb); stepM(t, Wa, Ma, T);
+        stepT(Wb, Ma, T); fetch(t - 2, Wa, Ma); stepM(t - 1, Wb, Mb, T);      // t - 2 = -1 reads the (dead) block in front
     }
+    if (t == 0) { stepT(Wa, Mb, T); stepM(0, Wa, Ma, T); }
 }
 
 // ROW-PARALLEL VECTOR RECURSIONS.  With the closed-loop matrix Acl_t = A_t + B_t K_t (5 x 5, computed by the lane that owns
@@ -566,48 +569,47 @@ __device__ __forceinline__ void rowpar_vector(int lane, int N, const RowLds L, b
     // step q works on stage t = q (FWD) / N-1-q (!FWD); src points at the lane's operands of step 0, dst at the place of
     // the vector produced by step 0; both move by one stage block per step (dst of an idle lane stays in the rear padding)
     const double *src = L.H + (FWD ? 0 : HS * (N - 1)) + RowVec::ACL + (FWD ? rc * RowVec::RS : rc);
-    double *dst = L.H + (FWD ? HS : HS * (N - 1)) + (store ? (FWD ? RowVec::X : RowVec::P) + r : RowLds::TAIL + (lane & 15));   // idle lanes: block tail
+    double *dst = L.H + (FWD ? HS : HS * (N - 1)) + (store ? (FWD ? RowVec::X : RowVec::P) + r : RowLds::TAIL);   // idle lanes: one dead word of the block
     constexpr int dstep = FWD ? HS : -HS;
     double A[D][5], c[D];
-    auto fetch = [&](const double *blk, double a[5], double &cc) {
-        if (FWD) {          // row r of Acl_t and c_t[r]: six consecutive doubles
+    const double *srcc = src + (FWD ? 5 : RowVec::CT);
+    auto fetch = [&](const double *blk, const double *blkc, double a[5], double &cc) {
 #pragma unroll
-            for (int k = 0; k < 5; k++) a[k] = blk[k];
-            cc = blk[5];
-        } else {            // column r of Acl_t, and c~_t[r]
-#pragma unroll
-            for (int k = 0; k < 5; k++) a[k] = blk[k * RowVec::RS];
-            cc = blk[RowVec::CT];
-        }
+        for (int k = 0; k < 5; k++) a[k] = blk[FWD ? k : k * RowVec::RS];      // row r (FWD) / column r of Acl_t
+        cc = *blkc;                                                            // c_t[r] / c~_t[r]
     };
-    auto stage = [&](double a[5], double &cc, double *out) {
+    // The accumulator starts as a copy of c made INSIDE the block: an in-out operand that arrives as half of a ds_read2_b64
+    // tuple would be copied out by the compiler behind an s_waitcnt right after the request was issued (a full LDS latency).
+    auto stage = [&](const double a[5], double cc, double *out) {
+        double acc;
         asm volatile(
                 "s_nop 1\n"
-                "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
-                "v_fmac_f64_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
-                "v_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
-                "v_fmac_f64_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
-                "v_fmac_f64_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
-                : "+v"(cc) : "v"(v), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]));
-        v = cc;
+                "v_mov_b64_e32 %0, %2\n"
+                "v_fmac_f64_dpp %0, %1, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f64_dpp %0, %1, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f64_dpp %0, %1, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f64_dpp %0, %1, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f64_dpp %0, %1, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+                : "=&v"(acc) : "v"(v), "v"(cc), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]));
+        v = acc;
         *out = v;
     };
     constexpr int SS = FWD ? HS : -HS;                              // stage stride of src
 #pragma unroll
-    for (int u = 0; u < D - 1; u++) fetch(src + u * SS, A[u], c[u]);
+    for (int u = 0; u < D - 1; u++) fetch(src + u * SS, srcc + u * SS, A[u], c[u]);
     int qb = 0;
     for (; qb + D <= Q; qb += D) {
 #pragma unroll
         for (int u = 0; u < D; u++) {
-            fetch(src + (u + D - 1) * SS, A[(u + D - 1) % D], c[(u + D - 1) % D]);
+            fetch(src + (u + D - 1) * SS, srcc + (u + D - 1) * SS, A[(u + D - 1) % D], c[(u + D - 1) % D]);
             stage(A[u], c[u], dst + u * SS);
         }
-        src += D * SS; dst += D * dstep;
+        src += D * SS; srcc += D * SS; dst += D * dstep;
     }
 #pragma unroll
     for (int u = 0; u < D - 1; u++) {
         if (qb + u < Q) {
-            fetch(src + (u + D - 1) * SS, A[(u + D - 1) % D], c[(u + D - 1) % D]);
+            fetch(src + (u + D - 1) * SS, srcc + (u + D - 1) * SS, A[(u + D - 1) % D], c[(u + D - 1) % D]);
             stage(A[u], c[u], dst + u * SS);
         }
     }
