@@ -249,7 +249,7 @@ def main():
     avg_kernel_s = kern_ms / max(1, launches) * 1e-3
     abytes = algorithmic_bytes_per_solve(N, no, fused=True) * batch
     lanes = loop.m.lanes_per_instance(batch)
-    kname = f"rti_solve_kernel<{no}, {lanes}, false>"
+    kname = f"rti_solve_kernel<{no}, {lanes}, 2>"       # <n_obst, lanes per instance, row-parallel sweeps>
     roof = {"bound": "hbm", "achieved": abytes / avg_kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": abytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic(kname, batch),
             "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_final_pmc_summary.json (FETCH_SIZE uncorrected: 8-byte-per-lane loads, see DESIGN.md section 5)",

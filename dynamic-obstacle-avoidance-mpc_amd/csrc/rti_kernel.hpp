@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                     for (int c = 0; c < 5; c++) { F.K0[c] = ko[c]; F.K1[c] = ko[8 + c]; }
                     F.k0 = ko[5]; F.k1 = ko[13]; F.i00 = ko[6]; F.l = ko[7]; F.i11 = ko[14];
                 }
-                __syncthreads();
+                // (no barrier: every lane overwrites only the block it has just read, and a wavefront's LDS operations complete in order)
                 if (has_u) {    // closed-loop matrix Acl = A + B K of this stage, row-major, for the row-parallel vector recursions
                     double *acl = RL.H + RowLds::HS * i + RowVec::ACL;
                     const double Ar[2][5] = {{1.0, 0.0, S.a02, S.a03, S.a04}, {0.0, 1.0, S.a12, S.a13, S.a14}};
@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                     dll_[k] = -(ll[k] * tl[k] + ll[k] * dtl_[k]) * rtl[k]; dlh_[k] = -(lh[k] * th[k] + lh[k] * dth_[k]) * rth[k];
                     ppl[k] = dll_[k] * dtl_[k]; pph[k] = dlh_[k] * dth_[k];
                     rmax = fmax(rmax, fmax(-dtl_[k] * rtl[k], -dth_[k] * rth[k]));
-                    rmaxd = fmax(rmaxd, fmax(-dll_[k] * rcp_nr(ll[k]), -dlh_[k] * rcp_nr(lh[k])));
+                    rmaxd = fmax(rmaxd, fmax(fma(dtl_[k], rtl[k], 1.0), fma(dth_[k], rth[k], 1.0)));      // -dlam/lam = 1 + dt/t when sigma = 0
                 }
             }
             double dt1_[NOBST], dl1_[NOBST], dt2_[NOBST], dl2_[NOBST];
@@ -1196,11 +1196,11 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                         dt2_[j] = o.rd2 + ds;
                         dl2_[j] = -(l2[j] * t2[j] + l2[j] * dt2_[j]) * rt2[j];
                         pp2[j] = dl2_[j] * dt2_[j];
-                        rmax = fmax(rmax, -dt2_[j] * rt2[j]); rmaxd = fmax(rmaxd, -dl2_[j] * rcp_nr(l2[j]));
+                        rmax = fmax(rmax, -dt2_[j] * rt2[j]); rmaxd = fmax(rmaxd, fma(dt2_[j], rt2[j], 1.0));
                     } else dt1_[j] = o.rd1 + y;
                     dl1_[j] = -(l1[j] * t1[j] + l1[j] * dt1_[j]) * rt1[j];
                     pp1[j] = dl1_[j] * dt1_[j];
-                    rmax = fmax(rmax, -dt1_[j] * rt1[j]); rmaxd = fmax(rmaxd, -dl1_[j] * rcp_nr(l1[j]));
+                    rmax = fmax(rmax, -dt1_[j] * rt1[j]); rmaxd = fmax(rmaxd, fma(dt1_[j], rt1[j], 1.0));
                 }
             }
             rmax = seg_max<G>(rmax, lane); rmaxd = seg_max<G>(rmaxd, lane);
@@ -1274,7 +1274,6 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         }
         MPC_TICK(6);
         if (ROWPAR) {
-            __syncthreads();
             if (has_u) {        // homogeneous dynamics: c_t = B k
                 double *cc = RL.H + RowLds::HS * i + RowVec::ACL + 5;
                 cc[0 * RowVec::RS] = S.b00 * F.k0 + S.b01 * F.k1; cc[1 * RowVec::RS] = S.b10 * F.k0 + S.b11 * F.k1;

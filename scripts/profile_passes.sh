@@ -1,0 +1,20 @@
+#!/bin/bash
+# rocprofv3 passes behind profiles/<tag>_kernel_stats.csv and profiles/<tag>_pmc_summary.json (run on the GPU box from the repo root):
+#   scripts/profile_passes.sh <tag> [bench.py arguments]
+# One --kernel-trace --stats pass, then one PMC pass per counter group (FETCH_SIZE and WRITE_SIZE do not fit one pass; PMC
+# passes carry no tracing options).  The program after `--` is python3 itself.
+set -u
+TAG=${1:-r01_final}; shift || true
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+ARGS="--no-cpu-baseline --no-extra $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$ROOT/bench.py" $ARGS > "$OUT/stats.log" 2>&1
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" \
+           "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+    i=$((i + 1))
+    rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc$i" -o pmc -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc$i.log" 2>&1 || echo "pmc pass $i failed (see $OUT/pmc$i.log)"
+done
+python3 "$ROOT/scripts/summarize_profile.py" "$OUT" "$TAG"

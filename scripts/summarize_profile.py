@@ -1,0 +1,43 @@
+"""Condense the rocprofv3 output of scripts/profile_passes.sh into <tag>_kernel_stats.csv and <tag>_pmc_summary.json (written to
+gpurun_out/; copy them into profiles/).  Per-launch means over the launches of the solve kernel."""
+import csv, glob, json, os, sys
+out, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(out)
+stats = sorted(glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True))
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+summary = {"batch": batch, "command": "scripts/profile_passes.sh: rocprofv3 --kernel-trace --stats | --pmc <group> (one pass per group) -- python3 bench.py --no-cpu-baseline --no-extra",
+           "kernel": None, "kernel_stats": None, "counters": {}}
+if stats:
+    rows = list(csv.DictReader(open(stats[0])))
+    with open(os.path.join(root, f"{tag}_kernel_stats.csv"), "w") as f:
+        f.write(open(stats[0]).read())
+    k = max((r for r in rows if "rti_solve_kernel" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]), default=None)
+    if k:
+        summary["kernel"] = k["Name"]
+        summary["kernel_stats"] = {"calls": int(k["Calls"]), "avg_ns": float(k["AverageNs"]), "percentage": float(k["Percentage"])}
+for f in sorted(glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        if "rti_solve_kernel" not in r.get("Kernel_Name", ""):
+            continue
+        if summary["kernel"] and r["Kernel_Name"] != summary["kernel"]:
+            continue
+        a = acc.setdefault(r["Counter_Name"], [0.0, 0])
+        a[0] += float(r["Counter_Value"]); a[1] += 1
+    for name, (tot, n) in acc.items():
+        summary["counters"][name] = {"mean_per_launch": tot / n, "launches": n}
+c = summary["counters"]
+d = {}
+if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+    summary["hbm_traffic_bytes_per_launch"] = {
+        "fetch_raw_kb": c["FETCH_SIZE"]["mean_per_launch"], "write_raw_kb": c["WRITE_SIZE"]["mean_per_launch"],
+        "fetch_bytes_corrected_x2": 2 * 1024 * c["FETCH_SIZE"]["mean_per_launch"], "write_bytes": 1024 * c["WRITE_SIZE"]["mean_per_launch"],
+        "note": "FETCH_SIZE/WRITE_SIZE are in KB; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads 1/2 of a wide coalesced stream (x2 correction "
+                "shown), other access widths (ours: 8 B per lane) are uncalibrated; WRITE_SIZE is exact for streaming stores"}
+if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CYCLES" in c and "SQ_WAVE_CYCLES" in c:
+    d["valu_active_fraction_of_wave_cycles"] = c["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / c["SQ_WAVE_CYCLES"]["mean_per_launch"]
+if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c:
+    d["valu_instructions_per_wave"] = c["SQ_INSTS_VALU"]["mean_per_launch"] / c["SQ_WAVES"]["mean_per_launch"]
+summary["derived"] = d
+json.dump(summary, open(os.path.join(root, f"{tag}_pmc_summary.json"), "w"), indent=1)
+print(json.dumps({"kernel": summary["kernel"], "stats": summary["kernel_stats"], "derived": d, "counters": sorted(c)}, indent=1))
