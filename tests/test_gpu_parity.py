@@ -239,6 +239,8 @@ def test_matrix_core_factorisation_matches_vector_path(env):
         assert (out[1][0]["iters"] == out[0][0]["iters"]).mean() > 0.95
         # the matrix-core path keeps the cost-to-go in a full (not triangular) tile and symmetrises every 4th stage: it is
         # ~100x less accurate than the vector paths on ill-conditioned stages (one reason it is not the default)
+        d1 = np.abs(out[1][1] - out[0][1]).reshape(B, -1).max(1)[ok]; d2 = np.abs(out[1][4] - out[0][4]).reshape(B, -1).max(1)[ok]
+        assert np.median(d1) < 1e-9 and np.median(d2) < 1e-9
         assert np.sort(d1)[-2] < 1e-5 and np.sort(d2)[-2] < 1e-4 and np.quantile(d2, 0.9) < 1e-6   # a sensitive instance or two allowed (on one the oracle at 1e-8 and 1e-12 differ by 5e-5)
 
 
