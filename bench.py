@@ -258,7 +258,7 @@ def main():
             "fp64_valu": {"achieved": algorithmic_flops_per_solve(N, no, mean_iters) * batch / avg_kernel_s / 1e12,
                           "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                           "frac": algorithmic_flops_per_solve(N, no, mean_iters) * batch / avg_kernel_s / 1e12 / FP64_VALU_PEAK_TF,
-                          "note": "the path is bound by FP64 vector-instruction ISSUE (PMC: VALU active 78% of wave cycles, 4 cycles per wave-instruction, one lane of 64 active in the stage recursions), not by HBM (DESIGN.md section 5); SURVEY 8(d) flop model x measured mean IPM iterations"}}
+                          "note": "the path is bound by the ISSUE of a serial FP64 instruction stream (PMC: 33k VALU instructions per solve, VALU active 55% of wave cycles, 24% parked on LDS waits; the stage recursions keep 8 or fewer lanes of 64 busy), not by HBM or by the FP64 flop peak (DESIGN.md section 5); SURVEY 8(d) flop model x measured mean IPM iterations"}}
     out = {"metric": "MPC solves/sec (N=20, 3 obstacles)", "value": value, "unit": "solves/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
