@@ -278,3 +278,33 @@ def test_row_parallel_factorisation_matches_systolic_and_oracle(env, N, no, B, l
     assert ok.mean() > 0.9 and (o["status"] == out[1][0]["status"]).mean() > 0.98
     assert np.abs(out[1][1] - o["X"])[ok].max() < (1e-6 if N <= 20 else 5e-5)
     assert (o["iters"][ok] == out[1][0]["iters"][ok]).mean() > 0.95
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [2, 3, 4, 14, 15, 30, 31, 62])
+def test_horizon_extremes_and_packing_boundaries(env, N):
+    """shortest / longest horizons and the horizons either side of a lanes-per-instance switch (N + 2 <= G), default
+    (row-parallel) sweeps: the operand prefetch runs past both ends of the per-instance LDS region at small N, a tail
+    wavefront has surplus instance slots, and the batch is not a multiple of the instances per wavefront"""
+    mpc_gpu, orc = env
+    no, B = 3, 37
+    x0, goal, obst = random_batch(B, no, seed=300 + N)
+    cfg = orc.config(N, no, 0.1 * N)
+    P = oracle_P(orc, cfg, obst); Xg, Ug = oracle_guess(orc, cfg, x0)
+    o = orc.rti_solve_batch(cfg, x0, P, goal, Xg, Ug)
+    with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
+        assert s.lanes_per_instance(B) == (16 if N + 2 <= 16 else 32 if N + 2 <= 32 else 64)
+        s.reset_guess(x0); g = s.solve(x0, obst, goal); X, U = s.get_traj(B)
+        s.shift(B); g2 = s.solve(x0, obst, goal)
+    assert (g["status"] == o["status"]).all()
+    ok = o["status"] == 0
+    assert ok.mean() > 0.9
+    tol = 1e-6 if N <= 31 else 5e-5
+    assert np.abs(X - o["X"])[ok].max() < tol and np.abs(U - o["U"])[ok].max() < tol * 8
+    assert (g["iters"][ok] == o["iters"][ok]).mean() > 0.95
+    # second step from the shifted iterate, against the oracle fed with the GPU's own iterate
+    Xs = np.stack([orc.shift(cfg, X[b], U[b])[0] for b in range(B)]); Us = np.stack([orc.shift(cfg, X[b], U[b])[1] for b in range(B)])
+    o2 = orc.rti_solve_batch(cfg, x0, P, goal, Xs, Us)
+    ok2 = (o2["status"] == 0) & (g2["status"] == 0)
+    assert (g2["status"] == o2["status"]).mean() > 0.97 and ok2.mean() > 0.85
+    assert np.abs(g2["u0"] - o2["u0"])[ok2].max() < tol * 8
