@@ -38,6 +38,42 @@ __global__ void obstacle_step_kernel(World w, int count, double dt, double *__re
     o[0] = x; o[1] = y; o[2] = vx; o[3] = vy;
 }
 
+// generate_random_moving_obstacles (obstacle_generator.py:8-28) for `count` seeds: thread s reproduces what the reference draws
+// after np.random.seed(seed0 + s) -- numpy's legacy MT19937 (init_genrand seeding, standard tempering), random_sample() =
+// ((a >> 5) * 2^26 + (b >> 6)) / 2^53 from two consecutive outputs, uniform(lo, hi) = lo + (hi - lo) * u (no contraction), drawn in
+// the reference's order: x block, y block (RANDOM only), vx block, vy block.  CENTER / EDGE place every obstacle at 0 / `edge`.
+// At most 8 * n_obst <= 80 outputs are needed, all from the first state regeneration, which touches state words < 80 + 398.
+enum { kScenarioRandom = 0, kScenarioCenter = 1, kScenarioEdge = 2 };
+__global__ void scenario_kernel(int count, int n_obst, int scenario, unsigned seed0, double x_lo, double x_hi, double y_lo, double y_hi,
+                                double v_max, double edge, double *__restrict__ out)
+{
+#pragma clang fp contract(off)
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= count) return;
+    constexpr int kWords = 80 + 398;
+    unsigned mt[kWords];
+    mt[0] = seed0 + (unsigned)s;
+    for (int k = 1; k < kWords; k++) mt[k] = 1812433253u * (mt[k - 1] ^ (mt[k - 1] >> 30)) + (unsigned)k;
+    int pos = 0;
+    auto next32 = [&]() {
+        const unsigned y0 = (mt[pos] & 0x80000000u) | (mt[pos + 1] & 0x7fffffffu);
+        unsigned y = mt[pos + 397] ^ (y0 >> 1) ^ ((y0 & 1u) ? 0x9908b0dfu : 0u);
+        pos++;
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        return y;
+    };
+    auto uniform = [&](double lo, double hi) {
+        const unsigned a = next32() >> 5, b = next32() >> 6;
+        const double u = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+        return lo + (hi - lo) * u;
+    };
+    double *o = out + (size_t)s * n_obst * 4;
+    for (int j = 0; j < n_obst; j++) o[j * 4 + 0] = scenario == kScenarioRandom ? uniform(x_lo, x_hi) : (scenario == kScenarioEdge ? edge : 0.0);
+    for (int j = 0; j < n_obst; j++) o[j * 4 + 1] = scenario == kScenarioRandom ? uniform(y_lo, y_hi) : (scenario == kScenarioEdge ? edge : 0.0);
+    for (int j = 0; j < n_obst; j++) o[j * 4 + 2] = uniform(-v_max, v_max);
+    for (int j = 0; j < n_obst; j++) o[j * 4 + 3] = uniform(-v_max, v_max);
+}
+
 // Warm-start shift, robot_ocp_problem.py:253-258: X[j] <- X[j+1] (j < N), U[j] <- U[j+1] (j < N-1), U[N-1] <- 0.
 // One wavefront per instance; every lane reads its successor stage before anyone writes.
 __global__ __launch_bounds__(64) void shift_kernel(int batch, int N, double *__restrict__ X, double *__restrict__ U)

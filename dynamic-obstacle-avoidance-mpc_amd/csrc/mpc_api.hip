@@ -329,6 +329,20 @@ int mpc_obstacle_step_dev(mpc_handle *h, int count, double *d_obst, const double
     return MPC_OK;
 }
 
+int mpc_generate_scenarios_dev(mpc_handle *h, int count, int scenario, unsigned seed0, const double *box, double *d_obst, void *stream)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    if (count < 0 || count > h->max_batch) return fail(MPC_ERR_ARG, "count outside [0, max_batch]");
+    if (scenario < 0 || scenario > 2) return fail(MPC_ERR_ARG, "scenario must be 0 (RANDOM), 1 (CENTER) or 2 (EDGE)");
+    if (count == 0) return MPC_OK;
+    if (!box || !d_obst) return fail(MPC_ERR_ARG, "null pointer");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(mpc::scenario_kernel, dim3((count + 63) / 64), dim3(64), 0, pick(h, stream), count, h->cfg.n_obst, scenario, seed0,
+                       box[0], box[1], box[2], box[3], box[4], box[5], d_obst);
+    HIPCHK(hipGetLastError());
+    return MPC_OK;
+}
+
 int mpc_linearize_dev(mpc_handle *h, int batch, const double *d_x0, const double *d_P, const double *d_goal,
                       const double *d_X, const double *d_U, double *d_A, double *d_B, double *d_b, double *d_q,
                       double *d_hval, double *d_dh, void *stream)
@@ -452,6 +466,17 @@ int mpc_predict(mpc_handle *h, int batch, const double *obst, double *P)
     HIPCHK(hipMemcpyAsync(h->d_obst, obst, (size_t)batch * no * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     rc = mpc_predict_dev(h, batch, h->d_obst, h->d_P, nullptr); if (rc) return rc;
     HIPCHK(hipMemcpyAsync(P, h->d_P, (size_t)batch * (N + 1) * no * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPC_OK;
+}
+
+int mpc_generate_scenarios(mpc_handle *h, int count, int scenario, unsigned seed0, const double *box, double *obst)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    if (count == 0) return MPC_OK;
+    if (!obst) return fail(MPC_ERR_ARG, "null pointer");
+    int rc = mpc_generate_scenarios_dev(h, count, scenario, seed0, box, h->d_obst, nullptr); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(obst, h->d_obst, (size_t)count * h->cfg.n_obst * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return MPC_OK;
 }

@@ -17,10 +17,15 @@ from .solver import BatchedMpc
 
 
 def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, init_guess_when_error=True,
-                 bug_compat_alias=True, seed=0, device=0, solver=None, **cfg):
-    """x0 (B,5), goal (B,2), obst (B,n_obst,4).  Returns dict(table (B,6), x_last (B,5), steps_run, solves)."""
+                 bug_compat_alias=True, seed=0, device=0, solver=None, n_obst=5, first_seed=0, **cfg):
+    """x0 (B,5), goal (B,2), obst (B,n_obst,4) -- or a scenario name ("RANDOM" | "CENTER" | "EDGE"): instance s then starts
+    from the reference generator's draw for np.random.seed(first_seed + s), produced on the device (experiments.py:26-29).
+    Returns dict(table (B,6), x_last (B,5), steps_run, solves)."""
     import torch
     x0 = np.ascontiguousarray(x0, dtype=np.float64); B = x0.shape[0]
+    if isinstance(obst, str):
+        with BatchedMpc(N, n_obst, Tf, max_batch=B, device=device) as g:
+            obst = g.generate_scenarios(obst, B, seed0=first_seed)
     obst = np.ascontiguousarray(obst, dtype=np.float64); n_obst = obst.shape[1]
     goal = np.ascontiguousarray(np.broadcast_to(goal, (B, 2)), dtype=np.float64)
     dev = torch.device("cuda", device)

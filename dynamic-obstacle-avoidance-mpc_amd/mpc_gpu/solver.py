@@ -111,6 +111,28 @@ class BatchedMpc:
         _lib.check(_lib.lib().mpc_predict(self._h, B, _ptr(obst), _ptr(P)))
         return P
 
+    SCENARIOS = {"RANDOM": 0, "CENTER": 1, "EDGE": 2}
+
+    @staticmethod
+    def _scenario_box():
+        from . import world as w
+        return np.array([w.X_MIN_OBST, w.X_MAX_OBST, w.Y_MIN_OBST, w.Y_MAX_OBST, w.V_MAX_OBST, 7.0], dtype=np.float64)
+
+    def generate_scenarios(self, scenario, count, seed0=0):
+        """generate_random_moving_obstacles for np.random.seed(seed0 + s), s < count (obstacle_generator.py:8-28) -> (count, n_obst, 4)"""
+        obst = np.empty((count, self.n_obst, 4))
+        box = self._scenario_box()
+        _lib.check(_lib.lib().mpc_generate_scenarios(self._h, count, self.SCENARIOS[scenario], seed0, _ptr(box), _ptr(obst)))
+        return obst
+
+    def generate_scenarios_dev(self, scenario, count, obst, seed0=0, stream=None):
+        box = self._scenario_box()
+        _lib.check(_lib.lib().mpc_generate_scenarios_dev(self._h, count, self.SCENARIOS[scenario], seed0, _ptr(box), _ptr(obst), _ptr(stream)))
+
+    def terminal_state(self, batch):
+        """x_N of the current iterate (the reference reads it at robot_ocp_problem.py:232; hook for a sub-goal policy)"""
+        return self.get_traj(batch)[0][:, -1].copy()
+
     # ------------------------------------------------------------------ device-pointer API (torch tensors or raw ints)
     def iterate_ptrs(self):
         dX, dU, st = C.c_void_p(), C.c_void_p(), C.c_void_p()

@@ -140,6 +140,12 @@ int mpc_plant_step_dev(mpc_handle *h, int batch, const double *d_x, const double
 /* Obstacle.step() ground-truth motion (visualization.py:20-33); d_noise[B*n_obst][2] standard normals or NULL */
 int mpc_obstacle_step_dev(mpc_handle *h, int count, double *d_obst, const double *d_noise,
                           double randomness, double vmax, void *stream);
+/* generate_random_moving_obstacles (src/utils/obstacle_generator.py:8-28) for the seeds seed0 .. seed0+count-1: instance s gets
+ * bit for bit what the reference draws after np.random.seed(seed0 + s) (numpy legacy MT19937 stream, reference draw order).
+ * scenario: 0 RANDOM, 1 CENTER, 2 EDGE (:10-18).  box = {X_MIN_OBST, X_MAX_OBST, Y_MIN_OBST, Y_MAX_OBST, V_MAX_OBST, edge (7)}
+ * (src/models/world_specification.py:25-40).  obst[count][n_obst][4] = (x, y, vx, vy). */
+int mpc_generate_scenarios_dev(mpc_handle *h, int count, int scenario, unsigned seed0, const double *box, double *d_obst, void *stream);
+int mpc_generate_scenarios(mpc_handle *h, int count, int scenario, unsigned seed0, const double *box, double *obst);
 /* Linearisation products of the current iterate, for parity tests of the linearise stage:
  * A[B][N][5][5], Bm[B][N][5][2], b[B][N][5], q[B][N+1][7] (order u,x), hval[B][N+1][n_obst], dh[B][N+1][n_obst][2] */
 int mpc_linearize_dev(mpc_handle *h, int batch, const double *d_x0, const double *d_P, const double *d_goal,

@@ -1,6 +1,6 @@
 """Reproduce the protocol of the reference's src/simulation/experiments.py on the GPU episode harness:
 2 scenarios x 100 seeds, start [-7,-7,pi/4,0,0], goal [7,7], N_OBST = 5, noisy obstacles, init_guess_when_error, max 400 steps.
-Scenario draws are the reference generator's own (tests/golden/, np.random.seed(i)); the obstacle noise stream is the GPU's
+Scenario draws are the reference generator's own (np.random.seed(i), reproduced bit for bit by the device generator); the obstacle noise stream is the GPU's
 (torch), so per-seed rows are not comparable, only the statistics (the tables are chaotic anyway)."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +12,7 @@ gold = np.load(os.path.join(ROOT, "tests", "golden", "reference_vectors.npz"))
 ref = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_tables.json")))["tables"]
 out = {}
 for scen, tf, n, qp in (("RANDOM", 2.0, 20, 100), ("EDGE", 2.0, 20, 100), ("RANDOM", 1.0, 10, 50), ("EDGE", 1.0, 10, 50)):
-    obst = gold[f"gen_{scen}_5"]                       # (100, 5, 4)
+    obst = scen                                        # drawn on the device: np.random.seed(i) streams, i < 100 (== gold[f"gen_{scen}_5"])
     x0 = np.tile([-7.0, -7.0, np.pi / 4, 0, 0], (100, 1)); goal = np.tile([7.0, 7.0], (100, 1))
     r = mpc_gpu.run_episodes(x0, goal, obst, N=n, Tf=tf, max_iter=400, random_move=True, init_guess_when_error=True, seed=0, qp_iter_max=qp)
     tb = r["table"]

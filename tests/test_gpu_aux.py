@@ -168,3 +168,29 @@ def test_episode_harness_free_space_and_table_format(env, tmp_path):
                                           "N_SOLV": 20, "N_OBST": 3, "QP_ITER": 50}, str(tmp_path))
     back = np.loadtxt(tmp_path / f"{stamp}_experiment_data.csv", delimiter=";")
     assert np.array_equal(back, tb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [3, 5, 10])
+def test_scenario_generator_kernel_bit_exact_vs_reference_draws(env, n):
+    """device scenario generator == the reference's generate_random_moving_obstacles after np.random.seed(i), i < 100, all three
+    scenarios (tests/golden/reference_vectors.npz, captured by importing the reference), bit for bit; and an offset seed range"""
+    mpc_gpu, _ = env
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"))
+    with mpc_gpu.BatchedMpc(20, n, 2.0, max_batch=128) as s:
+        for scen in ("RANDOM", "EDGE", "CENTER"):
+            want = gold[f"gen_{scen}_{n}"]
+            got = s.generate_scenarios(scen, 100)
+            assert got.shape == want.shape and (got == want).all()
+            assert (s.generate_scenarios(scen, 10, seed0=37) == want[37:47]).all()
+
+
+@pytest.mark.gpu
+def test_episode_harness_accepts_scenario_names(env):
+    """run_episodes("EDGE") == run_episodes(<the reference's EDGE draws>) : same table (same noise stream, same scenarios)"""
+    mpc_gpu, _ = env
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"))
+    x0 = np.tile([-7.0, -7.0, np.pi / 4, 0, 0], (16, 1)); goal = np.tile([7.0, 7.0], (16, 1))
+    a = mpc_gpu.run_episodes(x0, goal, "EDGE", N=10, Tf=1.0, max_iter=60, n_obst=5, seed=3)
+    b = mpc_gpu.run_episodes(x0, goal, gold["gen_EDGE_5"][:16], N=10, Tf=1.0, max_iter=60, seed=3)
+    assert (a["table"] == b["table"]).all()
