@@ -17,9 +17,11 @@ from .solver import BatchedMpc
 
 
 def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, init_guess_when_error=True,
-                 bug_compat_alias=True, seed=0, device=0, solver=None, n_obst=5, first_seed=0, **cfg):
+                 bug_compat_alias=True, seed=0, device=0, solver=None, n_obst=5, first_seed=0, record=False, **cfg):
     """x0 (B,5), goal (B,2), obst (B,n_obst,4) -- or a scenario name ("RANDOM" | "CENTER" | "EDGE"): instance s then starts
     from the reference generator's draw for np.random.seed(first_seed + s), produced on the device (experiments.py:26-29).
+    record=True also returns simX (steps+1,B,5), obst_traj (steps+1,B,n_obst,4) and pred (steps,B,N+1,5): what the reference keeps
+    for its visualisation (robot_ocp_problem.py:232-240,270-276).
     Returns dict(table (B,6), x_last (B,5), steps_run, solves)."""
     import torch
     x0 = np.ascontiguousarray(x0, dtype=np.float64); B = x0.shape[0]
@@ -47,20 +49,26 @@ def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, i
             fl |= _lib.STEP_RESET_ON_FAIL | (_lib.STEP_ALIAS_BUG if bug_compat_alias else 0)
         gen = torch.Generator(device=dev); gen.manual_seed(seed)
         k = 0
+        rec_x, rec_o, rec_p = [dx0.clone()], [dobst.clone()], []
         while k < max_iter:
             noise = torch.randn(B, n_obst, 2, dtype=torch.float64, device=dev, generator=gen) if random_move else None
             m.closed_loop_step_dev(B, dx0, dobst, dgoal, X, U, None, None, status, iters, noise, flags=fl,
                                    min_margin=margin, ep_flags=flags, ep_steps=steps, stream=s)
             k += 1
+            if record:      # X holds the shifted prediction: stage j of the solve is X[j - 1], stage N is kept (:253-258)
+                rec_x.append(dx0.clone()); rec_o.append(dobst.clone()); rec_p.append(X.clone())
             if k % 25 == 0 and bool((flags & 1).all().item()):     # every instance reached its goal
                 break
         stream.synchronize()
         fl_h = flags.cpu().numpy(); xl = dx0.cpu().numpy()
         table = np.column_stack([(fl_h & 4) != 0, (fl_h & 1) != 0, margin.cpu().numpy(),
                                  np.linalg.norm(xl[:, :2] - goal, axis=1), steps.cpu().numpy(), (fl_h & 2) != 0]).astype(np.float64)
+        extra = {}
+        if record:
+            extra = dict(simX=torch.stack(rec_x).cpu().numpy(), obst_traj=torch.stack(rec_o).cpu().numpy(), pred=torch.stack(rec_p).cpu().numpy())
     if solver is None:
         m.close()
-    return dict(table=table, x_last=xl, steps_run=k, solves=int(steps.sum().item()) + int((fl_h & 1).sum()))
+    return dict(table=table, x_last=xl, steps_run=k, solves=int(steps.sum().item()) + int((fl_h & 1).sum()), **extra)
 
 
 def write_experiment(table, spec, out_dir, stamp=None):

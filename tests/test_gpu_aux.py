@@ -194,3 +194,19 @@ def test_episode_harness_accepts_scenario_names(env):
     a = mpc_gpu.run_episodes(x0, goal, "EDGE", N=10, Tf=1.0, max_iter=60, n_obst=5, seed=3)
     b = mpc_gpu.run_episodes(x0, goal, gold["gen_EDGE_5"][:16], N=10, Tf=1.0, max_iter=60, seed=3)
     assert (a["table"] == b["table"]).all()
+
+
+@pytest.mark.gpu
+def test_episode_recording_for_visualisation(env):
+    """record=True returns the closed-loop state, obstacle and prediction histories the reference keeps for its plots"""
+    mpc_gpu, _ = env
+    x0 = np.tile([-7.0, -7.0, np.pi / 4, 0, 0], (4, 1)); goal = np.tile([7.0, 7.0], (4, 1))
+    r = mpc_gpu.run_episodes(x0, goal, "RANDOM", N=10, Tf=1.0, max_iter=30, n_obst=3, random_move=False, record=True)
+    k = r["steps_run"]
+    assert r["simX"].shape == (k + 1, 4, 5) and r["obst_traj"].shape == (k + 1, 4, 3, 4) and r["pred"].shape == (k, 4, 11, 5)
+    assert (r["simX"][0, :, :3] == x0[:, :3]).all() and (r["simX"][-1] == r["x_last"]).all()
+    moved = np.linalg.norm(r["simX"][-1, :, :2] - r["simX"][0, :, :2], axis=1)
+    assert (moved > 1.0).all()
+    # noise-free obstacles move with constant velocity between wall contacts
+    d = r["obst_traj"][1, :, :, :2] - r["obst_traj"][0, :, :, :2]
+    assert np.abs(d - 0.1 * r["obst_traj"][0, :, :, 2:]).max() < 1e-12
