@@ -17,4 +17,4 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_
     i=$((i + 1))
     rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc$i" -o pmc -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc$i.log" 2>&1 || echo "pmc pass $i failed (see $OUT/pmc$i.log)"
 done
-python3 "$ROOT/scripts/summarize_profile.py" "$OUT" "$TAG"
+python3 "$ROOT/scripts/summarize_profile.py" "$OUT" "$TAG" "${PROFILE_BATCH:-1024}"
