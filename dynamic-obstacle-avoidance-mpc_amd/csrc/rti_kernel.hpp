@@ -453,11 +453,17 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const RowLds L, b
             : "v"(Pc[0]), "v"(Pc[1]), "v"(Pc[2]), "v"(Pc[3]), "v"(Pc[4]), "v"(Pc[5]), "v"(Wc[0]), "v"(Wc[1]), "v"(Wc[2]), "v"(Wc[3]), "v"(Wc[4]));
     };
     // second half: M~ (accumulated onto the H~aug column in M), L D L' of Muu, column j of K~, P~+ in M[0..5]
-    auto stepM = [&](int t, const double Wc[5], double M[8], const double T[6]) {
+    auto stepM = [&](int t, const double Wc[5], const double Hc[8], const double T[6], double M[8]) {
         // M~ = H~aug + W~' T over the structural non-zeros of W~ (A = I + E, B: 24 of 40 products), rows 6, 7 (the input block) first;
         // then Muu = M~[6..7][6..7] -> L D L' (backward stable, see systolic_factor) and column j of K~ = -Muu^-1 M~[u, :],
         // computed in every lane and hand-interleaved with the remaining rows of M~ so that the serial reciprocal / Newton
         // chain (~15 dependent instructions) hides behind independent FMAs
+        // the accumulators start as copies of the H~aug column made HERE, after the operands have arrived: accumulating in place
+        // into registers that a ds_read2_b64 delivers makes the compiler copy them out right behind the request (a stall)
+        asm volatile("v_mov_b64_e32 %0, %8\nv_mov_b64_e32 %1, %9\nv_mov_b64_e32 %2, %10\nv_mov_b64_e32 %3, %11\n"
+                     "v_mov_b64_e32 %4, %12\nv_mov_b64_e32 %5, %13\nv_mov_b64_e32 %6, %14\nv_mov_b64_e32 %7, %15\n"
+                     : "=&v"(M[0]), "=&v"(M[1]), "=&v"(M[2]), "=&v"(M[3]), "=&v"(M[4]), "=&v"(M[5]), "=&v"(M[6]), "=&v"(M[7])
+                     : "v"(Hc[0]), "v"(Hc[1]), "v"(Hc[2]), "v"(Hc[3]), "v"(Hc[4]), "v"(Hc[5]), "v"(Hc[6]), "v"(Hc[7]));
         double K0, K1, i00, l, i11, m66, m67, m77, e_, r_;
         asm volatile(
             "s_nop 1\n"
@@ -528,19 +534,19 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const RowLds L, b
             : "+v"(M[0]), "+v"(M[1]), "+v"(M[2]), "+v"(M[3]), "+v"(M[4]), "+v"(M[5])
             : "v"(M[6]), "v"(M[7]), "v"(K0), "v"(K1));
     };
-    // Two register sets alternate: while stage t runs on (Wa, Ma) with P~ taken from Mb, the operands of stage t-1 are
-    // requested into (Wb, Mb) as soon as the T block has consumed Mb -- a stage is ~600 cycles of arithmetic, far more than
-    // the LDS latency of a lone wavefront -- and the stage's result P~+ stays in Ma for the next stage.  No register copies.
-    double Wa[5], Ma[8], Wb[5], Mb[8], T[6];
+    // Two operand sets (W, H) and two result sets (P) alternate: while stage t runs on (Wa, Ha) with P~ taken from Pb and its
+    // result going to Pa, the operands of stage t-1 are requested into (Wb, Hb) right after the T block -- a stage is ~600
+    // cycles of arithmetic, far more than the LDS latency of a lone wavefront.  No register copies between stages.
+    double Wa[5], Ha[8], Wb[5], Hb[8], Pa[8], Pb[8], T[6];
 #pragma unroll
-    for (int r = 0; r < 6; r++) Mb[r] = hp[HS * N + r * 8];           // P~_N = H~aug_N[0..5][0..5]
-    fetch(N - 1, Wa, Ma);
+    for (int r = 0; r < 6; r++) Pb[r] = hp[HS * N + r * 8];           // P~_N = H~aug_N[0..5][0..5]
+    fetch(N - 1, Wa, Ha);
     int t = N - 1;
     for (; t >= 1; t -= 2) {
-        stepT(Wa, Mb, T); fetch(t - 1, Wb, Mb); stepM(t, Wa, Ma, T);
-        stepT(Wb, Ma, T); fetch(t - 2, Wa, Ma); stepM(t - 1, Wb, Mb, T);      // t - 2 = -1 reads the (dead) block in front
+        stepT(Wa, Pb, T); fetch(t - 1, Wb, Hb); stepM(t, Wa, Ha, T, Pa);
+        stepT(Wb, Pa, T); fetch(t - 2, Wa, Ha); stepM(t - 1, Wb, Hb, T, Pb);      // t - 2 = -1 reads the (dead) block in front
     }
-    if (t == 0) { stepT(Wa, Mb, T); stepM(0, Wa, Ma, T); }
+    if (t == 0) { stepT(Wa, Pb, T); stepM(0, Wa, Ha, T, Pa); }
 }
 
 // ROW-PARALLEL VECTOR RECURSIONS.  With the closed-loop matrix Acl_t = A_t + B_t K_t (5 x 5, computed by the lane that owns
