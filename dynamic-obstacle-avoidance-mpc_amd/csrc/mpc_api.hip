@@ -118,7 +118,11 @@ int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
     const bool rowpar = !use_mfma && h->row_parallel;
     const size_t lds = ((p.obst ? (size_t)(64 / G) * (p.N + 1) * h->cfg.n_obst * 2 : 0) + (use_mfma ? (size_t)mpc::MfmaLds::doubles(p.N) : 0) +
                         (rowpar ? (size_t)mpc::RowLds::total(p.N, 64 / G) : 0)) * sizeof(double);
-#define MPC_LAUNCH(NO, GG, MF) hipLaunchKernelGGL((mpc::rti_solve_kernel<NO, GG, MF>), grid, block, lds, s, p)
+    // more than 64 KB of dynamic LDS (long horizons with 10 obstacles) has to be granted per kernel function
+#define MPC_LAUNCH(NO, GG, MF) do { \
+        if (lds > 65536) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&mpc::rti_solve_kernel<NO, GG, MF>), \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((mpc::rti_solve_kernel<NO, GG, MF>), grid, block, lds, s, p); } while (0)
 #define MPC_LAUNCH_G(NO) do { if (G == 16) { if (rowpar) MPC_LAUNCH(NO, 16, 2); else MPC_LAUNCH(NO, 16, 0); } \
                               else if (G == 32) { if (rowpar) MPC_LAUNCH(NO, 32, 2); else MPC_LAUNCH(NO, 32, 0); } \
                               else if (use_mfma) MPC_LAUNCH(NO, 64, 1); else if (rowpar) MPC_LAUNCH(NO, 64, 2); else MPC_LAUNCH(NO, 64, 0); } while (0)

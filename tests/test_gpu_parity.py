@@ -308,3 +308,20 @@ def test_horizon_extremes_and_packing_boundaries(env, N):
     ok2 = (o2["status"] == 0) & (g2["status"] == 0)
     assert (g2["status"] == o2["status"]).mean() > 0.97 and ok2.mean() > 0.85
     assert np.abs(g2["u0"] - o2["u0"])[ok2].max() < tol * 8
+
+
+@pytest.mark.gpu
+def test_longest_horizon_with_ten_obstacles_uses_more_than_64k_lds(env):
+    """N = 62 with 10 obstacles and the on-device look-ahead needs ~66 KB of dynamic LDS per workgroup (row-parallel operands
+    + look-ahead staging): the launch must be granted it, and the result must still match the oracle"""
+    mpc_gpu, orc = env
+    N, no, B = 62, 10, 6
+    x0, goal, obst = random_batch(B, no, seed=977)
+    cfg = orc.config(N, no, 0.1 * N)
+    P = oracle_P(orc, cfg, obst); Xg, Ug = oracle_guess(orc, cfg, x0)
+    o = orc.rti_solve_batch(cfg, x0, P, goal, Xg, Ug)
+    with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
+        s.reset_guess(x0); g = s.solve(x0, obst, goal); X, U = s.get_traj(B)     # obstacle states in: look-ahead staged in LDS
+    assert (g["status"] == o["status"]).all()
+    ok = o["status"] == 0
+    assert ok.sum() >= B - 2 and np.abs(X - o["X"])[ok].max() < 5e-5
