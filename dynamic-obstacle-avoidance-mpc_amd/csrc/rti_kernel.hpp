@@ -7,13 +7,15 @@
 // Mapping: G LANES PER INSTANCE (G = 64, 32 or 16 with N + 1 < G; one workgroup = one wavefront = 64/G instances that share
 // one instruction stream).
 //   * lane i owns horizon stage i (N+1 <= 64): its linearisation, its inequality rows (multiplier lam, slack t for the
-//     4 input-box, 8 state-box and 2*NOBST soft-obstacle rows live in that lane's REGISTERS for the whole solve);
-//   * the per-stage blocks that the Riccati recursion consumes/produces (A, B entries, barrier-modified Hessian and
-//     gradient, gains, LDL' factors, Newton step) also live in the owning lane's registers: no LDS, never HBM;
-//   * wavefront reductions (max step ratio, complementarity sum / max) are shuffle butterflies;
-//   * the stage recursions (backward Riccati, forward rollout) are sequential in the stage index and run SYSTOLICALLY:
-//     the recursion state (P, p, costate / dx) hops from lane to lane with one-lane DPP wave shifts, in step t only lane t
-//     computes, hand-expanded for the sparsity of A_i = I + E_i (6 non-trivial entries) and B_i (4 non-trivial entries).
+//     4 input-box, 8 state-box and 2*NOBST soft-obstacle rows live in that lane's REGISTERS for the whole solve); everything
+//     "per row" is lane-parallel over the stages;
+//   * wavefront reductions (max step ratio, complementarity sum / max) are DPP butterflies;
+//   * the stage recursions (backward Riccati, adjoint sweep, forward rollouts) are sequential in the stage index.  Two
+//     implementations, selected by the template parameter FACT:
+//       - ROW-PARALLEL (default): the algebra of ONE stage is spread over the 8 lanes of a 16-lane DPP row and runs as chains of
+//         v_fmac_f64_dpp with row_newbcast operands; the stage operands travel through LDS (rowpar_factor, rowpar_vector);
+//       - SYSTOLIC: the recursion state hops from lane to lane with one-lane DPP wave shifts and every stage is computed by the
+//         lane that owns it, hand-expanded for the sparsity of A_i = I + E_i (6 non-trivial entries) and B_i (4); no LDS.
 // HBM traffic is therefore the algorithmic minimum: read x0, goal, P, X, U once, write X, U, u0, cost, status once.
 //
 // Interior point method: Mehrotra predictor-corrector (separate primal / dual step lengths) in residual ("delta") form.  The costates the stationarity
@@ -255,7 +257,7 @@ struct StageFac {
 // backward; the state step dx going forward) travels from lane to lane by a one-lane DPP wave shift per stage: the value lane t
 // computes in step t is the one lane t-1 (t+1) consumes in the next step.  Whatever the other lanes (idle lanes, the
 // neighbouring instance) push into the chain arrives at a lane only AFTER that lane's own step, so it is never consumed.
-// No LDS, no barriers, no global traffic inside the interior-point loop.
+// No LDS, no barriers, no global traffic inside the interior-point loop (this variant).
 //
 // Backward Riccati factorisation + predictor right-hand side.
 //   q_t = gxs + A'(q+ + P+ r_b) + K'(lu + B'(q+ + P+ r_b)) is the cost-to-go gradient INCLUDING the costate of the
@@ -765,7 +767,7 @@ __device__ __forceinline__ void systolic_rollout(int stage, int N, const StageLi
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// The solve kernel.  grid = batch workgroups of 64 threads (one wavefront per instance); no LDS.
+// The solve kernel.  grid = ceil(batch / (64 / G)) workgroups of one wavefront; dynamic LDS: row-parallel operands + look-ahead staging.
 // ------------------------------------------------------------------------------------------------------------------
 // FACT selects the Riccati factorisation sweep: 0 one-lane systolic, 1 matrix cores (G = 64 only), 2 row-parallel DPP.
 template <int NOBST, int G, int FACT>

@@ -169,15 +169,17 @@ int mpc_debug_trace(mpc_handle *h, int enable, int batch, double *host_out);
 /* lanes per instance (64, 32, 16 or 8) the dispatcher picked for `batch`; 0 = automatic (default) */
 int mpc_set_lanes_per_instance(mpc_handle *h, int lanes);
 int mpc_get_lanes_per_instance(mpc_handle *h, int batch);
-/* 0 (default): vector-ALU systolic Riccati factorisation everywhere.  1: for batches <= 1024 (one instance per
- * wavefront) the factorisation runs on the matrix cores (v_mfma_f64_16x16x4, homogeneous 8x8 stage blocks).  Measured on
- * MI355X the two are equally fast (FP64 MFMA rate = FP64 vector rate, 116-cycle dependent MFMA links) and the vector
- * path is more accurate on ill-conditioned stages, hence the default; see DESIGN.md section 4. */
+/* 1: for batches <= 1024 (one instance per wavefront) the Riccati factorisation runs on the matrix cores (v_mfma_f64_16x16x4,
+ * homogeneous 8x8 stage blocks).  0 (default).  Measured on MI355X it is slower than both vector-ALU variants (FP64 MFMA rate =
+ * FP64 vector rate, 116-cycle dependent MFMA links, 75 % tile padding) and less accurate on ill-conditioned stages; it is kept
+ * as evidence, see DESIGN.md section 4.  No reference counterpart (tuning / test hook). */
 int mpc_set_matrix_cores(mpc_handle *h, int on);
 /* Riccati factorisation sweep of the interior point (same arithmetic specification, different lane mapping).
- * 1: row-parallel -- the 8 columns of a stage's homogeneous blocks sit in 8 lanes of a 16-lane DPP row and the
- * products run as v_fmac_f64_dpp row_newbcast chains (~130 instead of ~330 wave instructions per stage).
- * 0: one-lane systolic sweep.  No reference counterpart (tuning / test hook). */
+ * 1 (default): row-parallel -- the 8 columns of a stage's homogeneous blocks sit in 8 lanes of a 16-lane DPP row and the
+ * products run as v_fmac_f64_dpp row_newbcast chains (~135 instead of ~330 wave instructions per stage); the forward and
+ * adjoint vector recursions run the same way on the closed-loop matrix.
+ * 0: one-lane systolic sweeps (no LDS), the independent implementation the default is tested against.
+ * No reference counterpart (tuning / test hook). */
 int mpc_set_row_parallel(mpc_handle *h, int on);
 
 #ifdef __cplusplus
