@@ -131,7 +131,7 @@ def cpu_baseline(N, n_obst, x0, goal, obst, warm_steps, target_s=12.0):
     from oracle import oracle as orc
     cfg = orc.config(N, n_obst, 0.1 * N, qp_tol=1e-8)
     nthreads = os.cpu_count() or 1
-    S = min(len(x0), max(64, 4 * nthreads))
+    S = min(len(x0), max(64, 16 * nthreads))
     x0, goal, obst = x0[:S].copy(), goal[:S].copy(), obst[:S].copy()
     X = np.zeros((S, N + 1, 5)); U = np.zeros((S, N, 2))
     for b in range(S):

@@ -777,7 +777,7 @@ void orc_rti_solve_batch(const orc_config *c, int batch, const double *x0, const
     size_t sP = (size_t)(N + 1) * no * 2, sX = (size_t)(N + 1) * 5, sU = (size_t)N * 2;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
-#pragma omp parallel for schedule(dynamic, 8)
+#pragma omp parallel for schedule(dynamic, 1)
 #endif
     for (int b = 0; b < batch; b++) {
         int it = 0;
