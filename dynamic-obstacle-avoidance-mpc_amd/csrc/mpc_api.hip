@@ -3,6 +3,7 @@
 #include "../../include/mpc_gpu.h"
 #include "aux_kernels.hpp"
 #include "rti_kernel.hpp"
+#include "rti_split_kernel.hpp"
 
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -40,6 +41,8 @@ struct mpc_handle {
     int lanes_override;
     int use_mfma;                     // matrix-core Riccati factorisation when one instance per wavefront is chosen
     int row_parallel;                 // row-parallel (64-bit DPP) Riccati factorisation instead of the one-lane systolic sweep
+    int split_override;               // lanes per horizon stage: 0 automatic, 1 one lane per stage, 2 / 3 split kernel (mpc_set_lanes_per_stage)
+    int simd_count;                   // SIMDs of the device (4 per compute unit)
     int profiling;
     double *d_trace;                  // optional debug trace buffer (mpc_debug_trace)
     int32_t *d_iters_acc, *d_status_acc;   // optional accumulators (mpc_set_accumulators)
@@ -104,6 +107,29 @@ int pick_lanes(mpc_handle *h, int batch)
     return G;
 }
 
+// Lanes per horizon stage.  A batch of at most one instance per SIMD of the chip cannot fill the machine by packing instances
+// into wavefronts; each wavefront is then bound by the length of its own instruction stream, and dealing the inequality rows
+// of a stage out to 3 (N <= 20) or 2 (N <= 31) lanes shortens that stream (rti_split_kernel.hpp).  Larger batches keep one lane
+// per stage and 64/G instances per wavefront.
+int pick_split(mpc_handle *h, int batch)
+{
+    if (h->use_mfma || !h->row_parallel || h->lanes_override) return 1;
+    const int N = h->cfg.N;
+    const int fit = N <= 20 ? 3 : (N <= 31 ? 2 : 1);
+    if (h->split_override == 0) return batch <= h->simd_count ? fit : 1;
+    return h->split_override <= fit ? h->split_override : fit;
+}
+
+template <int NO, int LPS>
+int launch_split(mpc_handle *, const mpc::KParams &p, hipStream_t s)
+{
+    const size_t lds = (size_t)mpc::SplitLds<LPS, NO>::total(p.N, p.obst != nullptr) * sizeof(double);
+    if (lds > 65536) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&mpc::rti_split_kernel<NO, LPS>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((mpc::rti_split_kernel<NO, LPS>), dim3(p.batch), dim3(64), lds, s, p);
+    return MPC_OK;
+}
+
 int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
 {
     p.iters_acc = h->d_iters_acc; p.status_acc = h->d_status_acc;
@@ -111,6 +137,23 @@ int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
     if (h->profiling && h->ev_used < (int)h->ev_start.size()) {   // pool is created by mpc_profile_enable, never here
         e0 = h->ev_start[h->ev_used]; e1 = h->ev_stop[h->ev_used]; h->ev_used++;
         HIPCHK(hipEventRecord(e0, s));
+    }
+    const int lps = pick_split(h, p.batch);
+    if (lps > 1) {
+        int rc = MPC_OK;
+        switch (h->cfg.n_obst * 10 + lps) {
+        case 32: rc = launch_split<3, 2>(h, p, s); break;
+        case 33: rc = launch_split<3, 3>(h, p, s); break;
+        case 52: rc = launch_split<5, 2>(h, p, s); break;
+        case 53: rc = launch_split<5, 3>(h, p, s); break;
+        case 102: rc = launch_split<10, 2>(h, p, s); break;
+        case 103: rc = launch_split<10, 3>(h, p, s); break;
+        default: return fail(MPC_ERR_ARG, "n_obst must be 3, 5 or 10");
+        }
+        if (rc) return rc;
+        HIPCHK(hipGetLastError());
+        if (e1) HIPCHK(hipEventRecord(e1, s));
+        return MPC_OK;
     }
     const int G = pick_lanes(h, p.batch);
     const dim3 grid((p.batch + 64 / G - 1) / (64 / G)), block(64);
@@ -188,6 +231,12 @@ int mpc_create(const mpc_config *cfg, int device, int max_batch, mpc_handle **ou
     HIPCHK(hipSetDevice(device));
     mpc_handle *h = new mpc_handle();
     h->cfg = *cfg; h->device = device; h->max_batch = max_batch;
+    {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        h->simd_count = 4 * prop.multiProcessorCount;
+    }
+    h->split_override = 0;
     h->lanes_override = 0; h->use_mfma = 0; h->row_parallel = 1; h->profiling = 0; h->ev_used = 0; h->d_trace = nullptr; h->d_iters_acc = nullptr; h->d_status_acc = nullptr;
     const size_t B = (size_t)max_batch, N = (size_t)cfg->N, no = (size_t)cfg->n_obst;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -567,7 +616,22 @@ int mpc_set_row_parallel(mpc_handle *h, int on)
 int mpc_get_lanes_per_instance(mpc_handle *h, int batch)
 {
     if (!h) return fail(MPC_ERR_ARG, "null handle");
-    return pick_lanes(h, batch);
+    return pick_split(h, batch) > 1 ? 64 : pick_lanes(h, batch);
+}
+
+int mpc_set_lanes_per_stage(mpc_handle *h, int lanes)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    if (lanes < 0 || lanes > 3) return fail(MPC_ERR_ARG, "lanes per stage must be 0 (automatic), 1, 2 or 3");
+    if ((lanes == 3 && h->cfg.N > 20) || (lanes == 2 && h->cfg.N > 31)) return fail(MPC_ERR_ARG, "lanes per stage * (N + 1) must not exceed 64");
+    h->split_override = lanes;
+    return MPC_OK;
+}
+
+int mpc_get_lanes_per_stage(mpc_handle *h, int batch)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    return pick_split(h, batch);
 }
 
 }  // extern "C"

@@ -129,20 +129,26 @@ __device__ __forceinline__ void dyn_step(const double x[5], const double u[2], d
 // One constant-velocity step with wall reflection, src/utils/visualization.py:35-59.  Plain IEEE operators in the
 // reference's own operation order with FP contraction switched off for this block, so that the look-ahead is bit-exact
 // against numpy (HIP's __dmul_rn/__dadd_rn are inlined plain operators that the backend would still fuse into FMAs).
-__device__ __forceinline__ void obstacle_advance(const World w, double dt, double &x, double &vx, double &y, double &vy)
+// One coordinate (the reference treats x and y alike, :35-47 and :48-59):  t_hit = (distance to the wall ahead) / |v|;
+// t_hit <= dt reflects.  The division (~40 instructions, and the look-ahead is a serial chain of N such steps) is only
+// needed next to a wall: RN(n / |v|) <= dt is impossible when n > |v| dt (1 + 2^-50) -- the rounded product is at least
+// |v| dt (1 + 2^-51), so the quotient exceeds dt by two ulps or more before rounding -- and then the branch outcome, hence
+// every bit of the result, is that of the reference without computing t_hit.
+__device__ __forceinline__ void coord_advance(double lo, double hi, double dt, double &x, double &v)
 {
 #pragma clang fp contract(off)
-    double t_hit;
-    if (vx < 0) t_hit = (x - w.xmin) / fabs(vx);
-    else if (vx > 0) t_hit = (w.xmax - x) / fabs(vx);
-    else t_hit = INFINITY;
-    if (t_hit <= dt) { const double a = vx * t_hit, b = vx * (dt - t_hit); x = x + (a - b); vx = -vx; }
-    else { const double a = vx * dt; x = x + a; }
-    if (vy < 0) t_hit = (y - w.ymin) / fabs(vy);
-    else if (vy > 0) t_hit = (w.ymax - y) / fabs(vy);
-    else t_hit = INFINITY;
-    if (t_hit <= dt) { const double a = vy * t_hit, b = vy * (dt - t_hit); y = y + (a - b); vy = -vy; }
-    else { const double a = vy * dt; y = y + a; }
+    const double av = fabs(v);
+    const double n = v < 0 ? x - lo : hi - x;
+    bool hit = false;
+    double t_hit = 0.0;
+    if (v != 0 && !(n > av * dt * (1.0 + 0x1p-50))) { t_hit = n / av; hit = t_hit <= dt; }
+    if (hit) { const double a = v * t_hit, b = v * (dt - t_hit); x = x + (a - b); v = -v; }
+    else { const double a = v * dt; x = x + a; }
+}
+__device__ __forceinline__ void obstacle_advance(const World w, double dt, double &x, double &vx, double &y, double &vy)
+{
+    coord_advance(w.xmin, w.xmax, dt, x, vx);
+    coord_advance(w.ymin, w.ymax, dt, y, vy);
 }
 // velocity noise of Obstacle.step(), visualization.py:28-33
 __device__ __forceinline__ void obstacle_noise(double randomness, double vmax, double nx, double ny, double &vx, double &vy)
@@ -785,7 +791,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     const int i = lane - slot * G;            // this lane's stage
     const bool act = (i <= N);
     const bool has_u = (i < N);
-    const bool xb = (i >= 1) && (i < N || p.bx_terminal);
+    const bool xb = (i >= 1) && (i < N || (i == N && p.bx_terminal));
     const double dt = p.dt, h2 = p.h2;
 
     // ---- load (coalesced: consecutive lanes read consecutive stages of this instance's records) ----
@@ -804,7 +810,19 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     double pxy[NOBST][2];
     if (p.obst) {
         double *Pl = lds_P + (size_t)slot * (N + 1) * NOBST * 2;
-        if (i < NOBST) {       // lane j = i walks obstacle j through the horizon (Obstacle.predict_trajectory, visualization.py:62-79)
+        if (2 * NOBST <= G) {
+            if (i < 2 * NOBST) {   // lane i walks coordinate i & 1 of obstacle i >> 1 through the horizon (Obstacle.predict_trajectory, visualization.py:62-79)
+                const int j = i >> 1, c = i & 1;
+                const double *o = p.obst + ((size_t)inst * NOBST + j) * 4;
+                double q = o[c], v = (c == 0 && !p.world.bug_compat_predict) ? o[2] : o[3];      // defect D1: vx = self.vy (:69)
+                const double lo = c ? p.world.ymin : p.world.xmin, hi = c ? p.world.ymax : p.world.xmax;
+                Pl[i] = q;
+                for (int k = 1; k <= N; k++) {
+                    coord_advance(lo, hi, dt, q, v);
+                    Pl[k * NOBST * 2 + i] = q;
+                }
+            }
+        } else if (i < NOBST) {       // lane j = i walks obstacle j through the horizon
             const double *o = p.obst + ((size_t)inst * NOBST + i) * 4;
             double ox = o[0], oy = o[1], ovy = o[3];
             double ovx = p.world.bug_compat_predict ? o[3] : o[2];

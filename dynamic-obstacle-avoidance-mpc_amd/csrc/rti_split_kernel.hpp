@@ -1,0 +1,711 @@
+// rti_split_kernel.hpp -- the RTI solve kernel for SMALL batches (at most one instance per SIMD of the chip): one instance per
+// wavefront, LPS LANES PER HORIZON STAGE (LPS = 3 for N <= 20, LPS = 2 for N <= 31).
+//
+// Same mathematics, same interior point method and the same row-parallel stage recursions as rti_solve_kernel<NOBST, G, 2>
+// (rti_kernel.hpp; reference: src/simulation/robot_ocp_problem.py:126-132,145-166,186-198); what changes is who owns the
+// inequality rows.  With one instance per wavefront a batch of 1024 fills the 1024 SIMDs of an MI355X with one wavefront
+// each, and such a wavefront is bound by the length of its own instruction stream.  40 % of that stream
+// are the lane-parallel "row phases" in which the lane that owns stage t walks through all 12 box rows and 2*NOBST obstacle
+// rows of that stage while two thirds of the wavefront idle.  Here the rows of stage t are dealt out to LPS neighbouring
+// lanes (lane = LPS * t + part):
+//     box variables (ua, ual, x, y, v, om): 6 / LPS per lane (both sides of the box = 2 rows each),
+//     obstacle rows: ceil(NOBST / LPS) pairs per lane (obstacle j = slot * LPS + part),
+// so the row phases shrink by the factor LPS and the per-lane row state by as much (no AGPR round trips).  What the parts of
+// a stage have to add up -- the barrier terms of the reduced Hessian and the gradients of the two Newton right-hand sides --
+// goes through a small LDS mailbox twice per interior-point iteration; the sums are formed in a fixed order by every lane of
+// the stage, so the result is deterministic and identical in the LPS lanes.  Everything a lane needs of the stage's Newton
+// step it reads from the stage's LDS block (same address in the LPS lanes: a broadcast).
+#pragma once
+#include "rti_kernel.hpp"
+#include <type_traits>
+
+namespace mpc {
+
+template <int LPS, int NOBST>
+struct SplitLds {
+    static constexpr int NBL = 6 / LPS;                       // box variables per lane
+    static constexpr int NSL = (NOBST + LPS - 1) / LPS;       // obstacle row pairs per lane
+    static constexpr int MBL = 2 * NBL + 5;                   // mailbox doubles per lane: (H diagonal, gradient) per box variable, sxx, syy, sxy, sgx, sgy
+    static constexpr int MBS = LPS * MBL;                     // ... per stage
+    static constexpr int STAGES = 64 / LPS + 1;               // every lane has a mailbox of its own (lanes past the horizon write dead words)
+    static __host__ __device__ constexpr int mailbox() { return STAGES * MBS; }
+    static __host__ __device__ constexpr int total(int N, bool lookahead) { return RowLds::total(N, 1) + mailbox() + (lookahead ? (N + 1) * NOBST * 2 : 0); }
+};
+
+template <int K>
+__device__ __forceinline__ double nth_of_six(double a0, double a1, double a2, double a3, double a4, double a5)
+{
+    if constexpr (K == 0) return a0; else if constexpr (K == 1) return a1; else if constexpr (K == 2) return a2;
+    else if constexpr (K == 3) return a3; else if constexpr (K == 4) return a4; else return a5;
+}
+
+template <int NOBST, int LPS>
+__global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
+{
+    static_assert(LPS == 2 || LPS == 3, "two or three lanes per horizon stage");
+    using SL = SplitLds<LPS, NOBST>;
+    constexpr int NBL = SL::NBL, NSL = SL::NSL, MBL = SL::MBL, MBS = SL::MBS;
+    const int lane = threadIdx.x;
+    const int inst = blockIdx.x;              // grid = batch: one instance per wavefront
+    const int N = p.N;
+    const int i = lane / LPS;                 // this lane's stage
+    const int h = lane - i * LPS;             // ... and its part of the stage's rows
+    const bool own = (h == 0);                // the part that stages the stage's blocks in LDS and stores the iterate
+    const bool act = (i <= N);
+    const bool has_u = (i < N);
+    const bool xb = (i >= 1) && (i < N || (i == N && p.bx_terminal));
+    const double dt = p.dt, h2 = p.h2;
+    // part flags the optimiser cannot trace back to h (it would turn the select chains below into indexed loads from a stack array)
+    int is_part1 = (h == 1), is_part2 = (h == 2);
+    asm volatile("" : "+v"(is_part1), "+v"(is_part2));
+    // value of the box variable k = part * NBL + s out of six values indexed by k (ua, ual, x, y, v, om); scalars, not an array:
+    // the optimiser would turn selects between array elements into indexed loads from a stack copy
+    auto part_of = [&](auto sc, double a0, double a1, double a2, double a3, double a4, double a5) {
+        constexpr int s = decltype(sc)::value;
+        double r = nth_of_six<s>(a0, a1, a2, a3, a4, a5);
+        r = is_part1 ? nth_of_six<NBL + s>(a0, a1, a2, a3, a4, a5) : r;
+        if (LPS == 3) r = is_part2 ? nth_of_six<(2 * NBL + s) % 6>(a0, a1, a2, a3, a4, a5) : r;
+        return r;
+    };
+    // the same for vectors in z order (ua, ual, x, y, psi, v, om)
+    auto zpart_of = [&](const double v[7], int s) {
+        const int zidx[6] = {0, 1, 2, 3, 5, 6};
+        double r = v[zidx[s]];
+        r = is_part1 ? v[zidx[NBL + s]] : r;
+        if (LPS == 3) r = is_part2 ? v[zidx[(2 * NBL + s) % 6]] : r;
+        return r;
+    };
+
+#ifdef MPC_PHASE_TIMING
+    long long tacc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    MPC_T0();
+    // ---- load ----
+    double x0v[5], gl[2];
+#pragma unroll
+    for (int c = 0; c < 5; c++) x0v[c] = p.x0[(size_t)inst * 5 + c];
+    gl[0] = p.goal[(size_t)inst * 2]; gl[1] = p.goal[(size_t)inst * 2 + 1];
+    double *Xg = p.X + (size_t)inst * (N + 1) * 5, *Ug = p.U + (size_t)inst * N * 2;
+    const bool ep_done = (p.fused & kFuseMetrics) && p.ep_flags && (p.ep_flags[inst] & 1);
+    extern __shared__ double lds_raw[];
+    const RowLds RL(lds_raw + RowLds::pad_front(N), N);
+    double *MB = lds_raw + RowLds::total(N, 1);
+    double *lds_P = MB + SL::mailbox();
+    double *MBw = MB + i * MBS + h * MBL;     // this lane's mailbox
+    const double *MBr = MB + i * MBS;         // the mailboxes of this lane's stage
+    // obstacle positions of this lane's obstacle rows at its stage: explicit P (parameterize_model, robot_ocp_problem.py:154-166)
+    // or the look-ahead computed here (Obstacle.predict_trajectory, src/utils/visualization.py:62-79)
+    double pxy[NSL][2];
+    if (p.obst) {
+        if (lane < 2 * NOBST) {    // lane walks coordinate lane & 1 of obstacle lane >> 1 through the horizon
+            const int j = lane >> 1, c = lane & 1;
+            const double *o = p.obst + ((size_t)inst * NOBST + j) * 4;
+            double q = o[c], v = (c == 0 && !p.world.bug_compat_predict) ? o[2] : o[3];      // defect D1: vx = self.vy (visualization.py:69)
+            const double lo = c ? p.world.ymin : p.world.xmin, hi = c ? p.world.ymax : p.world.xmax;
+            lds_P[lane] = q;
+            for (int k = 1; k <= N; k++) {
+                coord_advance(lo, hi, dt, q, v);
+                lds_P[k * NOBST * 2 + lane] = q;
+            }
+        }
+        __syncthreads();
+    }
+    MPC_TICK(10);
+#pragma unroll
+    for (int s = 0; s < NSL; s++) {
+        const int j = s * LPS + h, jj = j < NOBST ? j : NOBST - 1;
+        const double *src = p.obst ? lds_P + ((act ? i : 0) * NOBST + jj) * 2
+                                   : p.P + (((size_t)inst * (N + 1) + (act ? i : 0)) * NOBST + jj) * 2;
+        pxy[s][0] = src[0]; pxy[s][1] = src[1];
+    }
+    double xi[5] = {0, 0, 0, 0, 0}, ui[2] = {0, 0}, xnext[5] = {0, 0, 0, 0, 0};
+    if (act) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) xi[c] = Xg[i * 5 + c];
+    }
+    if (has_u) {
+        ui[0] = Ug[i * 2]; ui[1] = Ug[i * 2 + 1];
+#pragma unroll
+        for (int c = 0; c < 5; c++) xnext[c] = Xg[(i + 1) * 5 + c];
+    }
+
+    MPC_TICK(11);
+    // ---- slack schedule, robot_ocp_problem.py:145-152 ----
+    double zpen = 0.0;
+    {
+        const double ex = x0v[0] - gl[0], ey = x0v[1] - gl[1];
+        const double scale = p.slack_a * (ex * ex + ey * ey + x0v[3] * x0v[3] + x0v[4] * x0v[4] + p.slack_b);
+        const double alpha_i = scale * (double)(N - i) / (double)N;
+        zpen = alpha_i * (has_u ? p.ss : 1.0);
+    }
+    const bool vs = act && (i >= 1) && (p.soft_h ? (zpen > 0.0) : true);
+    const bool soft = p.soft_h != 0;
+
+    // ---- linearise (every part of a stage computes the stage's linearisation: same instruction stream, no extra cost) ----
+    double lin0 = 0.0;
+    double d0[5] = {0, 0, 0, 0, 0};
+    StageLin S;
+    S.a02 = S.a03 = S.a04 = S.a12 = S.a13 = S.a14 = S.b00 = S.b01 = S.b10 = S.b11 = 0.0; S.dt = dt; S.h2 = h2;
+    double bb[5] = {0, 0, 0, 0, 0};
+    if (has_u) {
+        double xn[5], ae[6], be[4];
+        dyn_step<true>(xi, ui, dt, xn, ae, be);
+        S.a02 = ae[0]; S.a03 = ae[1]; S.a04 = ae[2]; S.a12 = ae[3]; S.a13 = ae[4]; S.a14 = ae[5];
+        S.b00 = be[0]; S.b01 = be[1]; S.b10 = be[2]; S.b11 = be[3];
+#pragma unroll
+        for (int c = 0; c < 5; c++) { bb[c] = xn[c] - xnext[c]; lin0 = fmax(lin0, fabs(bb[c])); }
+    }
+    if (i == 0) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) { d0[c] = x0v[c] - xi[c]; lin0 = fmax(lin0, fabs(d0[c])); }
+    }
+    if (own && has_u) {         // W~_t = [A b B] rows 0..4 (cols: x0..x4, b, ua, ual); column 5 is rewritten every iteration
+        double *w = RL.W + RowLds::WS * i;
+        const double Wrow[5][8] = {{1.0, 0.0, S.a02, S.a03, S.a04, 0.0, S.b00, S.b01}, {0.0, 1.0, S.a12, S.a13, S.a14, 0.0, S.b10, S.b11},
+                                   {0.0, 0.0, 1.0, 0.0, dt, 0.0, 0.0, h2}, {0.0, 0.0, 0.0, 1.0, 0.0, 0.0, dt, 0.0}, {0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, dt}};
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) w[k * 8 + c] = Wrow[k][c];
+    }
+
+    MPC_TICK(12);
+    // ---- this lane's box variables (slot s <-> variable k = part * NBL + s of ua, ual, x, y, v, om), in registers ----
+    // cost: Gauss-Newton diagonal hd (+ LM) and gradient gc0 = W (y - yref) of the variable; robot_ocp_problem.py:59-83
+    bool bp[NBL];
+    double cl0[NBL], ch0[NBL], hq[NBL], hd[NBL], gc0[NBL];
+    double ll[NBL], tl[NBL], lh[NBL], th[NBL], rtl[NBL], rth[NBL], zs[NBL];
+    {
+        auto slot_init = [&](auto sc) {     // slot index as a compile-time constant
+            constexpr int s = decltype(sc)::value;
+            const double val = part_of(sc, ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]);
+            const double lo = part_of(sc, p.bu_lo[0], p.bu_lo[1], p.bx_lo[0], p.bx_lo[1], p.bx_lo[2], p.bx_lo[3]);
+            const double hi = part_of(sc, p.bu_hi[0], p.bu_hi[1], p.bx_hi[0], p.bx_hi[1], p.bx_hi[2], p.bx_hi[3]);
+            const bool is_u = part_of(sc, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0) != 0.0;
+            bp[s] = act && (is_u ? has_u : xb);
+            hd[s] = part_of(sc, has_u ? p.Hd_stage[0] : 0.0, has_u ? p.Hd_stage[1] : 0.0, has_u ? p.Hd_stage[2] : p.Hd_term[0],
+                            has_u ? p.Hd_stage[3] : p.Hd_term[1], has_u ? p.Hd_stage[5] : p.Hd_term[3], has_u ? p.Hd_stage[6] : p.Hd_term[4]);
+            hq[s] = (is_u && !has_u) ? 1.0 : hd[s];       // the terminal stage has no inputs: unit block keeps Muu regular
+            const double wg = part_of(sc, has_u ? p.Wg[4] : 0.0, has_u ? p.Wg[5] : 0.0, has_u ? p.Wg[0] : p.Weg[0], has_u ? p.Wg[1] : p.Weg[1],
+                                      has_u ? p.Wg[2] : p.Weg[2], has_u ? p.Wg[3] : p.Weg[3]);
+            gc0[s] = wg * (val - part_of(sc, 0.0, 0.0, gl[0], gl[1], 0.0, 0.0));
+            cl0[s] = val - lo; ch0[s] = hi - val;
+            tl[s] = fmax(cl0[s], p.thr0); th[s] = fmax(ch0[s], p.thr0);
+            rtl[s] = rcp_nr(tl[s]); rth[s] = rcp_nr(th[s]);
+            ll[s] = p.mu0 * rtl[s]; lh[s] = p.mu0 * rth[s];
+            zs[s] = 0.0;
+            if (bp[s]) lin0 = fmax(lin0, fmax(tl[s] - cl0[s], th[s] - ch0[s]));
+        };
+        slot_init(std::integral_constant<int, 0>{});
+        slot_init(std::integral_constant<int, 1>{});
+        if constexpr (NBL > 2) slot_init(std::integral_constant<int, 2>{});
+    }
+    const double hd_psi = has_u ? p.Hd_stage[4] : p.Hd_term[2];
+    // ---- this lane's obstacle rows (slot s <-> obstacle j = s * LPS + part): rho1 = h + a'dx + s >= 0 (lam1, t1), rho2 = s >= 0
+    //      (lam2, t2); robot_model.py:60-65 ----
+    bool sp[NSL];
+    double hh[NSL], ax[NSL], ay[NSL], sv[NSL], l1[NSL], t1[NSL], l2[NSL], t2[NSL], rt1[NSL], rt2[NSL];
+#pragma unroll
+    for (int s = 0; s < NSL; s++) {
+        sp[s] = vs && (s * LPS + h < NOBST);
+        const double ex = xi[0] - pxy[s][0], ey = xi[1] - pxy[s][1];
+        hh[s] = ex * ex + ey * ey - p.r2; ax[s] = 2 * ex; ay[s] = 2 * ey;
+        if (soft) {
+            sv[s] = (hh[s] < 0 ? -hh[s] : 0.0) + p.thr0;
+            t1[s] = fmax(hh[s] + sv[s], p.thr0);
+            t2[s] = fmax(sv[s], p.thr0);
+        } else {
+            sv[s] = 0.0; t1[s] = fmax(hh[s], p.thr0); t2[s] = 1.0;
+            if (sp[s]) lin0 = fmax(lin0, t1[s] - hh[s]);
+        }
+        rt1[s] = rcp_nr(t1[s]); rt2[s] = rcp_nr(t2[s]);
+        l1[s] = p.mu0 * rt1[s]; l2[s] = soft ? p.mu0 * rt2[s] : 0.0;
+    }
+    int n_items_lane = 0;
+#pragma unroll
+    for (int s = 0; s < NBL; s++) n_items_lane += bp[s] ? 2 : 0;
+#pragma unroll
+    for (int s = 0; s < NSL; s++) n_items_lane += sp[s] ? (soft ? 2 : 1) : 0;
+    const double n_items = seg_sum<64>((double)n_items_lane, lane);
+    const double inv_items = n_items > 0 ? 1.0 / n_items : 0.0;
+    lin0 = seg_max<64>(lin0, lane);
+
+    double z[7] = {0, 0, 0, 0, 0, 0, 0};
+    double rhoPi = 1.0;
+    int status = 2, it = 0, it_done = 0;
+    bool running = !ep_done;
+
+    MPC_TICK(13);
+    for (it = 0;; it++) {
+        // ---- complementarity measures ----
+        double msum = 0.0, cmax = 0.0;
+#pragma unroll
+        for (int s = 0; s < NBL; s++) if (bp[s]) {
+            const double a = ll[s] * tl[s], b = lh[s] * th[s];
+            msum += a + b;
+            if (!(tl[s] <= 2 * kTLMin || ll[s] <= 2 * kTLMin)) cmax = fmax(cmax, a);
+            if (!(th[s] <= 2 * kTLMin || lh[s] <= 2 * kTLMin)) cmax = fmax(cmax, b);
+        }
+#pragma unroll
+        for (int s = 0; s < NSL; s++) if (sp[s]) {
+            const double a = l1[s] * t1[s];
+            msum += a;
+            if (!(t1[s] <= 2 * kTLMin || l1[s] <= 2 * kTLMin)) cmax = fmax(cmax, a);
+            if (soft) {
+                const double b = l2[s] * t2[s];
+                msum += b;
+                if (!(t2[s] <= 2 * kTLMin || l2[s] <= 2 * kTLMin)) cmax = fmax(cmax, b);
+            }
+        }
+        msum = seg_sum<64>(msum, lane);
+        cmax = seg_max<64>(cmax, lane);
+        const double mu = msum * inv_items;
+        const double lin = rhoPi * lin0;
+        if (running) {
+            if (!(mu == mu) || !(fabs(mu) <= 1e300)) { status = 4; running = false; it_done = it; }
+            else if (lin <= p.tol && cmax <= p.tol) { status = 0; running = false; it_done = it; }
+            else if (it >= p.iter_max) { status = 2; running = false; it_done = it; }
+        }
+        if (!running) break;      // wave-uniform: one instance per wavefront
+        MPC_TICK(0);
+
+        // ---- predictor (sigma = 0): this lane's share of the local gradient, the barrier terms and the reduced Hessian ----
+        double rdl[NBL], rdh[NBL];                  // residuals r_d = rho(z) - t of the box rows
+        struct SoftT { double w1, w2, rD, be1, be2, rs, rd1, rd2; } so[NSL];
+        {
+#pragma unroll
+            for (int s = 0; s < NBL; s++) {
+                rdl[s] = (cl0[s] + zs[s]) - tl[s];
+                rdh[s] = (ch0[s] - zs[s]) - th[s];
+                double hdiag = hq[s], g = gc0[s] + hd[s] * zs[s];           // (H z + q) of the variable
+                if (bp[s]) {
+                    const double wl = ll[s] * rtl[s], wh = lh[s] * rth[s];
+                    const double bl = (ll[s] * tl[s] + ll[s] * rdl[s]) * rtl[s], bh = (lh[s] * th[s] + lh[s] * rdh[s]) * rth[s];
+                    hdiag += wl + wh;
+                    g += lh[s] - ll[s];                                     // - C'lam
+                    g += bl - bh;                                           // sum_c c beta_c
+                }
+                MBw[2 * s] = hdiag; MBw[2 * s + 1] = g;
+            }
+            double sxx = 0.0, syy = 0.0, sxy = 0.0, glx = 0.0, gly = 0.0, cbx = 0.0, cby = 0.0;
+#pragma unroll
+            for (int s = 0; s < NSL; s++) {
+                SoftT &o = so[s];
+                const double y = ax[s] * z[2] + ay[s] * z[3];
+                o.w1 = l1[s] * rt1[s];
+                if (soft) {
+                    o.rd1 = (hh[s] + y + sv[s]) - t1[s]; o.rd2 = sv[s] - t2[s];
+                    o.be1 = (l1[s] * t1[s] + l1[s] * o.rd1) * rt1[s];
+                    o.w2 = l2[s] * rt2[s];
+                    o.be2 = (l2[s] * t2[s] + l2[s] * o.rd2) * rt2[s];
+                    o.rs = zpen * sv[s] + zpen - l1[s] - l2[s];
+                    o.rD = rcp_nr(zpen + o.w1 + o.w2);
+                } else {
+                    o.rd1 = (hh[s] + y) - t1[s]; o.rd2 = 0.0;
+                    o.be1 = (l1[s] * t1[s] + l1[s] * o.rd1) * rt1[s];
+                    o.w2 = 0.0; o.be2 = 0.0; o.rs = 0.0; o.rD = 0.0;
+                }
+                if (sp[s]) {
+                    double weff, geff;
+                    if (soft) {       // slack eliminated; cancellation-free forms
+                        weff = o.w1 * (zpen + o.w2) * o.rD;
+                        geff = (o.be1 * (zpen + o.w2) - o.w1 * (o.rs + o.be2)) * o.rD;
+                    } else { weff = o.w1; geff = o.be1; }
+                    sxx += weff * ax[s] * ax[s]; syy += weff * ay[s] * ay[s]; sxy += weff * ax[s] * ay[s];
+                    glx -= l1[s] * ax[s]; gly -= l1[s] * ay[s];
+                    cbx += geff * ax[s]; cby += geff * ay[s];
+                }
+            }
+            MBw[2 * NBL] = sxx; MBw[2 * NBL + 1] = syy; MBw[2 * NBL + 2] = sxy; MBw[2 * NBL + 3] = glx + cbx; MBw[2 * NBL + 4] = gly + cby;
+        }
+        MPC_TICK(1);
+        __syncthreads();
+        double bbr[5], x_init[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) { bbr[c] = rhoPi * bb[c]; x_init[c] = rhoPi * d0[c]; }
+        {   // the stage's sums, in a fixed order (identical in the LPS lanes of the stage)
+            double Hk[6], gk[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { Hk[k] = MBr[(k / NBL) * MBL + 2 * (k % NBL)]; gk[k] = MBr[(k / NBL) * MBL + 2 * (k % NBL) + 1]; }
+            double Sxx = MBr[2 * NBL], Syy = MBr[2 * NBL + 1], Sxy = MBr[2 * NBL + 2], Sgx = MBr[2 * NBL + 3], Sgy = MBr[2 * NBL + 4];
+#pragma unroll
+            for (int q = 1; q < LPS; q++) {
+                Sxx += MBr[q * MBL + 2 * NBL]; Syy += MBr[q * MBL + 2 * NBL + 1]; Sxy += MBr[q * MBL + 2 * NBL + 2];
+                Sgx += MBr[q * MBL + 2 * NBL + 3]; Sgy += MBr[q * MBL + 2 * NBL + 4];
+            }
+            if (own && act) {   // H~aug_t, dense 8 x 8, z~ order (x0..x4, 1, ua, ual); affine column of W~_t
+                const double hxx = Hk[2] + Sxx, hyy = Hk[3] + Syy;
+                const double gxs[5] = {gk[2] + Sgx, gk[3] + Sgy, hd_psi * z[4], gk[4], gk[5]};
+                const double lu0 = gk[0], lu1 = gk[1];
+                const double Hrow[8][8] = {{hxx, Sxy, 0.0, 0.0, 0.0, gxs[0], 0.0, 0.0}, {Sxy, hyy, 0.0, 0.0, 0.0, gxs[1], 0.0, 0.0},
+                                           {0.0, 0.0, hd_psi, 0.0, 0.0, gxs[2], 0.0, 0.0}, {0.0, 0.0, 0.0, Hk[4], 0.0, gxs[3], 0.0, 0.0},
+                                           {0.0, 0.0, 0.0, 0.0, Hk[5], gxs[4], 0.0, 0.0}, {gxs[0], gxs[1], gxs[2], gxs[3], gxs[4], 0.0, lu0, lu1},
+                                           {0.0, 0.0, 0.0, 0.0, 0.0, lu0, Hk[0], 0.0}, {0.0, 0.0, 0.0, 0.0, 0.0, lu1, 0.0, Hk[1]}};
+                double *hc = RL.H + RowLds::HS * i;
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+#pragma unroll
+                    for (int c = 0; c < 8; c++) hc[r * 8 + c] = Hrow[r][c];
+                if (has_u) {
+#pragma unroll
+                    for (int k = 0; k < 5; k++) RL.W[RowLds::WS * i + k * 8 + 5] = bbr[k];
+                }
+            }
+        }
+        __syncthreads();
+        MPC_TICK(9);
+        rowpar_factor(lane, N, RL, lane < 16);
+        __syncthreads();
+        StageFac F;
+        F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 5; c++) { F.K0[c] = 0.0; F.K1[c] = 0.0; }
+        if (has_u) {
+            const double *ko = RL.H + RowLds::HS * i;
+#pragma unroll
+            for (int c = 0; c < 5; c++) { F.K0[c] = ko[c]; F.K1[c] = ko[8 + c]; }
+            F.k0 = ko[5]; F.k1 = ko[13]; F.i00 = ko[6]; F.l = ko[7]; F.i11 = ko[14];
+        }
+        // the parts of a stage must all have read the factors before the owner overwrites the block: LDS operations of one
+        // wavefront complete in order, so no barrier is needed
+        if (own && has_u) {     // closed-loop matrix Acl = A + B K, row-major, and c_t = r_b + B k, for the row-parallel vector recursions
+            double *acl = RL.H + RowLds::HS * i + RowVec::ACL;
+            const double Ar[2][5] = {{1.0, 0.0, S.a02, S.a03, S.a04}, {0.0, 1.0, S.a12, S.a13, S.a14}};
+            const double Br[2][2] = {{S.b00, S.b01}, {S.b10, S.b11}};
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                acl[0 * RowVec::RS + c] = Ar[0][c] + Br[0][0] * F.K0[c] + Br[0][1] * F.K1[c];
+                acl[1 * RowVec::RS + c] = Ar[1][c] + Br[1][0] * F.K0[c] + Br[1][1] * F.K1[c];
+                acl[2 * RowVec::RS + c] = (c == 2 ? 1.0 : (c == 4 ? dt : 0.0)) + h2 * F.K1[c];
+                acl[3 * RowVec::RS + c] = (c == 3 ? 1.0 : 0.0) + dt * F.K0[c];
+                acl[4 * RowVec::RS + c] = (c == 4 ? 1.0 : 0.0) + dt * F.K1[c];
+            }
+            double *cc = acl + 5;
+            cc[0 * RowVec::RS] = bbr[0] + S.b00 * F.k0 + S.b01 * F.k1; cc[1 * RowVec::RS] = bbr[1] + S.b10 * F.k0 + S.b11 * F.k1;
+            cc[2 * RowVec::RS] = bbr[2] + h2 * F.k1; cc[3 * RowVec::RS] = bbr[3] + dt * F.k0; cc[4 * RowVec::RS] = bbr[4] + dt * F.k1;
+        }
+        MPC_TICK(2);
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = x_init[c];
+        }
+        __syncthreads();
+        rowpar_vector<true>(lane, N, RL, lane < 16);
+        __syncthreads();
+        double za[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (act) {
+            const double *xx = RL.H + RowLds::HS * i + RowVec::X;
+            double u0 = F.k0, u1 = F.k1;
+#pragma unroll
+            for (int c = 0; c < 5; c++) { za[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }
+            za[0] = u0; za[1] = u1;
+        }
+        MPC_TICK(3);
+
+        // ---- affine step: dt, dlam per row, step ratios, products dlam_aff * dt_aff ----
+        double ppl[NBL], pph[NBL], pp1[NSL], pp2[NSL];
+        double smu;
+        {
+            double rmax = 0.0, rmaxd = 0.0;      // largest -dt/t (primal) and -dlam/lam (dual) ratios
+            double dtl_[NBL], dth_[NBL], dll_[NBL], dlh_[NBL];
+#pragma unroll
+            for (int s = 0; s < NBL; s++) {
+                const double dzk = zpart_of(za, s);
+                dtl_[s] = dzk + rdl[s]; dth_[s] = -dzk + rdh[s];
+                dll_[s] = -(ll[s] * tl[s] + ll[s] * dtl_[s]) * rtl[s]; dlh_[s] = -(lh[s] * th[s] + lh[s] * dth_[s]) * rth[s];
+                ppl[s] = dll_[s] * dtl_[s]; pph[s] = dlh_[s] * dth_[s];
+                if (bp[s]) {
+                    rmax = fmax(rmax, fmax(-dtl_[s] * rtl[s], -dth_[s] * rth[s]));
+                    rmaxd = fmax(rmaxd, fmax(fma(dtl_[s], rtl[s], 1.0), fma(dth_[s], rth[s], 1.0)));      // -dlam/lam = 1 + dt/t when sigma = 0
+                }
+            }
+            double dt1_[NSL], dl1_[NSL], dt2_[NSL], dl2_[NSL];
+#pragma unroll
+            for (int s = 0; s < NSL; s++) {
+                const SoftT &o = so[s];
+                const double y = ax[s] * za[2] + ay[s] * za[3];
+                dt2_[s] = dl2_[s] = 0.0; pp2[s] = 0.0;
+                if (soft) {
+                    const double rsum = o.rs + o.be1 + o.be2;
+                    const double ds = -(rsum + o.w1 * y) * o.rD;
+                    dt1_[s] = o.rd1 + (y * (zpen + o.w2) - rsum) * o.rD;     // y + ds without cancellation
+                    dt2_[s] = o.rd2 + ds;
+                    dl2_[s] = -(l2[s] * t2[s] + l2[s] * dt2_[s]) * rt2[s];
+                    pp2[s] = dl2_[s] * dt2_[s];
+                    if (sp[s]) { rmax = fmax(rmax, -dt2_[s] * rt2[s]); rmaxd = fmax(rmaxd, fma(dt2_[s], rt2[s], 1.0)); }
+                } else dt1_[s] = o.rd1 + y;
+                dl1_[s] = -(l1[s] * t1[s] + l1[s] * dt1_[s]) * rt1[s];
+                pp1[s] = dl1_[s] * dt1_[s];
+                if (sp[s]) { rmax = fmax(rmax, -dt1_[s] * rt1[s]); rmaxd = fmax(rmaxd, fma(dt1_[s], rt1[s], 1.0)); }
+            }
+            rmax = seg_max<64>(rmax, lane); rmaxd = seg_max<64>(rmaxd, lane);
+            const double a_aff = rmax > 1.0 ? 1.0 / rmax : 1.0, a_affd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;
+            double maff = 0.0;
+#pragma unroll
+            for (int s = 0; s < NBL; s++) if (bp[s])
+                maff += (ll[s] + a_affd * dll_[s]) * (tl[s] + a_aff * dtl_[s]) + (lh[s] + a_affd * dlh_[s]) * (th[s] + a_aff * dth_[s]);
+#pragma unroll
+            for (int s = 0; s < NSL; s++) if (sp[s]) {
+                maff += (l1[s] + a_affd * dl1_[s]) * (t1[s] + a_aff * dt1_[s]);
+                if (soft) maff += (l2[s] + a_affd * dl2_[s]) * (t2[s] + a_aff * dt2_[s]);
+            }
+            maff = seg_sum<64>(maff, lane) * inv_items;
+            double sigma = mu > 0 ? maff / mu : 0.0;
+            sigma = sigma * sigma * sigma;
+            if (sigma > 1.0) sigma = 1.0;
+            smu = sigma * mu;
+#ifndef MPC_PHASE_TIMING
+            if (p.trace && lane == 0) {
+                double *tr = p.trace + ((size_t)inst * p.iter_max + it) * 4;
+                tr[0] = mu; tr[1] = sigma; tr[3] = cmax;
+            }
+#endif
+        }
+        MPC_TICK(4);
+
+        // ---- corrector: homogeneous system for the change of right-hand side, d beta_c = (dlam_aff dt_aff - sigma mu) / t ----
+        double gc[7];
+        {
+#pragma unroll
+            for (int s = 0; s < NBL; s++) {
+                const double dbl = (ppl[s] - smu) * rtl[s], dbh = (pph[s] - smu) * rth[s];
+                MBw[s] = bp[s] ? dbl - dbh : 0.0;
+            }
+            double sgx = 0.0, sgy = 0.0;
+#pragma unroll
+            for (int s = 0; s < NSL; s++) if (sp[s]) {
+                const double db1 = (pp1[s] - smu) * rt1[s];
+                double geff;
+                if (soft) {
+                    const SoftT &o = so[s];
+                    const double db2 = (pp2[s] - smu) * rt2[s];
+                    geff = (db1 * (zpen + o.w2) - o.w1 * db2) * o.rD;
+                } else geff = db1;
+                sgx += geff * ax[s]; sgy += geff * ay[s];
+            }
+            MBw[NBL] = sgx; MBw[NBL + 1] = sgy;
+            MPC_TICK(5);
+            __syncthreads();
+            const int zidx[6] = {0, 1, 2, 3, 5, 6};
+            gc[4] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) gc[zidx[k]] = MBr[(k / NBL) * MBL + (k % NBL)];
+            double Sgx = MBr[NBL], Sgy = MBr[NBL + 1];
+#pragma unroll
+            for (int q = 1; q < LPS; q++) { Sgx += MBr[q * MBL + NBL]; Sgy += MBr[q * MBL + NBL + 1]; }
+            gc[2] += Sgx; gc[3] += Sgy;
+            if (own && act) {   // c~_t = gc_x + K' gc_u  (K = 0 in the terminal lane)
+                double *cc = RL.H + RowLds::HS * i + RowVec::CT;
+#pragma unroll
+                for (int c = 0; c < 5; c++) cc[c] = gc[2 + c] + F.K0[c] * gc[0] + F.K1[c] * gc[1];
+            }
+            __syncthreads();
+            rowpar_vector<false>(lane, N, RL, lane < 16);
+            __syncthreads();
+            if (has_u) {        // feed-forward of the corrector right-hand side: k = -Muu^-1 (gc_u + B' p_{t+1})
+                const double *pp = RL.H + RowLds::HS * (i + 1) + RowVec::P;
+                const double pv[5] = {pp[0], pp[1], pp[2], pp[3], pp[4]};
+                const double m0 = gc[0] + S.dua(pv), m1 = gc[1] + S.dual(pv);
+                F.k1 = fma(F.l, m0, -m1) * F.i11;
+                F.k0 = fma(-F.l, F.k1, -(m0 * F.i00));
+            }
+        }
+        MPC_TICK(6);
+        if (own && has_u) {     // homogeneous dynamics: c_t = B k
+            double *cc = RL.H + RowLds::HS * i + RowVec::ACL + 5;
+            cc[0 * RowVec::RS] = S.b00 * F.k0 + S.b01 * F.k1; cc[1 * RowVec::RS] = S.b10 * F.k0 + S.b11 * F.k1;
+            cc[2 * RowVec::RS] = h2 * F.k1; cc[3 * RowVec::RS] = dt * F.k0; cc[4 * RowVec::RS] = dt * F.k1;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = 0.0;
+        }
+        __syncthreads();
+        rowpar_vector<true>(lane, N, RL, lane < 16);
+        __syncthreads();
+        double dz[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (act) {
+            const double *xx = RL.H + RowLds::HS * i + RowVec::X;
+            double u0 = F.k0, u1 = F.k1;
+#pragma unroll
+            for (int c = 0; c < 5; c++) { dz[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }
+            dz[0] = u0; dz[1] = u1;
+        }
+#pragma unroll
+        for (int c = 0; c < 7; c++) dz[c] += za[c];
+        MPC_TICK(7);
+
+        // ---- combined step: ratios, step length, update ----
+        {
+            double rmax = 0.0, rmaxd = 0.0;
+            double dzs[NBL], dtl_[NBL], dth_[NBL], dll_[NBL], dlh_[NBL];
+#pragma unroll
+            for (int s = 0; s < NBL; s++) {
+                dzs[s] = zpart_of(dz, s);
+                dtl_[s] = dzs[s] + rdl[s]; dth_[s] = -dzs[s] + rdh[s];
+                dll_[s] = -(ll[s] * tl[s] - smu + ppl[s] + ll[s] * dtl_[s]) * rtl[s];
+                dlh_[s] = -(lh[s] * th[s] - smu + pph[s] + lh[s] * dth_[s]) * rth[s];
+                if (bp[s]) {
+                    rmax = fmax(rmax, fmax(-dtl_[s] * rtl[s], -dth_[s] * rth[s]));
+                    rmaxd = fmax(rmaxd, fmax(-dll_[s] * rcp_nr(ll[s]), -dlh_[s] * rcp_nr(lh[s])));
+                }
+            }
+            double dt1_[NSL], dl1_[NSL], dt2_[NSL], dl2_[NSL], ds_[NSL];
+#pragma unroll
+            for (int s = 0; s < NSL; s++) {
+                const SoftT &o = so[s];
+                const double y = ax[s] * dz[2] + ay[s] * dz[3];
+                dt2_[s] = dl2_[s] = ds_[s] = 0.0;
+                if (soft) {
+                    const double db1 = (pp1[s] - smu) * rt1[s], db2 = (pp2[s] - smu) * rt2[s];
+                    const double rsum = o.rs + (o.be1 + db1) + (o.be2 + db2);
+                    ds_[s] = -(rsum + o.w1 * y) * o.rD;
+                    dt1_[s] = o.rd1 + (y * (zpen + o.w2) - rsum) * o.rD;
+                    dt2_[s] = o.rd2 + ds_[s];
+                    dl2_[s] = -(l2[s] * t2[s] - smu + pp2[s] + l2[s] * dt2_[s]) * rt2[s];
+                    if (sp[s]) { rmax = fmax(rmax, -dt2_[s] * rt2[s]); rmaxd = fmax(rmaxd, -dl2_[s] * rcp_nr(l2[s])); }
+                } else dt1_[s] = o.rd1 + y;
+                dl1_[s] = -(l1[s] * t1[s] - smu + pp1[s] + l1[s] * dt1_[s]) * rt1[s];
+                if (sp[s]) { rmax = fmax(rmax, -dt1_[s] * rt1[s]); rmaxd = fmax(rmaxd, -dl1_[s] * rcp_nr(l1[s])); }
+            }
+            rmax = seg_max<64>(rmax, lane); rmaxd = seg_max<64>(rmaxd, lane);
+            const double amax = rmax > 1.0 ? 1.0 / rmax : 1.0, amaxd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;
+            const double alpha = (amax >= 1.0) ? 1.0 : 0.9995 * amax;        // primal step: z, s, t
+            const double alphad = (amaxd >= 1.0) ? 1.0 : 0.9995 * amaxd;     // dual step: lam
+#ifndef MPC_PHASE_TIMING
+            if (p.trace && lane == 0) p.trace[((size_t)inst * p.iter_max + it) * 4 + 2] = alpha;
+#endif
+            if (!(alpha > 1e-14) || !(alphad > 1e-14)) { status = 4; running = false; it_done = it; }
+            if (running) {
+#pragma unroll
+                for (int c = 0; c < 7; c++) z[c] += alpha * dz[c];
+#pragma unroll
+                for (int s = 0; s < NBL; s++) {
+                    zs[s] += alpha * dzs[s];
+                    if (bp[s]) {
+                        tl[s] = fmax(tl[s] + alpha * dtl_[s], kTLMin); th[s] = fmax(th[s] + alpha * dth_[s], kTLMin);
+                        ll[s] = fmax(ll[s] + alphad * dll_[s], kTLMin); lh[s] = fmax(lh[s] + alphad * dlh_[s], kTLMin);
+                        rtl[s] = rcp_nr(tl[s]); rth[s] = rcp_nr(th[s]);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < NSL; s++) if (sp[s]) {
+                    t1[s] = fmax(t1[s] + alpha * dt1_[s], kTLMin); l1[s] = fmax(l1[s] + alphad * dl1_[s], kTLMin);
+                    rt1[s] = rcp_nr(t1[s]);
+                    if (soft) {
+                        sv[s] += alpha * ds_[s];
+                        t2[s] = fmax(t2[s] + alpha * dt2_[s], kTLMin); l2[s] = fmax(l2[s] + alphad * dl2_[s], kTLMin);
+                        rt2[s] = rcp_nr(t2[s]);
+                    }
+                }
+                rhoPi *= (1.0 - alpha);
+            }
+        }
+        MPC_TICK(8);
+        if (!running) break;
+    }
+
+    // ---- full step on the iterate; status 4 leaves it unchanged ----
+    const bool store = !ep_done;
+    if (status != 4) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) xi[c] += z[2 + c];
+        ui[0] += z[0]; ui[1] += z[1];
+    }
+    const double u_apply[2] = {lane_value(ui[0], 0), lane_value(ui[1], 0)};   // u* = U[0]
+    if ((p.fused & kFuseResetOnFail) && status == 4) {      // set_initial_guess(), robot_ocp_problem.py:203-205,286-306
+        xi[0] = x0v[0]; xi[1] = x0v[1]; xi[2] = x0v[2]; xi[3] = 0.0; xi[4] = 0.0; ui[0] = ui[1] = 0.0;
+    }
+    if (store && own && (status != 4 || (p.fused & (kFuseResetOnFail | kFuseShift)))) {
+        if (p.fused & kFuseShift) {                          // X[j] <- X[j+1], U[j] <- U[j+1], U[N-1] <- 0, X[N] kept (:253-258)
+            if (act && i >= 1) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) Xg[(i - 1) * 5 + c] = xi[c];
+            }
+            if (i == N) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) Xg[N * 5 + c] = xi[c];
+            }
+            if (has_u && i >= 1) { Ug[(i - 1) * 2] = ui[0]; Ug[(i - 1) * 2 + 1] = ui[1]; }
+            if (i == 0) { Ug[(N - 1) * 2] = 0.0; Ug[(N - 1) * 2 + 1] = 0.0; }
+        } else {
+            if (act) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) Xg[i * 5 + c] = xi[c];
+            }
+            if (has_u) { Ug[i * 2] = ui[0]; Ug[i * 2 + 1] = ui[1]; }
+        }
+    }
+    // ---- plant, obstacles, episode bookkeeping (fused closed-loop step) ----
+    if (p.fused & (kFusePlant | kFuseObstacles | kFuseMetrics)) {
+        double xp[5] = {x0v[0], x0v[1], x0v[2], x0v[3], x0v[4]};
+        if ((p.fused & kFuseAliasBug) && (p.fused & kFuseResetOnFail) && status == 4) { xp[3] = 0.0; xp[4] = 0.0; }
+        double xnew[5] = {xp[0], xp[1], xp[2], xp[3], xp[4]};
+        if (p.fused & kFusePlant) dyn_step<false>(xp, u_apply, dt, xnew, nullptr, nullptr);     // every lane, same value
+        if ((p.fused & kFusePlant) && lane == 0 && store && p.x0_rw) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) p.x0_rw[(size_t)inst * 5 + c] = xnew[c];
+        }
+        double margin = INFINITY;
+        if (p.obst && lane < NOBST) {                        // ground-truth motion of obstacle j = lane
+            const double *o = p.obst + ((size_t)inst * NOBST + lane) * 4;
+            double ox = o[0], oy = o[1], ovx = o[2], ovy = o[3];
+            if (p.fused & kFuseObstacles) {
+                if (p.noise) obstacle_noise(p.randomness, p.vmax, p.noise[((size_t)inst * NOBST + lane) * 2], p.noise[((size_t)inst * NOBST + lane) * 2 + 1], ovx, ovy);
+                obstacle_advance(p.world, dt, ox, ovx, oy, ovy);
+                if (store && p.obst_rw) { double *w = p.obst_rw + ((size_t)inst * NOBST + lane) * 4; w[0] = ox; w[1] = oy; w[2] = ovx; w[3] = ovy; }
+            }
+            const double ddx = xnew[0] - ox, ddy = xnew[1] - oy;
+            margin = sqrt(ddx * ddx + ddy * ddy) - p.r_hit;  // :222-228
+        }
+        if (p.fused & kFuseMetrics) {
+            margin = -seg_max<64>(-margin, lane);
+            if (lane == 0 && store) {
+                int fl = p.ep_flags[inst];
+                if (xnew[0] < p.world.xmin || xnew[0] > p.world.xmax || xnew[1] < p.world.ymin || xnew[1] > p.world.ymax) fl |= 2;   // :213-214
+                const double mm = fmin(p.ep_min_margin[inst], margin);
+                p.ep_min_margin[inst] = mm;
+                if (mm <= 0.0) fl |= 4;
+                const double gx_ = xnew[0] - gl[0], gy_ = xnew[1] - gl[1];
+                if (sqrt(gx_ * gx_ + gy_ * gy_) <= p.tol_goal) fl |= 1;      // :247-250: reached, the loop breaks before i += 1
+                else p.ep_steps[inst] += 1;
+                p.ep_flags[inst] = fl;
+            }
+        }
+    }
+    if (lane == 0 && p.u0 && store) { p.u0[(size_t)inst * 2] = u_apply[0]; p.u0[(size_t)inst * 2 + 1] = u_apply[1]; }
+    // NLP objective at the returned iterate: LS cost (the stage's owner) + exact penalty of the obstacle violation (the rows' lanes)
+    if (p.cost) {
+        double J = 0.0;
+        if (act) {
+            if (own) {
+                const double ex = xi[0] - gl[0], ey = xi[1] - gl[1];
+                if (has_u) J = 0.5 * (p.Wg[0] * ex * ex + p.Wg[1] * ey * ey + p.Wg[2] * xi[3] * xi[3] + p.Wg[3] * xi[4] * xi[4]
+                                      + p.Wg[4] * ui[0] * ui[0] + p.Wg[5] * ui[1] * ui[1]);
+                else J = 0.5 * (p.Weg[0] * ex * ex + p.Weg[1] * ey * ey + p.Weg[2] * xi[3] * xi[3] + p.Weg[3] * xi[4] * xi[4]);
+            }
+#pragma unroll
+            for (int s = 0; s < NSL; s++) if (s * LPS + h < NOBST) {
+                const double dx = xi[0] - pxy[s][0], dy = xi[1] - pxy[s][1];
+                const double hv = dx * dx + dy * dy - p.r2;
+                const double v = hv < 0 ? -hv : 0.0;
+                J += zpen * (v + 0.5 * v * v);
+            }
+        }
+        J = seg_sum<64>(J, lane);
+        if (lane == 0 && store) p.cost[inst] = J;
+    }
+    if (lane == 0 && store) {
+        if (p.iters_acc) p.iters_acc[inst] += it_done;
+        if (p.status_acc) p.status_acc[inst] += (status == 4 ? 1 : 0) + (status == 2 ? 65536 : 0);
+        if (p.status) p.status[inst] = status;
+        if (p.iters) p.iters[inst] = it_done;
+    }
+#ifdef MPC_PHASE_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+    MPC_TICK(14);
+    if (p.trace && lane == 0) { for (int k = 0; k < 16; k++) p.trace[((size_t)inst * p.iter_max) * 4 + k] = (double)tacc_[k]; }
+#endif
+}
+
+}  // namespace mpc

@@ -67,6 +67,8 @@ SYMBOLS = {
     "mpc_debug_trace": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "mpc_set_lanes_per_instance": (C.c_int, [_vp, C.c_int]),
     "mpc_get_lanes_per_instance": (C.c_int, [_vp, C.c_int]),
+    "mpc_set_lanes_per_stage": (C.c_int, [_vp, C.c_int]),
+    "mpc_get_lanes_per_stage": (C.c_int, [_vp, C.c_int]),
     "mpc_set_matrix_cores": (C.c_int, [_vp, C.c_int]),
     "mpc_set_row_parallel": (C.c_int, [_vp, C.c_int]),
     "mpc_generate_scenarios_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint, _vp, _vp, _vp]),

@@ -28,6 +28,9 @@ def _ptr(a):
 
 
 class BatchedMpc:
+    # lanes per horizon stage applied to every new handle (0 = automatic, see set_lanes_per_stage); a test / tuning hook
+    default_lanes_per_stage = 0
+
     def __init__(self, N=20, n_obst=3, Tf=2.0, max_batch=1, device=0, **cfg_overrides):
         self.cfg = _lib.default_config(N, n_obst, Tf, **cfg_overrides)
         self.N, self.n_obst, self.Tf = int(N), int(n_obst), float(Tf)
@@ -36,6 +39,8 @@ class BatchedMpc:
         self.device = int(device)
         self._h = C.c_void_p()
         _lib.check(_lib.lib().mpc_create(C.byref(self.cfg), self.device, self.max_batch, C.byref(self._h)))
+        if BatchedMpc.default_lanes_per_stage:
+            _lib.check(_lib.lib().mpc_set_lanes_per_stage(self._h, int(BatchedMpc.default_lanes_per_stage)))
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -194,3 +199,10 @@ class BatchedMpc:
 
     def lanes_per_instance(self, batch):
         return _lib.lib().mpc_get_lanes_per_instance(self._h, batch)
+
+    def set_lanes_per_stage(self, lanes):
+        """0 automatic (small batches: rows of a stage split over 2-3 lanes), 1 one lane per stage, 2 / 3 split mapping."""
+        _lib.check(_lib.lib().mpc_set_lanes_per_stage(self._h, int(lanes)))
+
+    def lanes_per_stage(self, batch):
+        return _lib.lib().mpc_get_lanes_per_stage(self._h, batch)

@@ -19,8 +19,10 @@ _lib.check(_lib.lib().mpc_debug_trace(loop.m._h, 1, B, None))
 for _ in range(10): loop.step()
 torch.cuda.synchronize()
 tr = np.zeros((B, 50, 4)); _lib.check(_lib.lib().mpc_debug_trace(loop.m._h, 1, B, tr.ctypes.data))
-t = tr.reshape(B, -1)[:, :10]
+t = tr.reshape(B, -1)[:, :16]
 names = ["mu/conv check", "predictor assemble", "factor sweep", "rollout (affine)", "affine step + sigma", "corrector rhs", "corrector sweep", "rollout", "combined step + update", "(row-parallel: stage operands -> LDS)"]
-tot = t.sum(1).mean(); it = loop.iters.double().mean().item()
+tot = t[:, :10].sum(1).mean(); it = loop.iters.double().mean().item()
 print(f"B={B} mean IPM iters {it:.2f}  total cycles/solve (IPM loop) {tot:.0f}  per iteration {tot/it:.0f}")
+for k, n in zip(range(10, 15), ["loads + look-ahead", "iterate loads", "linearise + W staging", "row state init", "tail (step, plant, stores)"]):
+    print(f"  outside the IPM loop: {n:28s} {t[:,k].mean():10.0f} cycles")
 for k, n in enumerate(names[:10]): print(f"  {n:24s} {t[:,k].mean():10.0f} cycles  {100*t[:,k].mean()/tot:5.1f}%   per iter {t[:,k].mean()/it:8.0f}")

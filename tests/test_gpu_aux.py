@@ -123,7 +123,7 @@ def test_fused_closed_loop_step_equals_kernel_sequence(env):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     z = lambda *s, dt=torch.float64: torch.zeros(*s, dtype=dt, device=dev)
     noise = torch.from_numpy(np.random.default_rng(0).normal(size=(12, B, no, 2))).to(dev)
-    for lanes in (64, 32):
+    for lanes in (64, 32, 0):       # 0: automatic = rows of a stage split over 3 lanes (batch 67)
         # torch ops (copy_) and the library's kernels must share ONE queue: an explicit, non-default torch stream
         with mpc_gpu.BatchedMpc(N, no, 2.0, max_batch=B) as s, torch.cuda.stream(torch.cuda.Stream(device=dev)):
             _lib.check(_lib.lib().mpc_set_lanes_per_instance(s._h, lanes))

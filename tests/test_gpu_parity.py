@@ -16,11 +16,16 @@ TOL_U = 1e-6 * 8.0
 TOL_LIN = 1e-12
 
 
-@pytest.fixture(scope="module")
-def env(built):
+@pytest.fixture(scope="module", params=["stage-split", "one-lane-per-stage"])
+def env(built, request):
+    """Every parity test runs on both lane mappings of the solve kernel: the automatic choice (these batches are small, so the
+    rows of a stage are split over 2-3 lanes wherever the horizon fits: rti_split_kernel) and one lane per stage
+    (rti_solve_kernel, what large batches use)."""
     import mpc_gpu
     from oracle import oracle as orc
-    return mpc_gpu, orc
+    mpc_gpu.BatchedMpc.default_lanes_per_stage = 0 if request.param == "stage-split" else 1
+    yield mpc_gpu, orc
+    mpc_gpu.BatchedMpc.default_lanes_per_stage = 0
 
 
 def run_pair(mpc_gpu, orc, N, no, Tf, x0, goal, obst, steps=1, X=None, U=None, resync=True, **cfgkw):
@@ -203,6 +208,7 @@ def test_lanes_per_instance_packing(env):
         for lanes in (0, 64, 32) + ((16,) if N + 2 <= 16 else ()):
             with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
                 _lib.check(_lib.lib().mpc_set_matrix_cores(s._h, 0))        # vector-ALU factorisation on every path: bitwise comparable
+                s.set_lanes_per_stage(1)
                 _lib.check(_lib.lib().mpc_set_lanes_per_instance(s._h, lanes))
                 got = s.lanes_per_instance(B)
                 s.reset_guess(x0); g = s.solve(x0, obst, goal); X, U = s.get_traj(B)
@@ -293,7 +299,10 @@ def test_horizon_extremes_and_packing_boundaries(env, N):
     P = oracle_P(orc, cfg, obst); Xg, Ug = oracle_guess(orc, cfg, x0)
     o = orc.rti_solve_batch(cfg, x0, P, goal, Xg, Ug)
     with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
-        assert s.lanes_per_instance(B) == (16 if N + 2 <= 16 else 32 if N + 2 <= 32 else 64)
+        if s.lanes_per_stage(B) == 1:
+            assert s.lanes_per_instance(B) == (16 if N + 2 <= 16 else 32 if N + 2 <= 32 else 64)
+        else:
+            assert s.lanes_per_stage(B) == (3 if N <= 20 else 2) and N <= 31 and s.lanes_per_instance(B) == 64
         s.reset_guess(x0); g = s.solve(x0, obst, goal); X, U = s.get_traj(B)
         s.shift(B); g2 = s.solve(x0, obst, goal)
     assert (g["status"] == o["status"]).all()
@@ -325,3 +334,62 @@ def test_longest_horizon_with_ten_obstacles_uses_more_than_64k_lds(env):
     assert (g["status"] == o["status"]).all()
     ok = o["status"] == 0
     assert ok.sum() >= B - 2 and np.abs(X - o["X"])[ok].max() < 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,no,B", [(20, 3, 300), (20, 5, 100), (20, 10, 60), (10, 5, 130), (31, 3, 50), (25, 10, 40), (2, 3, 33)])
+def test_stage_split_matches_one_lane_per_stage_and_oracle(env, N, no, B):
+    """rows of a stage dealt out to 3 / 2 lanes (rti_split_kernel) vs one lane per stage (rti_solve_kernel) vs the oracle:
+    same statuses and iteration counts, iterates equal to rounding; explicit P and on-device look-ahead; two control steps"""
+    mpc_gpu, orc = env
+    x0, goal, obst = random_batch(B, no, seed=500 + N + no)
+    cfg = orc.config(N, no, 0.1 * N)
+    P = oracle_P(orc, cfg, obst); Xg, Ug = oracle_guess(orc, cfg, x0)
+    o = orc.rti_solve_batch(cfg, x0, P, goal, Xg, Ug)
+    out = {}
+    for lps in (1, 2, 3) if N <= 20 else (1, 2):
+        with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
+            s.set_lanes_per_stage(lps)
+            assert s.lanes_per_stage(B) == lps
+            s.reset_guess(x0); g = s.solve(x0, obst, goal); X, U = s.get_traj(B)          # look-ahead in the kernel
+            s.shift(B); g2 = s.solve(x0, P, goal); X2, U2 = s.get_traj(B)                # explicit P, warm start with defects
+            out[lps] = (g, X, U, g2, X2, U2)
+    ok = o["status"] == 0
+    assert ok.mean() > 0.85
+    for lps in out:
+        g, X, U, g2, X2, U2 = out[lps]
+        assert (g["status"] == o["status"]).all()
+        assert (g["iters"][ok] == o["iters"][ok]).mean() > 0.95
+        tol = 1e-6 if N <= 20 else 5e-5           # longer horizons: an ill-conditioned instance or two sit at 1e-6 on either mapping
+        d = np.abs(X - o["X"]).reshape(B, -1).max(1)[ok]; dU = np.abs(U - o["U"]).reshape(B, -1).max(1)[ok]
+        # an ill-conditioned QP or two per batch (10 obstacles, long horizons) sit at the float64 floor of the interior point
+        # on EVERY mapping (DESIGN.md section 2): at most 2 instances may exceed the tolerance, and then by less than 1e-3
+        assert (d > tol).sum() <= (2 if no == 10 else 0) and d.max() < 1e-3 and np.quantile(d, 0.9) < 1e-8 and (dU > 8 * tol).sum() <= (2 if no == 10 else 0)
+        rel = np.abs(g["cost"] - o["cost"])[ok] / np.maximum(1.0, np.abs(o["cost"][ok]))
+        assert np.sort(rel)[-3 if no == 10 else -1] < (1e-8 if N <= 20 else 1e-6)
+        if lps > 1:
+            ref = out[1]
+            both = ok & (g2["status"] == 0) & (ref[3]["status"] == 0)
+            assert (g["status"] == ref[0]["status"]).all() and (g2["status"] == ref[3]["status"]).mean() > 0.97
+            d1 = np.abs(X - ref[1]).reshape(B, -1).max(1)[ok]; d2 = np.abs(X2 - ref[4]).reshape(B, -1).max(1)[both]
+            assert np.median(d1) < 1e-11 and np.sort(d1)[-3] < 10 * tol and np.median(d2) < 1e-10 and np.quantile(d2, 0.95) < 1e-6
+
+
+@pytest.mark.gpu
+def test_stage_split_is_the_automatic_choice_for_small_batches_only(env):
+    mpc_gpu, orc = env
+    mpc_gpu.BatchedMpc.default_lanes_per_stage, keep = 0, mpc_gpu.BatchedMpc.default_lanes_per_stage
+    try:
+        with mpc_gpu.BatchedMpc(20, 3, 2.0, max_batch=70000) as s:
+            assert s.lanes_per_stage(1) == 3 and s.lanes_per_stage(1024) == 3 and s.lanes_per_instance(1024) == 64
+            assert s.lanes_per_stage(1025) == 1 and s.lanes_per_instance(65536) == 32
+            s.set_lanes_per_instance(64)
+            assert s.lanes_per_stage(8) == 1
+        with mpc_gpu.BatchedMpc(31, 3, 3.1, max_batch=8) as s:
+            assert s.lanes_per_stage(8) == 2
+        with mpc_gpu.BatchedMpc(32, 3, 3.2, max_batch=8) as s:
+            assert s.lanes_per_stage(8) == 1
+            from mpc_gpu import _lib
+            assert _lib.lib().mpc_set_lanes_per_stage(s._h, 2) == _lib.MPC_ERR_ARG
+    finally:
+        mpc_gpu.BatchedMpc.default_lanes_per_stage = keep
