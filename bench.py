@@ -44,11 +44,14 @@ def algorithmic_bytes_per_solve(N, n_obst, fused=True):
     return 8 * (rd + wr) + 8
 
 
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_split_pmc_summary.json")   # rocprofv3 passes of this very command (scripts/profile_passes.sh)
+
+
 def measured_valu_instructions(kernel_name, batch):
     """VALU wave-instructions per launch of the solve kernel from the committed PMC summary (SQ_INSTS_VALU); None if it is for
     another kernel variant or batch."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_summary.json")))
+        d = json.load(open(PMC_SUMMARY))
         if d["batch"] != batch or kernel_name.replace(" ", "") not in d["kernel"].replace(" ", ""):
             return None
         return d["counters"]["SQ_INSTS_VALU"]["mean_per_launch"]
@@ -57,10 +60,10 @@ def measured_valu_instructions(kernel_name, batch):
 
 
 def measured_traffic(kernel_name, batch):
-    """HBM bytes per launch of the solve kernel from the committed rocprofv3 PMC passes (profiles/r01_final_pmc_summary.json,
-    collected with the command recorded there); None when the summary is for another kernel variant or batch."""
+    """HBM bytes per launch of the solve kernel from the committed rocprofv3 PMC passes (PMC_SUMMARY, collected with the
+    command recorded there); None when the summary is for another kernel variant or batch."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_summary.json")))
+        d = json.load(open(PMC_SUMMARY))
         if d["batch"] != batch or kernel_name.replace(" ", "") not in d["kernel"].replace(" ", ""):
             return None
         t = d["hbm_traffic_bytes_per_launch"]
@@ -268,25 +271,26 @@ def main():
     mean_iters = float(it_acc.double().sum().item()) / (batch * args.steps)
     avg_kernel_s = kern_ms / max(1, launches) * 1e-3
     abytes = algorithmic_bytes_per_solve(N, no, fused=True) * batch
-    lanes = loop.m.lanes_per_instance(batch)
-    kname = f"rti_solve_kernel<{no}, {lanes}, 2>"       # <n_obst, lanes per instance, row-parallel sweeps>
+    lanes, lps = loop.m.lanes_per_instance(batch), loop.m.lanes_per_stage(batch)
+    # <n_obst, lanes per instance, row-parallel sweeps> / small batches: <n_obst, lanes per stage> (one instance per wavefront)
+    kname = f"rti_solve_kernel<{no}, {lanes}, 2>" if lps == 1 else f"rti_split_kernel<{no}, {lps}>"
     roof = {"bound": "hbm", "achieved": abytes / avg_kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": abytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic(kname, batch),
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_final_pmc_summary.json (FETCH_SIZE uncorrected: 8-byte-per-lane loads, see DESIGN.md section 5)",
+            "traffic_source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/{os.path.basename(PMC_SUMMARY)} (FETCH_SIZE uncorrected: 8-byte-per-lane loads, see DESIGN.md section 5)",
             "kernel": kname, "avg_launch_us": avg_kernel_s * 1e6, "launches": launches,
             "algorithmic_bytes_per_launch": abytes,
             "fp64_valu": {"achieved": algorithmic_flops_per_solve(N, no, mean_iters) * batch / avg_kernel_s / 1e12,
                           "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                           "frac": algorithmic_flops_per_solve(N, no, mean_iters) * batch / avg_kernel_s / 1e12 / FP64_VALU_PEAK_TF,
-                          "note": "the path is bound by the ISSUE of a serial FP64 instruction stream (PMC: 33k VALU instructions per solve, VALU active 55% of wave cycles, 24% parked on LDS waits; the stage recursions keep 8 or fewer lanes of 64 busy), not by HBM or by the FP64 flop peak (DESIGN.md section 5); SURVEY 8(d) flop model x measured mean IPM iterations"}}
+                          "note": "the path is bound by the ISSUE of a serial FP64 instruction stream per wavefront (the stage recursions keep 8 or fewer lanes of 64 busy), not by HBM or by the FP64 flop peak (DESIGN.md section 5); SURVEY 8(d) flop model x measured mean IPM iterations"}}
     # the roof that actually binds: vector-instruction issue slots (one wave-instruction per 4 cycles per SIMD, 4 SIMDs x 256 CUs)
     n_valu = measured_valu_instructions(kname, batch)
     if n_valu is not None:
         peak = 1024 * 2.4e9 / 4
         roof["valu_issue"] = {"achieved": n_valu / avg_kernel_s / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
                               "frac": n_valu / avg_kernel_s / peak,
-                              "note": "SQ_INSTS_VALU per launch (profiles/r01_final_pmc_summary.json) / measured launch time; at batch 1024 only "
-                                      "512 of the 1024 SIMDs hold a wavefront, so 0.5 is the ceiling of this fraction for C2"}
+                              "note": f"SQ_INSTS_VALU per launch (profiles/{os.path.basename(PMC_SUMMARY)}) / measured launch time; one wavefront per "
+                                      "SIMD (512-register kernel), so a wavefront's own dependent instruction stream sets the rate"}
     out = {"metric": "MPC solves/sec (N=20, 3 obstacles)", "value": value, "unit": "solves/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -295,7 +299,7 @@ def main():
                       "parallelism": f"replicas x{world}, cost all-gather (RCCL)" if world > 1 else "single GPU"},
            "mean_ipm_iters": mean_iters, "qp_failure_frac": float((st_acc % 65536).double().sum().item()) / (batch * args.steps),
            "qp_iter_cap_frac": float((st_acc // 65536).double().sum().item()) / (batch * args.steps),
-           "lanes_per_instance": loop.m.lanes_per_instance(batch), "roofline": roof}
+           "lanes_per_instance": lanes, "lanes_per_stage": lps, "roofline": roof}
 
     if rank == 0 and world == 1 and not args.no_extra and args.workload == "c2":
         # supplementary: the large-batch configuration (configs[2]) on the same GPU

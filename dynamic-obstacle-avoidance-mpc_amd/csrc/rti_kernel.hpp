@@ -412,8 +412,9 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const RowLds L, b
     const double d5 = (j == 5) ? 1.0 : 0.0;     // row 5 of W~ is e_5'
     // Results overlay rows 0, 1 of the consumed H~aug_t: K~[0][j] at [j], K~[1][j] at [8 + j], 1/d0, l, 1/d1 at [6], [7], [14].
     // Stores are unconditional: lanes with nothing to store write into dead parts of the same block ([16..63]).
-    double *k0p = L.H + (store ? j : 48), *k1p = L.H + (store ? 8 + j : 49);
-    double *f0p = L.H + (store0 ? 6 : 50), *f1p = L.H + (store0 ? 7 : 50), *f2p = L.H + (store0 ? 14 : 50);
+    // (two per-lane pointers, the rest are immediate offsets: K~[1][j] is 8 words behind K~[0][j], 1/d1 8 words behind 1/d0, and the
+    // dead words an idle lane hits instead -- 48, 56 resp. 50, 51, 58 -- lie in rows 6, 7 of the block, consumed one stage earlier)
+    double *kp = L.H + (store ? j : 48), *fp = L.H + (store0 ? 6 : 50);
     const double *wp = L.W + j, *hp = L.H + j;
     auto fetch = [&](int t, double Wc[5], double Hc[8]) {
 #pragma unroll
@@ -522,8 +523,8 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const RowLds L, b
               "=&v"(K0), "=&v"(K1), "=&v"(i00), "=&v"(l), "=&v"(i11), "=&v"(m66), "=&v"(m67), "=&v"(m77), "=&v"(e_), "=&v"(r_)
             : "v"(Wc[0]), "v"(Wc[1]), "v"(Wc[2]), "v"(Wc[3]), "v"(Wc[4]), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]), "v"(T[4]));
         M[5] += T[5];                                                  // r = 5 term of W~' T
-        k0p[HS * t] = K0; k1p[HS * t] = K1;
-        f0p[HS * t] = i00; f1p[HS * t] = l; f2p[HS * t] = i11;
+        kp[HS * t] = K0; kp[HS * t + 8] = K1;
+        fp[HS * t] = i00; fp[HS * t + 1] = l; fp[HS * t + 8] = i11;
         // P~+ = M~[0..5][0..5] + M~[0..5][u] K~   (M~[i][6] = M~[6][i] is lane i's register 6)
         asm volatile(
             "s_nop 4\n"

@@ -12,9 +12,10 @@
 //     obstacle rows: ceil(NOBST / LPS) pairs per lane (obstacle j = slot * LPS + part),
 // so the row phases shrink by the factor LPS and the per-lane row state by as much (no AGPR round trips).  What the parts of
 // a stage have to add up -- the barrier terms of the reduced Hessian and the gradients of the two Newton right-hand sides --
-// goes through a small LDS mailbox twice per interior-point iteration; the sums are formed in a fixed order by every lane of
-// the stage, so the result is deterministic and identical in the LPS lanes.  Everything a lane needs of the stage's Newton
-// step it reads from the stage's LDS block (same address in the LPS lanes: a broadcast).
+// travels to the stage's first lane (the "owner", which stages the stage's blocks in LDS) by one-lane DPP wave shifts
+// (v_mov_b32_dpp wave_shl:1, once for the neighbour's value and twice for the next lane's) twice per interior-point iteration;
+// the sums are formed in a fixed order, so the result is deterministic.  Everything a lane needs of the stage's Newton step it
+// reads from the stage's LDS block (same address in the LPS lanes: a broadcast).
 #pragma once
 #include "rti_kernel.hpp"
 #include <type_traits>
@@ -25,11 +26,7 @@ template <int LPS, int NOBST>
 struct SplitLds {
     static constexpr int NBL = 6 / LPS;                       // box variables per lane
     static constexpr int NSL = (NOBST + LPS - 1) / LPS;       // obstacle row pairs per lane
-    static constexpr int MBL = 2 * NBL + 5;                   // mailbox doubles per lane: (H diagonal, gradient) per box variable, sxx, syy, sxy, sgx, sgy
-    static constexpr int MBS = LPS * MBL;                     // ... per stage
-    static constexpr int STAGES = 64 / LPS + 1;               // every lane has a mailbox of its own (lanes past the horizon write dead words)
-    static __host__ __device__ constexpr int mailbox() { return STAGES * MBS; }
-    static __host__ __device__ constexpr int total(int N, bool lookahead) { return RowLds::total(N, 1) + mailbox() + (lookahead ? (N + 1) * NOBST * 2 : 0); }
+    static __host__ __device__ constexpr int total(int N, bool lookahead) { return RowLds::total(N, 1) + (lookahead ? (N + 1) * NOBST * 2 : 0); }
 };
 
 template <int K>
@@ -44,7 +41,8 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
 {
     static_assert(LPS == 2 || LPS == 3, "two or three lanes per horizon stage");
     using SL = SplitLds<LPS, NOBST>;
-    constexpr int NBL = SL::NBL, NSL = SL::NSL, MBL = SL::MBL, MBS = SL::MBS;
+    constexpr int NBL = SL::NBL, NSL = SL::NSL;
+    constexpr int kKK = 45;                   // free words 45, 46 of a stage block (RowVec uses 0..44, dead-store words start at RowLds::TAIL)
     const int lane = threadIdx.x;
     const int inst = blockIdx.x;              // grid = batch: one instance per wavefront
     const int N = p.N;
@@ -89,10 +87,10 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
     const bool ep_done = (p.fused & kFuseMetrics) && p.ep_flags && (p.ep_flags[inst] & 1);
     extern __shared__ double lds_raw[];
     const RowLds RL(lds_raw + RowLds::pad_front(N), N);
-    double *MB = lds_raw + RowLds::total(N, 1);
-    double *lds_P = MB + SL::mailbox();
-    double *MBw = MB + i * MBS + h * MBL;     // this lane's mailbox
-    const double *MBr = MB + i * MBS;         // the mailboxes of this lane's stage
+    double *lds_P = lds_raw + RowLds::total(N, 1);
+    // what part q of this lane's stage holds in the variable v: from_right shifts the whole wavefront by one lane, so the owner
+    // (part 0) sees its neighbours' values; only the owner's result is meaningful
+    auto of_part = [&](double v, int q) { return q == 0 ? v : (q == 1 ? from_right(v) : from_right(from_right(v))); };
     // obstacle positions of this lane's obstacle rows at its stage: explicit P (parameterize_model, robot_ocp_problem.py:154-166)
     // or the look-ahead computed here (Obstacle.predict_trajectory, src/utils/visualization.py:62-79)
     double pxy[NSL][2];
@@ -272,6 +270,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
         // ---- predictor (sigma = 0): this lane's share of the local gradient, the barrier terms and the reduced Hessian ----
         double rdl[NBL], rdh[NBL];                  // residuals r_d = rho(z) - t of the box rows
         struct SoftT { double w1, w2, rD, be1, be2, rs, rd1, rd2; } so[NSL];
+        double hdiag_[NBL], g_[NBL], ssum[5];       // this lane's share: per box variable (H diagonal, gradient); sxx, syy, sxy, sgx, sgy
         {
 #pragma unroll
             for (int s = 0; s < NBL; s++) {
@@ -285,7 +284,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
                     g += lh[s] - ll[s];                                     // - C'lam
                     g += bl - bh;                                           // sum_c c beta_c
                 }
-                MBw[2 * s] = hdiag; MBw[2 * s + 1] = g;
+                hdiag_[s] = hdiag; g_[s] = g;
             }
             double sxx = 0.0, syy = 0.0, sxy = 0.0, glx = 0.0, gly = 0.0, cbx = 0.0, cby = 0.0;
 #pragma unroll
@@ -316,23 +315,22 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
                     cbx += geff * ax[s]; cby += geff * ay[s];
                 }
             }
-            MBw[2 * NBL] = sxx; MBw[2 * NBL + 1] = syy; MBw[2 * NBL + 2] = sxy; MBw[2 * NBL + 3] = glx + cbx; MBw[2 * NBL + 4] = gly + cby;
+            ssum[0] = sxx; ssum[1] = syy; ssum[2] = sxy; ssum[3] = glx + cbx; ssum[4] = gly + cby;
         }
         MPC_TICK(1);
-        __syncthreads();
         double bbr[5], x_init[5];
 #pragma unroll
         for (int c = 0; c < 5; c++) { bbr[c] = rhoPi * bb[c]; x_init[c] = rhoPi * d0[c]; }
-        {   // the stage's sums, in a fixed order (identical in the LPS lanes of the stage)
-            double Hk[6], gk[6];
+        {   // the stage's values and sums in the owner lane, in a fixed order
+            double Hk[6], gk[6], Ssum[5];
 #pragma unroll
-            for (int k = 0; k < 6; k++) { Hk[k] = MBr[(k / NBL) * MBL + 2 * (k % NBL)]; gk[k] = MBr[(k / NBL) * MBL + 2 * (k % NBL) + 1]; }
-            double Sxx = MBr[2 * NBL], Syy = MBr[2 * NBL + 1], Sxy = MBr[2 * NBL + 2], Sgx = MBr[2 * NBL + 3], Sgy = MBr[2 * NBL + 4];
+            for (int q = 0; q < LPS; q++) {
 #pragma unroll
-            for (int q = 1; q < LPS; q++) {
-                Sxx += MBr[q * MBL + 2 * NBL]; Syy += MBr[q * MBL + 2 * NBL + 1]; Sxy += MBr[q * MBL + 2 * NBL + 2];
-                Sgx += MBr[q * MBL + 2 * NBL + 3]; Sgy += MBr[q * MBL + 2 * NBL + 4];
+                for (int s = 0; s < NBL; s++) { Hk[q * NBL + s] = of_part(hdiag_[s], q); gk[q * NBL + s] = of_part(g_[s], q); }
+#pragma unroll
+                for (int e = 0; e < 5; e++) { const double v = of_part(ssum[e], q); Ssum[e] = q == 0 ? v : Ssum[e] + v; }
             }
+            const double Sxx = Ssum[0], Syy = Ssum[1], Sxy = Ssum[2], Sgx = Ssum[3], Sgy = Ssum[4];
             if (own && act) {   // H~aug_t, dense 8 x 8, z~ order (x0..x4, 1, ua, ual); affine column of W~_t
                 const double hxx = Hk[2] + Sxx, hyy = Hk[3] + Syy;
                 const double gxs[5] = {gk[2] + Sgx, gk[3] + Sgy, hd_psi * z[4], gk[4], gk[5]};
@@ -464,12 +462,13 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
         MPC_TICK(4);
 
         // ---- corrector: homogeneous system for the change of right-hand side, d beta_c = (dlam_aff dt_aff - sigma mu) / t ----
-        double gc[7];
+        double gc[7];       // assembled in the owner lane only
         {
+            double gcs[NBL];
 #pragma unroll
             for (int s = 0; s < NBL; s++) {
                 const double dbl = (ppl[s] - smu) * rtl[s], dbh = (pph[s] - smu) * rth[s];
-                MBw[s] = bp[s] ? dbl - dbh : 0.0;
+                gcs[s] = bp[s] ? dbl - dbh : 0.0;
             }
             double sgx = 0.0, sgy = 0.0;
 #pragma unroll
@@ -483,16 +482,17 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
                 } else geff = db1;
                 sgx += geff * ax[s]; sgy += geff * ay[s];
             }
-            MBw[NBL] = sgx; MBw[NBL + 1] = sgy;
             MPC_TICK(5);
-            __syncthreads();
             const int zidx[6] = {0, 1, 2, 3, 5, 6};
             gc[4] = 0.0;
+            double Sgx = 0.0, Sgy = 0.0;
 #pragma unroll
-            for (int k = 0; k < 6; k++) gc[zidx[k]] = MBr[(k / NBL) * MBL + (k % NBL)];
-            double Sgx = MBr[NBL], Sgy = MBr[NBL + 1];
+            for (int q = 0; q < LPS; q++) {
 #pragma unroll
-            for (int q = 1; q < LPS; q++) { Sgx += MBr[q * MBL + NBL]; Sgy += MBr[q * MBL + NBL + 1]; }
+                for (int s = 0; s < NBL; s++) gc[zidx[q * NBL + s]] = of_part(gcs[s], q);
+                const double vx = of_part(sgx, q), vy = of_part(sgy, q);
+                Sgx = q == 0 ? vx : Sgx + vx; Sgy = q == 0 ? vy : Sgy + vy;
+            }
             gc[2] += Sgx; gc[3] += Sgy;
             if (own && act) {   // c~_t = gc_x + K' gc_u  (K = 0 in the terminal lane)
                 double *cc = RL.H + RowLds::HS * i + RowVec::CT;
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
             __syncthreads();
             rowpar_vector<false>(lane, N, RL, lane < 16);
             __syncthreads();
-            if (has_u) {        // feed-forward of the corrector right-hand side: k = -Muu^-1 (gc_u + B' p_{t+1})
+            if (has_u) {        // feed-forward of the corrector right-hand side: k = -Muu^-1 (gc_u + B' p_{t+1}); owner lane (it has gc)
                 const double *pp = RL.H + RowLds::HS * (i + 1) + RowVec::P;
                 const double pv[5] = {pp[0], pp[1], pp[2], pp[3], pp[4]};
                 const double m0 = gc[0] + S.dua(pv), m1 = gc[1] + S.dual(pv);
@@ -511,10 +511,11 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
             }
         }
         MPC_TICK(6);
-        if (own && has_u) {     // homogeneous dynamics: c_t = B k
+        if (own && has_u) {     // homogeneous dynamics: c_t = B k; k itself for the other parts of the stage
             double *cc = RL.H + RowLds::HS * i + RowVec::ACL + 5;
             cc[0 * RowVec::RS] = S.b00 * F.k0 + S.b01 * F.k1; cc[1 * RowVec::RS] = S.b10 * F.k0 + S.b11 * F.k1;
             cc[2 * RowVec::RS] = h2 * F.k1; cc[3 * RowVec::RS] = dt * F.k0; cc[4 * RowVec::RS] = dt * F.k1;
+            RL.H[RowLds::HS * i + kKK] = F.k0; RL.H[RowLds::HS * i + kKK + 1] = F.k1;
         }
         if (lane == 0) {
 #pragma unroll
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
         double dz[7] = {0, 0, 0, 0, 0, 0, 0};
         if (act) {
             const double *xx = RL.H + RowLds::HS * i + RowVec::X;
-            double u0 = F.k0, u1 = F.k1;
+            double u0 = has_u ? RL.H[RowLds::HS * i + kKK] : 0.0, u1 = has_u ? RL.H[RowLds::HS * i + kKK + 1] : 0.0;
 #pragma unroll
             for (int c = 0; c < 5; c++) { dz[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }
             dz[0] = u0; dz[1] = u1;

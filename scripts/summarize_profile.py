@@ -11,14 +11,14 @@ if stats:
     rows = list(csv.DictReader(open(stats[0])))
     with open(os.path.join(root, f"{tag}_kernel_stats.csv"), "w") as f:
         f.write(open(stats[0]).read())
-    k = max((r for r in rows if "rti_solve_kernel" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]), default=None)
+    k = max((r for r in rows if "rti_solve_kernel" in r["Name"] or "rti_split_kernel" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]), default=None)
     if k:
         summary["kernel"] = k["Name"]
         summary["kernel_stats"] = {"calls": int(k["Calls"]), "avg_ns": float(k["AverageNs"]), "percentage": float(k["Percentage"])}
 for f in sorted(glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
     acc = {}
     for r in csv.DictReader(open(f)):
-        if "rti_solve_kernel" not in r.get("Kernel_Name", ""):
+        if "rti_solve_kernel" not in r.get("Kernel_Name", "") and "rti_split_kernel" not in r.get("Kernel_Name", ""):
             continue
         if summary["kernel"] and r["Kernel_Name"] != summary["kernel"]:
             continue
