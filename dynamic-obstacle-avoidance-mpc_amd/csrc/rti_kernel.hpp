@@ -630,6 +630,180 @@ __device__ __forceinline__ void rowpar_vector(int lane, int N, const RowLds L, b
     }
 }
 
+// HAND-SCHEDULED VARIANT of rowpar_vector (same arithmetic, same LDS layout, same results bit for bit).  For a lone wavefront an
+// FP64 instruction issues every 5 cycles (a dependent one after 8.4) but an LDS instruction costs ~14 whatever its width
+// (scripts/bin_src/lds_issue_test.hip), so the four LDS instructions of a stage weigh as much as its eight VALU instructions.
+// Here ONE set of operand requests serves TWO stages: the travelling vector alternates between the halves of the DPP row --
+//   even step: source = lanes 0..4 of B (row_newbcast:k),   accumulator A in lanes 8..12, whose own registers hold the even stage's rows,
+//   odd step:  source = lanes 8..12 of A (row_newbcast:8+k), accumulator B in lanes 0..4,  whose registers hold the odd stage's rows --
+// and one store writes both results (the halves merged by two masked v_mov_b32_dpp).  The whole sweep is one asm block: a ring of two
+// operand sets in fixed registers (ds_read2_b64 needs register tuples whose halves are used separately, which asm operands cannot
+// express), requested one pair ahead and placed into the bubbles of the dependent FMA chain; s_waitcnt lgkmcnt(1) at the head of a pair
+// (only the previous pair's store is younger than its operands).  The compiler never sees a register with a load in flight: the block
+// drains the LDS queue before it ends.  Four stages per loop pass; the leading N mod 4 stages run through the plain path; the adjoint
+// sweep also computes p_0 (unused) so that both directions take N steps.
+#define MPC_VEC_ASM_FWD \
+        "v_mov_b64_e32 v[230:231], %0\n" \
+        "ds_read2_b64 v[180:183], %1 offset0:0 offset1:1\n" \
+        "ds_read2_b64 v[184:187], %1 offset0:2 offset1:3\n" \
+        "ds_read2_b64 v[188:191], %1 offset0:4 offset1:5\n" \
+        "v_add_u32_e32 %1, 0x410, %1\n" \
+        "s_waitcnt lgkmcnt(0)\n" \
+        "1:\n" \
+        "s_waitcnt lgkmcnt(1)\n" \
+        "v_mov_b64_e32 v[228:229], v[190:191]\n" \
+        "ds_read2_b64 v[192:195], %1 offset0:0 offset1:1\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[180:181] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "ds_read2_b64 v[196:199], %1 offset0:2 offset1:3\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[182:183] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "ds_read2_b64 v[200:203], %1 offset0:4 offset1:5\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[184:185] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_add_u32_e32 %1, 0x410, %1\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[186:187] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[188:189] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_e32 v[230:231], v[190:191]\n" \
+        "s_nop 0\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[180:181] row_newbcast:8 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[182:183] row_newbcast:9 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[184:185] row_newbcast:10 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[186:187] row_newbcast:11 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[188:189] row_newbcast:12 row_mask:0xf bank_mask:0xf\n" \
+        "s_nop 1\n" \
+        "v_mov_b32_dpp v228, v230 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3\n" \
+        "v_mov_b32_dpp v229, v231 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3\n" \
+        "ds_write_b64 %2, v[228:229]\n" \
+        "v_add_u32_e32 %2, 0x410, %2\n" \
+        "s_waitcnt lgkmcnt(1)\n" \
+        "v_mov_b64_e32 v[228:229], v[202:203]\n" \
+        "ds_read2_b64 v[180:183], %1 offset0:0 offset1:1\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[192:193] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "ds_read2_b64 v[184:187], %1 offset0:2 offset1:3\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[194:195] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "ds_read2_b64 v[188:191], %1 offset0:4 offset1:5\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[196:197] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_add_u32_e32 %1, 0x410, %1\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[198:199] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[200:201] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_e32 v[230:231], v[202:203]\n" \
+        "s_nop 0\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[192:193] row_newbcast:8 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[194:195] row_newbcast:9 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[196:197] row_newbcast:10 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[198:199] row_newbcast:11 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[200:201] row_newbcast:12 row_mask:0xf bank_mask:0xf\n" \
+        "s_nop 1\n" \
+        "v_mov_b32_dpp v228, v230 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3\n" \
+        "v_mov_b32_dpp v229, v231 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3\n" \
+        "ds_write_b64 %2, v[228:229]\n" \
+        "v_add_u32_e32 %2, 0x410, %2\n" \
+        "s_sub_u32 %3, %3, 1\n" \
+        "s_cmp_lg_u32 %3, 0\n" \
+        "s_cbranch_scc1 1b\n" \
+        "s_waitcnt lgkmcnt(0)\n"
+
+#define MPC_VEC_ASM_BWD \
+        "v_mov_b64_e32 v[230:231], %0\n" \
+        "ds_read2_b64 v[180:183], %1 offset0:0 offset1:6\n" \
+        "ds_read2_b64 v[184:187], %1 offset0:12 offset1:18\n" \
+        "ds_read2_b64 v[188:191], %1 offset0:24 offset1:30\n" \
+        "v_add_u32_e32 %1, 0xfffffbf0, %1\n" \
+        "s_waitcnt lgkmcnt(0)\n" \
+        "1:\n" \
+        "s_waitcnt lgkmcnt(1)\n" \
+        "v_mov_b64_e32 v[228:229], v[190:191]\n" \
+        "ds_read2_b64 v[192:195], %1 offset0:0 offset1:6\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[180:181] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "ds_read2_b64 v[196:199], %1 offset0:12 offset1:18\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[182:183] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "ds_read2_b64 v[200:203], %1 offset0:24 offset1:30\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[184:185] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_add_u32_e32 %1, 0xfffffbf0, %1\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[186:187] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[188:189] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_e32 v[230:231], v[190:191]\n" \
+        "s_nop 0\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[180:181] row_newbcast:8 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[182:183] row_newbcast:9 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[184:185] row_newbcast:10 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[186:187] row_newbcast:11 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[188:189] row_newbcast:12 row_mask:0xf bank_mask:0xf\n" \
+        "s_nop 1\n" \
+        "v_mov_b32_dpp v228, v230 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3\n" \
+        "v_mov_b32_dpp v229, v231 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3\n" \
+        "ds_write_b64 %2, v[228:229]\n" \
+        "v_add_u32_e32 %2, 0xfffffbf0, %2\n" \
+        "s_waitcnt lgkmcnt(1)\n" \
+        "v_mov_b64_e32 v[228:229], v[202:203]\n" \
+        "ds_read2_b64 v[180:183], %1 offset0:0 offset1:6\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[192:193] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "ds_read2_b64 v[184:187], %1 offset0:12 offset1:18\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[194:195] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "ds_read2_b64 v[188:191], %1 offset0:24 offset1:30\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[196:197] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_add_u32_e32 %1, 0xfffffbf0, %1\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[198:199] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[228:229], v[230:231], v[200:201] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_e32 v[230:231], v[202:203]\n" \
+        "s_nop 0\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[192:193] row_newbcast:8 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[194:195] row_newbcast:9 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[196:197] row_newbcast:10 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[198:199] row_newbcast:11 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[230:231], v[228:229], v[200:201] row_newbcast:12 row_mask:0xf bank_mask:0xf\n" \
+        "s_nop 1\n" \
+        "v_mov_b32_dpp v228, v230 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3\n" \
+        "v_mov_b32_dpp v229, v231 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3\n" \
+        "ds_write_b64 %2, v[228:229]\n" \
+        "v_add_u32_e32 %2, 0xfffffbf0, %2\n" \
+        "s_sub_u32 %3, %3, 1\n" \
+        "s_cmp_lg_u32 %3, 0\n" \
+        "s_cbranch_scc1 1b\n" \
+        "s_waitcnt lgkmcnt(0)\n"
+
+#define MPC_VEC_ASM_CLOBBERS "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v228", "v229", "v230", "v231", "scc", "memory"
+
+__device__ __forceinline__ uint32_t lds_address(const void *p) { return (uint32_t)(uintptr_t)p; }     // low half of a flat LDS address = LDS byte offset
+
+template <bool FWD>
+__device__ __forceinline__ void rowpar_vector_fast(int lane, int N, const RowLds L, bool worker_row)
+{
+    constexpr int HS = RowLds::HS, SS = FWD ? HS : -HS;
+    const int r = lane & 7, rc = r < 5 ? r : 0;
+    const bool store = worker_row && r < 5;
+    double v = FWD ? L.H[RowVec::X + r] : L.H[HS * N + RowVec::CT + r];
+    if (!FWD && worker_row && (lane & 15) < 5) L.H[HS * N + RowVec::P + r] = v;
+    // block of the first stage step: its operands (src) and the place of the vector it produces (dst)
+    const double *src = L.H + (FWD ? 0 : HS * (N - 1)) + RowVec::ACL + (FWD ? rc * RowVec::RS : rc);
+    double *dst = L.H + (FWD ? HS : HS * (N - 1));
+    for (int q = 0; q < (N & 3); q++) {        // leading N mod 4 stages, every lane with r = lane & 7 (both halves of the row hold the vector)
+        double a[5], cc, acc;
+#pragma unroll
+        for (int k = 0; k < 5; k++) a[k] = src[FWD ? k : k * RowVec::RS];
+        cc = src[FWD ? 5 : RowVec::CT];
+        asm volatile(
+                "s_nop 1\n"
+                "v_mov_b64_e32 %0, %2\n"
+                "v_fmac_f64_dpp %0, %1, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f64_dpp %0, %1, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f64_dpp %0, %1, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f64_dpp %0, %1, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+                "v_fmac_f64_dpp %0, %1, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+                : "=&v"(acc) : "v"(v), "v"(cc), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]));
+        v = acc;
+        dst[(worker_row && (lane & 15) < 5) ? (FWD ? RowVec::X : RowVec::P) + r : RowLds::TAIL] = v;
+        src += SS; dst += SS;
+    }
+    int passes = N >> 2;
+    if (passes > 0) {
+        // lanes 8..15 of a row take the first stage of a pair, lanes 0..7 the second one
+        const bool first = (lane & 8) != 0;
+        uint32_t ra = lds_address(src + (first ? 0 : SS));
+        uint32_t rd = lds_address(dst + (first ? 0 : SS) + (store ? (FWD ? RowVec::X : RowVec::P) + r : RowLds::TAIL));
+        if (FWD) asm volatile(MPC_VEC_ASM_FWD : "+v"(v), "+v"(ra), "+v"(rd), "+s"(passes) : : MPC_VEC_ASM_CLOBBERS);
+        else     asm volatile(MPC_VEC_ASM_BWD : "+v"(v), "+v"(ra), "+v"(rd), "+s"(passes) : : MPC_VEC_ASM_CLOBBERS);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // MATRIX-CORE RICCATI FACTORISATION (one instance per wavefront).  In homogeneous coordinates
 //     x~ = (x[5], 1),   z~ = (x[5], 1, ua, ual),   W~ = [A b_r B; 0 1 0] (6 x 8),   P~ = [P q; q' .] (6 x 6)

@@ -388,7 +388,9 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
             for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = x_init[c];
         }
         __syncthreads();
-        rowpar_vector<true>(lane, N, RL, lane < 16);
+        MPC_TICK(3);
+        rowpar_vector_fast<true>(lane, N, RL, lane < 16);
+        MPC_TICK(15);
         __syncthreads();
         double za[7] = {0, 0, 0, 0, 0, 0, 0};
         if (act) {
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
                 for (int c = 0; c < 5; c++) cc[c] = gc[2 + c] + F.K0[c] * gc[0] + F.K1[c] * gc[1];
             }
             __syncthreads();
-            rowpar_vector<false>(lane, N, RL, lane < 16);
+            rowpar_vector_fast<false>(lane, N, RL, lane < 16);
             __syncthreads();
             if (has_u) {        // feed-forward of the corrector right-hand side: k = -Muu^-1 (gc_u + B' p_{t+1}); owner lane (it has gc)
                 const double *pp = RL.H + RowLds::HS * (i + 1) + RowVec::P;
@@ -522,7 +524,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
             for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = 0.0;
         }
         __syncthreads();
-        rowpar_vector<true>(lane, N, RL, lane < 16);
+        rowpar_vector_fast<true>(lane, N, RL, lane < 16);
         __syncthreads();
         double dz[7] = {0, 0, 0, 0, 0, 0, 0};
         if (act) {

@@ -25,4 +25,5 @@ tot = t[:, :10].sum(1).mean(); it = loop.iters.double().mean().item()
 print(f"B={B} mean IPM iters {it:.2f}  total cycles/solve (IPM loop) {tot:.0f}  per iteration {tot/it:.0f}")
 for k, n in zip(range(10, 15), ["loads + look-ahead", "iterate loads", "linearise + W staging", "row state init", "tail (step, plant, stores)"]):
     print(f"  outside the IPM loop: {n:28s} {t[:,k].mean():10.0f} cycles")
+print(f"  (of the affine rollout: the sweep itself        {t[:,15].mean():10.0f} cycles, per iter {t[:,15].mean()/it:8.0f})")
 for k, n in enumerate(names[:10]): print(f"  {n:24s} {t[:,k].mean():10.0f} cycles  {100*t[:,k].mean()/tot:5.1f}%   per iter {t[:,k].mean()/it:8.0f}")
