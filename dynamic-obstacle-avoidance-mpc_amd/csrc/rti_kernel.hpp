@@ -1343,7 +1343,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = x_init[c];
             }
             __syncthreads();
-            rowpar_vector<true>(lane, N, RL, i < 16);
+            rowpar_vector_fast<true>(lane, N, RL, i < 16);
             __syncthreads();
             if (act) {
                 const double *xx = RL.H + RowLds::HS * i + RowVec::X;
@@ -1461,7 +1461,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                     for (int c = 0; c < 5; c++) cc[c] = gc[2 + c] + F.K0[c] * gc[0] + F.K1[c] * gc[1];
                 }
                 __syncthreads();
-                rowpar_vector<false>(lane, N, RL, i < 16);
+                rowpar_vector_fast<false>(lane, N, RL, i < 16);
                 __syncthreads();
                 if (has_u) {    // feed-forward of the corrector right-hand side: k = -Muu^-1 (gc_u + B' p_{t+1})
                     const double *pp = RL.H + RowLds::HS * (i + 1) + RowVec::P;
@@ -1485,7 +1485,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = 0.0;
             }
             __syncthreads();
-            rowpar_vector<true>(lane, N, RL, i < 16);
+            rowpar_vector_fast<true>(lane, N, RL, i < 16);
             __syncthreads();
             if (act) {
                 const double *xx = RL.H + RowLds::HS * i + RowVec::X;
