@@ -427,7 +427,7 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const RowLds L, b
 #pragma unroll
         for (int r = 0; r < 6; r++) T[r] = Pc[r] * d5;                 // k = 5 term of T = P~ W~
         asm volatile(
-            "s_nop 4\n"
+            "s_nop 1\n"
             "v_fmac_f64_dpp %0, %6, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
             "v_fmac_f64_dpp %1, %6, %12 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
             "v_fmac_f64_dpp %2, %6, %12 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
@@ -527,7 +527,7 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const RowLds L, b
         fp[HS * t] = i00; fp[HS * t + 1] = l; fp[HS * t + 8] = i11;
         // P~+ = M~[0..5][0..5] + M~[0..5][u] K~   (M~[i][6] = M~[6][i] is lane i's register 6)
         asm volatile(
-            "s_nop 4\n"
+            "s_nop 1\n"
             "v_fmac_f64_dpp %0, %6, %8 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
             "v_fmac_f64_dpp %1, %6, %8 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
             "v_fmac_f64_dpp %2, %6, %8 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
@@ -550,6 +550,10 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const RowLds L, b
 #pragma unroll
     for (int r = 0; r < 6; r++) Pb[r] = hp[HS * N + r * 8];           // P~_N = H~aug_N[0..5][0..5]
     fetch(N - 1, Wa, Ha);
+    // DPP hazards: 5 wait states after an EXEC write (the branches in front of this sweep), covered once here; inside the loop nothing
+    // writes EXEC (stores are unconditional), and the 2 wait states after a VALU write of a DPP source are the s_nop 1 at the head of
+    // every block
+    asm volatile("s_nop 4");
     int t = N - 1;
     for (; t >= 1; t -= 2) {
         stepT(Wa, Pb, T); fetch(t - 1, Wb, Hb); stepM(t, Wa, Ha, T, Pa);
