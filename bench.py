@@ -9,7 +9,7 @@ Workload (default, BASELINE.json configs[1] = "C2"): batch = 1024 identical scen
 `--workload c3` runs 65536 randomized scenarios instead.
 
 N > 1 GPUs (launched by torch.distributed.run, one rank per GPU): the batch is replicated per rank (weak scaling, no
-data-path collective); the per-scenario costs are all-gathered over RCCL every step on a side stream.
+data-path collective); the per-scenario costs are all-gathered over RCCL on a side stream, 25 control steps per message.
 """
 import argparse
 import json
@@ -123,14 +123,15 @@ class Loop:
         self.x0.copy_(self.x0_init); self.obst.copy_(self.obst_init)
         self.m.reset_guess_dev(self.B, self.x0, self.X, self.U, stream=self.stream)
 
-    def step(self):
-        """one control step of the whole batch = ONE kernel launch (look-ahead, solve, plant, obstacles, shift fused)"""
+    def step(self, cost_out=None):
+        """one control step of the whole batch = ONE kernel launch (look-ahead, solve, plant, obstacles, shift fused);
+        cost_out: where the kernel writes the per-scenario costs of this step (default self.cost)"""
         if self.episode_len and self.k % self.episode_len == 0 and self.k > 0:
             self.reset()
         self.k += 1
         if self.fused:
-            self.m.closed_loop_step_dev(self.B, self.x0, self.obst, self.goal, self.X, self.U, self.u0, self.cost, self.status, self.iters,
-                                        None, stream=self.stream)
+            self.m.closed_loop_step_dev(self.B, self.x0, self.obst, self.goal, self.X, self.U, self.u0,
+                                        self.cost if cost_out is None else cost_out, self.status, self.iters, None, stream=self.stream)
             return
         m, B, s = self.m, self.B, self.stream
         m.predict_dev(B, self.obst, self.P, stream=s)
@@ -226,19 +227,33 @@ def main():
     x0, goal, obst, desc = make_workload(args.workload, batch, N, no, rank)
     loop = Loop(mpc_gpu, N, no, batch, x0, goal, obst, dev)
 
-    gathered = torch.zeros(world * batch, dtype=torch.float64, device=dev) if world > 1 else None
+    # Multi-GPU: the per-scenario costs of GATHER_EVERY consecutive control steps are all-gathered in one collective (RCCL over xGMI)
+    # on a side stream.  Not every step: at batch 1024 the solve kernel fills every SIMD of the chip with exactly one 512-register
+    # wavefront, so any kernel running beside it (the collective's) holds back the workgroups of the CUs it occupies -- one message
+    # of GATHER_EVERY x 8 KB per rank costs that once instead of GATHER_EVERY times.
+    GATHER_EVERY = 25
+    # (the kernel writes each step's costs straight into its row of the history; two histories alternate, so that one can be in
+    # flight while the next fills)
+    cost_hist = torch.zeros(2, GATHER_EVERY, batch, dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.zeros(world, GATHER_EVERY, batch, dtype=torch.float64, device=dev) if world > 1 else None
     side = torch.cuda.Stream(device=dev) if world > 1 else None
     handle = None
+    nstep = 0
 
     def one_step():
-        nonlocal handle
-        loop.step()
-        if world > 1:   # RCCL all-gather of the per-scenario costs over xGMI, off the critical path
+        nonlocal handle, nstep
+        if world == 1:
+            loop.step()
+            return
+        buf = (nstep // GATHER_EVERY) % 2
+        loop.step(cost_out=cost_hist[buf, nstep % GATHER_EVERY])
+        nstep += 1
+        if nstep % GATHER_EVERY == 0:
             if handle is not None:
-                handle.wait()
+                handle.wait()        # the previous message (it left the other history two fills ago)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                handle = dist.all_gather_into_tensor(gathered, loop.cost.clone(), async_op=True)
+                handle = dist.all_gather_into_tensor(gathered.view(-1), cost_hist[buf].view(-1), async_op=True)
 
     for _ in range(args.warmup):
         one_step()
@@ -296,7 +311,7 @@ def main():
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": desc, "per_gpu_batch": batch, "N": N, "n_obst": no, "qp_tol": 1e-8, "qp_iter_max": 50,
                       "step": "one fused launch: obstacle look-ahead + RTI solve + plant step + obstacle motion + warm-start shift, device resident; episodes of 100 control steps",
-                      "parallelism": f"replicas x{world}, cost all-gather (RCCL)" if world > 1 else "single GPU"},
+                      "parallelism": f"replicas x{world}, cost all-gather (RCCL, 25 control steps per message)" if world > 1 else "single GPU"},
            "mean_ipm_iters": mean_iters, "qp_failure_frac": float((st_acc % 65536).double().sum().item()) / (batch * args.steps),
            "qp_iter_cap_frac": float((st_acc // 65536).double().sum().item()) / (batch * args.steps),
            "lanes_per_instance": lanes, "lanes_per_stage": lps, "roofline": roof}
