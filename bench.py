@@ -260,7 +260,10 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    loop.m.profile_enable(True)          # creates its HIP event pool here, outside the timed region
+    # HIP events around every 7th launch of the timed region (pool created here, outside it): a pair of event records between two
+    # back-to-back launches costs the stream ~7 us (scripts/gap_probe.py), 4 % of a control step -- sampled (0.7 % instead), not every launch
+    EVENT_EVERY = 7          # coprime with the episode length: the samples visit every position of an episode
+    loop.m.profile_enable(True, every=EVENT_EVERY)
     it_acc = torch.zeros(batch, dtype=torch.int32, device=dev)   # summed inside the solve kernel (mpc_set_accumulators)
     st_acc = torch.zeros(batch, dtype=torch.int32, device=dev)
     loop.m.set_accumulators(it_acc, st_acc)
@@ -293,6 +296,7 @@ def main():
             "frac": abytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic(kname, batch),
             "traffic_source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/{os.path.basename(PMC_SUMMARY)} (FETCH_SIZE uncorrected: 8-byte-per-lane loads, see DESIGN.md section 5)",
             "kernel": kname, "avg_launch_us": avg_kernel_s * 1e6, "launches": launches,
+            "launch_timing": f"HIP events on the launch stream around every {EVENT_EVERY}th launch of the timed region ({launches} of {args.steps} launches)",
             "algorithmic_bytes_per_launch": abytes,
             "fp64_valu": {"achieved": algorithmic_flops_per_solve(N, no, mean_iters) * batch / avg_kernel_s / 1e12,
                           "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",

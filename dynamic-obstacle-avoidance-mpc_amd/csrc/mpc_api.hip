@@ -43,7 +43,8 @@ struct mpc_handle {
     int row_parallel;                 // row-parallel (64-bit DPP) Riccati factorisation instead of the one-lane systolic sweep
     int split_override;               // lanes per horizon stage: 0 automatic, 1 one lane per stage, 2 / 3 split kernel (mpc_set_lanes_per_stage)
     int simd_count;                   // SIMDs of the device (4 per compute unit)
-    int profiling;
+    int profiling;                    // 0 off, k > 0: HIP events around every k-th solve launch
+    int launch_count;
     double *d_trace;                  // optional debug trace buffer (mpc_debug_trace)
     int32_t *d_iters_acc, *d_status_acc;   // optional accumulators (mpc_set_accumulators)
     std::vector<hipEvent_t> ev_start, ev_stop;
@@ -134,7 +135,7 @@ int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
 {
     p.iters_acc = h->d_iters_acc; p.status_acc = h->d_status_acc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->profiling && h->ev_used < (int)h->ev_start.size()) {   // pool is created by mpc_profile_enable, never here
+    if (h->profiling && (h->launch_count++ % h->profiling) == 0 && h->ev_used < (int)h->ev_start.size()) {   // pool is created by mpc_profile_enable, never here
         e0 = h->ev_start[h->ev_used]; e1 = h->ev_stop[h->ev_used]; h->ev_used++;
         HIPCHK(hipEventRecord(e0, s));
     }
@@ -237,7 +238,7 @@ int mpc_create(const mpc_config *cfg, int device, int max_batch, mpc_handle **ou
         h->simd_count = 4 * prop.multiProcessorCount;
     }
     h->split_override = 0;
-    h->lanes_override = 0; h->use_mfma = 0; h->row_parallel = 1; h->profiling = 0; h->ev_used = 0; h->d_trace = nullptr; h->d_iters_acc = nullptr; h->d_status_acc = nullptr;
+    h->lanes_override = 0; h->use_mfma = 0; h->row_parallel = 1; h->profiling = 0; h->launch_count = 0; h->ev_used = 0; h->d_trace = nullptr; h->d_iters_acc = nullptr; h->d_status_acc = nullptr;
     const size_t B = (size_t)max_batch, N = (size_t)cfg->N, no = (size_t)cfg->n_obst;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc(&h->dX, B * (N + 1) * 5 * sizeof(double)));
@@ -539,8 +540,8 @@ int mpc_generate_scenarios(mpc_handle *h, int count, int scenario, unsigned seed
 int mpc_profile_enable(mpc_handle *h, int on)
 {
     if (!h) return fail(MPC_ERR_ARG, "null handle");
-    h->profiling = on ? 1 : 0;
-    h->ev_used = 0;
+    h->profiling = on > 0 ? on : 0;
+    h->ev_used = 0; h->launch_count = 0;
     if (on) {   // event pool up front, so that no event is created inside a timed region
         HIPCHK(hipSetDevice(h->device));
         while ((int)h->ev_start.size() < kMaxEvents) {

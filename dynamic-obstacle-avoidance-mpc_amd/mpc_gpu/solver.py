@@ -179,8 +179,9 @@ class BatchedMpc:
     def set_accumulators(self, iters_acc=None, status_acc=None):
         _lib.check(_lib.lib().mpc_set_accumulators(self._h, _ptr(iters_acc), _ptr(status_acc)))
 
-    def profile_enable(self, on=True):
-        _lib.check(_lib.lib().mpc_profile_enable(self._h, 1 if on else 0))
+    def profile_enable(self, on=True, every=1):
+        """HIP events around every `every`-th solve launch (on=False: off)."""
+        _lib.check(_lib.lib().mpc_profile_enable(self._h, int(every) if on else 0))
 
     def profile_read(self):
         ms, n = C.c_double(), C.c_int()

@@ -152,7 +152,9 @@ int mpc_linearize_dev(mpc_handle *h, int batch, const double *d_x0, const double
                       const double *d_X, const double *d_U,
                       double *d_A, double *d_B, double *d_b, double *d_q, double *d_hval, double *d_dh, void *stream);
 
-/* ---- measurement: HIP events around every solve-kernel launch on the launch stream ---- */
+/* ---- measurement: HIP events around solve-kernel launches on the launch stream ----
+ * on = 0: off; on = k > 0: events around every k-th launch (k = 1: every launch).  A pair of event records between two back-to-back
+ * launches costs the stream ~7 us (measured, scripts/gap_probe.py), so a throughput run samples (bench.py: every 7th launch). */
 int mpc_profile_enable(mpc_handle *h, int on);
 /* synchronises; returns the summed duration and the number of solve-kernel launches since the last call */
 int mpc_profile_read(mpc_handle *h, double *sum_ms, int *launches);
