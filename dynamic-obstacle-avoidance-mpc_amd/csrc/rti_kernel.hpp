@@ -210,6 +210,23 @@ __device__ __forceinline__ double seg_sum(double v, int lane)
     return a + b;
 }
 
+// Two reductions at once (a: sum if SUM_A else max; b: max): the DPP steps of the two chains alternate, so that the wait states a DPP
+// read needs after the VALU write of its source, and the latency of each dependent max / add, are filled by the other chain.
+template <int G, bool SUM_A>
+__device__ __forceinline__ void seg_reduce2(double &a, double &b, int lane)
+{
+#define MPC_RED2_STEP(CTRL) { const double a2 = dpp_f64<CTRL>(a), b2 = dpp_f64<CTRL>(b); a = SUM_A ? a + a2 : fmax(a, a2); b = fmax(b, b2); }
+    MPC_RED2_STEP(0xB1) MPC_RED2_STEP(0x4E) MPC_RED2_STEP(0x141) MPC_RED2_STEP(0x140)
+#undef MPC_RED2_STEP
+    if (G == 16) return;
+    const double a0 = lane_value(a, 0), a1 = lane_value(a, 16), a2 = lane_value(a, 32), a3 = lane_value(a, 48);
+    const double b0 = lane_value(b, 0), b1 = lane_value(b, 16), b2 = lane_value(b, 32), b3 = lane_value(b, 48);
+    const double al = SUM_A ? a0 + a1 : fmax(a0, a1), ah = SUM_A ? a2 + a3 : fmax(a2, a3);
+    const double bl = fmax(b0, b1), bh = fmax(b2, b3);
+    if (G == 32) { a = lane < 32 ? al : ah; b = lane < 32 ? bl : bh; return; }
+    a = SUM_A ? al + ah : fmax(al, ah); b = fmax(bl, bh);
+}
+
 // reciprocal: hardware seed + two Newton steps (1-2 ulp); used for 1/t of the inequality rows
 __device__ __forceinline__ double rcp_nr(double x)
 {
@@ -1167,8 +1184,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 }
             }
         }
-        msum = seg_sum<G>(msum, lane);
-        cmax = seg_max<G>(cmax, lane);
+        seg_reduce2<G, true>(msum, cmax, lane);
         const double mu = msum * inv_items;
         const double lin = rhoPi * lin0;
         if (running) {
@@ -1408,8 +1424,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                     rmax = fmax(rmax, -dt1_[j] * rt1[j]); rmaxd = fmax(rmaxd, fma(dt1_[j], rt1[j], 1.0));
                 }
             }
-            rmax = seg_max<G>(rmax, lane); rmaxd = seg_max<G>(rmaxd, lane);
-            const double a_aff = rmax > 1.0 ? 1.0 / rmax : 1.0, a_affd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;
+            seg_reduce2<G, false>(rmax, rmaxd, lane);
+            const double a_aff = rmax > 1.0 ? 1.0 / rmax : 1.0, a_affd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;      // (true divisions, as the oracle: a 1-ulp reciprocal here moves a sensitive instance past the parity tolerance)
             double maff = 0.0;
 #pragma unroll
             for (int k = 0; k < NB; k++) if ((k < 2) ? vbu : vbx)
@@ -1549,7 +1565,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                     rmax = fmax(rmax, -dt1_[j] * rt1[j]); rmaxd = fmax(rmaxd, -dl1_[j] * rcp_nr(l1[j]));
                 }
             }
-            rmax = seg_max<G>(rmax, lane); rmaxd = seg_max<G>(rmaxd, lane);
+            seg_reduce2<G, false>(rmax, rmaxd, lane);
             const double amax = rmax > 1.0 ? 1.0 / rmax : 1.0, amaxd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;
             const double alpha = (amax >= 1.0) ? 1.0 : 0.9995 * amax;        // primal step: z, s, t
             const double alphad = (amaxd >= 1.0) ? 1.0 : 0.9995 * amaxd;     // dual step: lam

@@ -255,8 +255,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
                 if (!(t2[s] <= 2 * kTLMin || l2[s] <= 2 * kTLMin)) cmax = fmax(cmax, b);
             }
         }
-        msum = seg_sum<64>(msum, lane);
-        cmax = seg_max<64>(cmax, lane);
+        seg_reduce2<64, true>(msum, cmax, lane);
         const double mu = msum * inv_items;
         const double lin = rhoPi * lin0;
         if (running) {
@@ -321,14 +320,23 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
         double bbr[5], x_init[5];
 #pragma unroll
         for (int c = 0; c < 5; c++) { bbr[c] = rhoPi * bb[c]; x_init[c] = rhoPi * d0[c]; }
-        {   // the stage's values and sums in the owner lane, in a fixed order
-            double Hk[6], gk[6], Ssum[5];
+        {   // the stage's values and sums in the owner lane, in a fixed order.  All first shifts, then all second shifts: a DPP read needs
+            // two wait states after the VALU write of its source, which the other values' moves fill
+            double Hk[6], gk[6], Ssum[5], sh_h[NBL], sh_g[NBL], sh_s[5];
 #pragma unroll
-            for (int q = 0; q < LPS; q++) {
+            for (int s = 0; s < NBL; s++) { Hk[s] = hdiag_[s]; gk[s] = g_[s]; sh_h[s] = hdiag_[s]; sh_g[s] = g_[s]; }
 #pragma unroll
-                for (int s = 0; s < NBL; s++) { Hk[q * NBL + s] = of_part(hdiag_[s], q); gk[q * NBL + s] = of_part(g_[s], q); }
+            for (int e = 0; e < 5; e++) { Ssum[e] = ssum[e]; sh_s[e] = ssum[e]; }
 #pragma unroll
-                for (int e = 0; e < 5; e++) { const double v = of_part(ssum[e], q); Ssum[e] = q == 0 ? v : Ssum[e] + v; }
+            for (int q = 1; q < LPS; q++) {
+#pragma unroll
+                for (int s = 0; s < NBL; s++) { sh_h[s] = from_right(sh_h[s]); sh_g[s] = from_right(sh_g[s]); }
+#pragma unroll
+                for (int e = 0; e < 5; e++) sh_s[e] = from_right(sh_s[e]);
+#pragma unroll
+                for (int s = 0; s < NBL; s++) { Hk[q * NBL + s] = sh_h[s]; gk[q * NBL + s] = sh_g[s]; }
+#pragma unroll
+                for (int e = 0; e < 5; e++) Ssum[e] += sh_s[e];
             }
             const double Sxx = Ssum[0], Syy = Ssum[1], Sxy = Ssum[2], Sgx = Ssum[3], Sgy = Ssum[4];
             if (own && act) {   // H~aug_t, dense 8 x 8, z~ order (x0..x4, 1, ua, ual); affine column of W~_t
@@ -438,8 +446,8 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
                 pp1[s] = dl1_[s] * dt1_[s];
                 if (sp[s]) { rmax = fmax(rmax, -dt1_[s] * rt1[s]); rmaxd = fmax(rmaxd, fma(dt1_[s], rt1[s], 1.0)); }
             }
-            rmax = seg_max<64>(rmax, lane); rmaxd = seg_max<64>(rmaxd, lane);
-            const double a_aff = rmax > 1.0 ? 1.0 / rmax : 1.0, a_affd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;
+            seg_reduce2<64, false>(rmax, rmaxd, lane);
+            const double a_aff = rmax > 1.0 ? 1.0 / rmax : 1.0, a_affd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;      // (true divisions, as the oracle: a 1-ulp reciprocal here moves a sensitive instance past the parity tolerance)
             double maff = 0.0;
 #pragma unroll
             for (int s = 0; s < NBL; s++) if (bp[s])
@@ -571,7 +579,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
                 dl1_[s] = -(l1[s] * t1[s] - smu + pp1[s] + l1[s] * dt1_[s]) * rt1[s];
                 if (sp[s]) { rmax = fmax(rmax, -dt1_[s] * rt1[s]); rmaxd = fmax(rmaxd, -dl1_[s] * rcp_nr(l1[s])); }
             }
-            rmax = seg_max<64>(rmax, lane); rmaxd = seg_max<64>(rmaxd, lane);
+            seg_reduce2<64, false>(rmax, rmaxd, lane);
             const double amax = rmax > 1.0 ? 1.0 / rmax : 1.0, amaxd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;
             const double alpha = (amax >= 1.0) ? 1.0 : 0.9995 * amax;        // primal step: z, s, t
             const double alphad = (amaxd >= 1.0) ? 1.0 : 0.9995 * amaxd;     // dual step: lam
