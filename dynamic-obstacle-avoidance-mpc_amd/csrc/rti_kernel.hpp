@@ -418,7 +418,11 @@ struct RowLds {
     static __host__ __device__ constexpr int pad_rear() { return AHEAD * HS; }
     static __host__ __device__ constexpr int total(int N, int instances) { return pad_front(N) + instances * per_instance(N) + pad_rear(); }
     double *W, *H;     // W[t][k][j] (5 x 8 per stage, t < N), H[t][i][j] (8 x 8 per stage, t <= N)
-    __device__ __forceinline__ RowLds(double *base, int N) : W(base), H(base + WS * N) {}
+    double *R;         // results of the sweeps, one block of HS words per stage: overlays H (the blocks are dead once fetched) unless a
+                       // region of its own is given -- then the structural zeros of the H~aug blocks survive an iteration and only their
+                       // non-zeros have to be restaged (an LDS instruction costs a lone wavefront ~14 cycles)
+    __device__ __forceinline__ RowLds(double *base, int N) : W(base), H(base + WS * N), R(base + WS * N) {}
+    __device__ __forceinline__ RowLds(double *base, int N, double *results) : W(base), H(base + WS * N), R(results) {}
 };
 
 __device__ __forceinline__ void rowpar_factor(int lane, int N, const RowLds L, bool worker_row)
@@ -431,7 +435,7 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const RowLds L, b
     // Stores are unconditional: lanes with nothing to store write into dead parts of the same block ([16..63]).
     // (two per-lane pointers, the rest are immediate offsets: K~[1][j] is 8 words behind K~[0][j], 1/d1 8 words behind 1/d0, and the
     // dead words an idle lane hits instead -- 48, 56 resp. 50, 51, 58 -- lie in rows 6, 7 of the block, consumed one stage earlier)
-    double *kp = L.H + (store ? j : 48), *fp = L.H + (store0 ? 6 : 50);
+    double *kp = L.R + (store ? j : 48), *fp = L.R + (store0 ? 6 : 50);
     const double *wp = L.W + j, *hp = L.H + j;
     auto fetch = [&](int t, double Wc[5], double Hc[8]) {
 #pragma unroll
@@ -600,12 +604,12 @@ __device__ __forceinline__ void rowpar_vector(int lane, int N, const RowLds L, b
     const int r = lane & 7, rc = r < 5 ? r : 0;
     const bool store = worker_row && (lane & 15) < 5;
     const int Q = FWD ? N : N - 1;                                  // number of stage steps
-    double v = FWD ? L.H[RowVec::X + r] : L.H[HS * N + RowVec::CT + r];
-    if (!FWD && store) L.H[HS * N + RowVec::P + r] = v;
+    double v = FWD ? L.R[RowVec::X + r] : L.R[HS * N + RowVec::CT + r];
+    if (!FWD && store) L.R[HS * N + RowVec::P + r] = v;
     // step q works on stage t = q (FWD) / N-1-q (!FWD); src points at the lane's operands of step 0, dst at the place of
     // the vector produced by step 0; both move by one stage block per step (dst of an idle lane stays in the rear padding)
-    const double *src = L.H + (FWD ? 0 : HS * (N - 1)) + RowVec::ACL + (FWD ? rc * RowVec::RS : rc);
-    double *dst = L.H + (FWD ? HS : HS * (N - 1)) + (store ? (FWD ? RowVec::X : RowVec::P) + r : RowLds::TAIL);   // idle lanes: one dead word of the block
+    const double *src = L.R + (FWD ? 0 : HS * (N - 1)) + RowVec::ACL + (FWD ? rc * RowVec::RS : rc);
+    double *dst = L.R + (FWD ? HS : HS * (N - 1)) + (store ? (FWD ? RowVec::X : RowVec::P) + r : RowLds::TAIL);   // idle lanes: one dead word of the block
     constexpr int dstep = FWD ? HS : -HS;
     double A[D][5], c[D];
     const double *srcc = src + (FWD ? 5 : RowVec::CT);
@@ -791,11 +795,11 @@ __device__ __forceinline__ void rowpar_vector_fast(int lane, int N, const RowLds
     constexpr int HS = RowLds::HS, SS = FWD ? HS : -HS;
     const int r = lane & 7, rc = r < 5 ? r : 0;
     const bool store = worker_row && r < 5;
-    double v = FWD ? L.H[RowVec::X + r] : L.H[HS * N + RowVec::CT + r];
-    if (!FWD && worker_row && (lane & 15) < 5) L.H[HS * N + RowVec::P + r] = v;
+    double v = FWD ? L.R[RowVec::X + r] : L.R[HS * N + RowVec::CT + r];
+    if (!FWD && worker_row && (lane & 15) < 5) L.R[HS * N + RowVec::P + r] = v;
     // block of the first stage step: its operands (src) and the place of the vector it produces (dst)
-    const double *src = L.H + (FWD ? 0 : HS * (N - 1)) + RowVec::ACL + (FWD ? rc * RowVec::RS : rc);
-    double *dst = L.H + (FWD ? HS : HS * (N - 1));
+    const double *src = L.R + (FWD ? 0 : HS * (N - 1)) + RowVec::ACL + (FWD ? rc * RowVec::RS : rc);
+    double *dst = L.R + (FWD ? HS : HS * (N - 1));
     for (int q = 0; q < (N & 3); q++) {        // leading N mod 4 stages, every lane with r = lane & 7 (both halves of the row hold the vector)
         double a[5], cc, acc;
 #pragma unroll

@@ -26,7 +26,8 @@ template <int LPS, int NOBST>
 struct SplitLds {
     static constexpr int NBL = 6 / LPS;                       // box variables per lane
     static constexpr int NSL = (NOBST + LPS - 1) / LPS;       // obstacle row pairs per lane
-    static __host__ __device__ constexpr int total(int N, bool lookahead) { return RowLds::total(N, 1) + (lookahead ? (N + 1) * NOBST * 2 : 0); }
+    static __host__ __device__ constexpr int results(int N) { return (N + 1) * RowLds::HS; }     // result blocks of the sweeps, apart from the H~aug blocks
+    static __host__ __device__ constexpr int total(int N, bool lookahead) { return RowLds::total(N, 1) + results(N) + (lookahead ? (N + 1) * NOBST * 2 : 0); }
 };
 
 template <int K>
@@ -86,8 +87,8 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
     double *Xg = p.X + (size_t)inst * (N + 1) * 5, *Ug = p.U + (size_t)inst * N * 2;
     const bool ep_done = (p.fused & kFuseMetrics) && p.ep_flags && (p.ep_flags[inst] & 1);
     extern __shared__ double lds_raw[];
-    const RowLds RL(lds_raw + RowLds::pad_front(N), N);
-    double *lds_P = lds_raw + RowLds::total(N, 1);
+    const RowLds RL(lds_raw + RowLds::pad_front(N), N, lds_raw + RowLds::total(N, 1));
+    double *lds_P = lds_raw + RowLds::total(N, 1) + SL::results(N);
     // what part q of this lane's stage holds in the variable v: from_right shifts the whole wavefront by one lane, so the owner
     // (part 0) sees its neighbours' values; only the owner's result is meaningful
     auto of_part = [&](double v, int q) { return q == 0 ? v : (q == 1 ? from_right(v) : from_right(from_right(v))); };
@@ -156,6 +157,11 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
     if (i == 0) {
 #pragma unroll
         for (int c = 0; c < 5; c++) { d0[c] = x0v[c] - xi[c]; lin0 = fmax(lin0, fabs(d0[c])); }
+    }
+    if (own && act) {           // H~aug_t: the structural zeros (and the constant psi diagonal) once; the 22 non-zeros are restaged every iteration
+        double *hc = RL.H + RowLds::HS * i;
+#pragma unroll
+        for (int e = 0; e < 64; e++) hc[e] = 0.0;
     }
     if (own && has_u) {         // W~_t = [A b B] rows 0..4 (cols: x0..x4, b, ua, ual); column 5 is rewritten every iteration
         double *w = RL.W + RowLds::WS * i;
@@ -343,15 +349,11 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
                 const double hxx = Hk[2] + Sxx, hyy = Hk[3] + Syy;
                 const double gxs[5] = {gk[2] + Sgx, gk[3] + Sgy, hd_psi * z[4], gk[4], gk[5]};
                 const double lu0 = gk[0], lu1 = gk[1];
-                const double Hrow[8][8] = {{hxx, Sxy, 0.0, 0.0, 0.0, gxs[0], 0.0, 0.0}, {Sxy, hyy, 0.0, 0.0, 0.0, gxs[1], 0.0, 0.0},
-                                           {0.0, 0.0, hd_psi, 0.0, 0.0, gxs[2], 0.0, 0.0}, {0.0, 0.0, 0.0, Hk[4], 0.0, gxs[3], 0.0, 0.0},
-                                           {0.0, 0.0, 0.0, 0.0, Hk[5], gxs[4], 0.0, 0.0}, {gxs[0], gxs[1], gxs[2], gxs[3], gxs[4], 0.0, lu0, lu1},
-                                           {0.0, 0.0, 0.0, 0.0, 0.0, lu0, Hk[0], 0.0}, {0.0, 0.0, 0.0, 0.0, 0.0, lu1, 0.0, Hk[1]}};
-                double *hc = RL.H + RowLds::HS * i;
+                double *hc = RL.H + RowLds::HS * i;      // row-major 8 x 8; everything else in the block is zero and stays zero
+                hc[0] = hxx; hc[1] = Sxy; hc[8] = Sxy; hc[9] = hyy; hc[18] = hd_psi; hc[27] = Hk[4]; hc[36] = Hk[5]; hc[54] = Hk[0]; hc[63] = Hk[1];
 #pragma unroll
-                for (int r = 0; r < 8; r++)
-#pragma unroll
-                    for (int c = 0; c < 8; c++) hc[r * 8 + c] = Hrow[r][c];
+                for (int c = 0; c < 5; c++) { hc[c * 8 + 5] = gxs[c]; hc[40 + c] = gxs[c]; }
+                hc[46] = lu0; hc[47] = lu1; hc[53] = lu0; hc[61] = lu1;
                 if (has_u) {
 #pragma unroll
                     for (int k = 0; k < 5; k++) RL.W[RowLds::WS * i + k * 8 + 5] = bbr[k];
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
 #pragma unroll
         for (int c = 0; c < 5; c++) { F.K0[c] = 0.0; F.K1[c] = 0.0; }
         if (has_u) {
-            const double *ko = RL.H + RowLds::HS * i;
+            const double *ko = RL.R + RowLds::HS * i;
 #pragma unroll
             for (int c = 0; c < 5; c++) { F.K0[c] = ko[c]; F.K1[c] = ko[8 + c]; }
             F.k0 = ko[5]; F.k1 = ko[13]; F.i00 = ko[6]; F.l = ko[7]; F.i11 = ko[14];
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
         // the parts of a stage must all have read the factors before the owner overwrites the block: LDS operations of one
         // wavefront complete in order, so no barrier is needed
         if (own && has_u) {     // closed-loop matrix Acl = A + B K, row-major, and c_t = r_b + B k, for the row-parallel vector recursions
-            double *acl = RL.H + RowLds::HS * i + RowVec::ACL;
+            double *acl = RL.R + RowLds::HS * i + RowVec::ACL;
             const double Ar[2][5] = {{1.0, 0.0, S.a02, S.a03, S.a04}, {0.0, 1.0, S.a12, S.a13, S.a14}};
             const double Br[2][2] = {{S.b00, S.b01}, {S.b10, S.b11}};
 #pragma unroll
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
         MPC_TICK(2);
         if (lane == 0) {
 #pragma unroll
-            for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = x_init[c];
+            for (int c = 0; c < 5; c++) RL.R[RowVec::X + c] = x_init[c];
         }
         __syncthreads();
         MPC_TICK(3);
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
         __syncthreads();
         double za[7] = {0, 0, 0, 0, 0, 0, 0};
         if (act) {
-            const double *xx = RL.H + RowLds::HS * i + RowVec::X;
+            const double *xx = RL.R + RowLds::HS * i + RowVec::X;
             double u0 = F.k0, u1 = F.k1;
 #pragma unroll
             for (int c = 0; c < 5; c++) { za[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
             }
             gc[2] += Sgx; gc[3] += Sgy;
             if (own && act) {   // c~_t = gc_x + K' gc_u  (K = 0 in the terminal lane)
-                double *cc = RL.H + RowLds::HS * i + RowVec::CT;
+                double *cc = RL.R + RowLds::HS * i + RowVec::CT;
 #pragma unroll
                 for (int c = 0; c < 5; c++) cc[c] = gc[2 + c] + F.K0[c] * gc[0] + F.K1[c] * gc[1];
             }
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
             rowpar_vector_fast<false>(lane, N, RL, lane < 16);
             __syncthreads();
             if (has_u) {        // feed-forward of the corrector right-hand side: k = -Muu^-1 (gc_u + B' p_{t+1}); owner lane (it has gc)
-                const double *pp = RL.H + RowLds::HS * (i + 1) + RowVec::P;
+                const double *pp = RL.R + RowLds::HS * (i + 1) + RowVec::P;
                 const double pv[5] = {pp[0], pp[1], pp[2], pp[3], pp[4]};
                 const double m0 = gc[0] + S.dua(pv), m1 = gc[1] + S.dual(pv);
                 F.k1 = fma(F.l, m0, -m1) * F.i11;
@@ -522,22 +524,22 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
         }
         MPC_TICK(6);
         if (own && has_u) {     // homogeneous dynamics: c_t = B k; k itself for the other parts of the stage
-            double *cc = RL.H + RowLds::HS * i + RowVec::ACL + 5;
+            double *cc = RL.R + RowLds::HS * i + RowVec::ACL + 5;
             cc[0 * RowVec::RS] = S.b00 * F.k0 + S.b01 * F.k1; cc[1 * RowVec::RS] = S.b10 * F.k0 + S.b11 * F.k1;
             cc[2 * RowVec::RS] = h2 * F.k1; cc[3 * RowVec::RS] = dt * F.k0; cc[4 * RowVec::RS] = dt * F.k1;
-            RL.H[RowLds::HS * i + kKK] = F.k0; RL.H[RowLds::HS * i + kKK + 1] = F.k1;
+            RL.R[RowLds::HS * i + kKK] = F.k0; RL.R[RowLds::HS * i + kKK + 1] = F.k1;
         }
         if (lane == 0) {
 #pragma unroll
-            for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = 0.0;
+            for (int c = 0; c < 5; c++) RL.R[RowVec::X + c] = 0.0;
         }
         __syncthreads();
         rowpar_vector_fast<true>(lane, N, RL, lane < 16);
         __syncthreads();
         double dz[7] = {0, 0, 0, 0, 0, 0, 0};
         if (act) {
-            const double *xx = RL.H + RowLds::HS * i + RowVec::X;
-            double u0 = has_u ? RL.H[RowLds::HS * i + kKK] : 0.0, u1 = has_u ? RL.H[RowLds::HS * i + kKK + 1] : 0.0;
+            const double *xx = RL.R + RowLds::HS * i + RowVec::X;
+            double u0 = has_u ? RL.R[RowLds::HS * i + kKK] : 0.0, u1 = has_u ? RL.R[RowLds::HS * i + kKK + 1] : 0.0;
 #pragma unroll
             for (int c = 0; c < 5; c++) { dz[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }
             dz[0] = u0; dz[1] = u1;
