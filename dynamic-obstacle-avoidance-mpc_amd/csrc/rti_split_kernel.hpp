@@ -85,7 +85,18 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
     for (int c = 0; c < 5; c++) x0v[c] = p.x0[(size_t)inst * 5 + c];
     gl[0] = p.goal[(size_t)inst * 2]; gl[1] = p.goal[(size_t)inst * 2 + 1];
     double *Xg = p.X + (size_t)inst * (N + 1) * 5, *Ug = p.U + (size_t)inst * N * 2;
-    const bool ep_done = (p.fused & kFuseMetrics) && p.ep_flags && (p.ep_flags[inst] & 1);
+    const int ep_word = ((p.fused & kFuseMetrics) && p.ep_flags) ? p.ep_flags[inst] : 0;     // consumed after the look-ahead (no early wait)
+    // the iterate: requested here, in front of the obstacle look-ahead, so that its global-memory latency passes behind that loop
+    double xi[5] = {0, 0, 0, 0, 0}, ui[2] = {0, 0}, xnext[5] = {0, 0, 0, 0, 0};
+    if (act) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) xi[c] = Xg[i * 5 + c];
+    }
+    if (has_u) {
+        ui[0] = Ug[i * 2]; ui[1] = Ug[i * 2 + 1];
+#pragma unroll
+        for (int c = 0; c < 5; c++) xnext[c] = Xg[(i + 1) * 5 + c];
+    }
     extern __shared__ double lds_raw[];
     const RowLds RL(lds_raw + RowLds::pad_front(N), N, lds_raw + RowLds::total(N, 1));
     double *lds_P = lds_raw + RowLds::total(N, 1) + SL::results(N);
@@ -110,23 +121,22 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
         __syncthreads();
     }
     MPC_TICK(10);
+    if (p.obst) {       // (two branches, not a select between an LDS and a global pointer: that would be a flat load)
 #pragma unroll
-    for (int s = 0; s < NSL; s++) {
-        const int j = s * LPS + h, jj = j < NOBST ? j : NOBST - 1;
-        const double *src = p.obst ? lds_P + ((act ? i : 0) * NOBST + jj) * 2
-                                   : p.P + (((size_t)inst * (N + 1) + (act ? i : 0)) * NOBST + jj) * 2;
-        pxy[s][0] = src[0]; pxy[s][1] = src[1];
-    }
-    double xi[5] = {0, 0, 0, 0, 0}, ui[2] = {0, 0}, xnext[5] = {0, 0, 0, 0, 0};
-    if (act) {
+        for (int s = 0; s < NSL; s++) {
+            const int j = s * LPS + h, jj = j < NOBST ? j : NOBST - 1;
+            const double *src = lds_P + ((act ? i : 0) * NOBST + jj) * 2;
+            pxy[s][0] = src[0]; pxy[s][1] = src[1];
+        }
+    } else {
 #pragma unroll
-        for (int c = 0; c < 5; c++) xi[c] = Xg[i * 5 + c];
+        for (int s = 0; s < NSL; s++) {
+            const int j = s * LPS + h, jj = j < NOBST ? j : NOBST - 1;
+            const double *src = p.P + (((size_t)inst * (N + 1) + (act ? i : 0)) * NOBST + jj) * 2;
+            pxy[s][0] = src[0]; pxy[s][1] = src[1];
+        }
     }
-    if (has_u) {
-        ui[0] = Ug[i * 2]; ui[1] = Ug[i * 2 + 1];
-#pragma unroll
-        for (int c = 0; c < 5; c++) xnext[c] = Xg[(i + 1) * 5 + c];
-    }
+    const bool ep_done = (ep_word & 1) != 0;
 
     MPC_TICK(11);
     // ---- slack schedule, robot_ocp_problem.py:145-152 ----
