@@ -66,13 +66,18 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
         if (LPS == 3) r = is_part2 ? nth_of_six<(2 * NBL + s) % 6>(a0, a1, a2, a3, a4, a5) : r;
         return r;
     };
-    // the same for vectors in z order (ua, ual, x, y, psi, v, om)
-    auto zpart_of = [&](const double v[7], int s) {
-        const int zidx[6] = {0, 1, 2, 3, 5, 6};
-        double r = v[zidx[s]];
-        r = is_part1 ? v[zidx[NBL + s]] : r;
-        if (LPS == 3) r = is_part2 ? v[zidx[(2 * NBL + s) % 6]] : r;
-        return r;
+    // the same for vectors in z order (ua, ual, x, y, psi, v, om), whose box variables sit at 0, 1, 2, 3, 5, 6: compile-time slot, scalar
+    // arguments (written with a run-time slot this became a table look-up in GLOBAL memory plus a seven-way select inside the iteration
+    // loop; written on the array, a select between its elements becomes an indexed load from a stack copy)
+    auto zpart_of = [&](auto sc, double v0, double v1, double v2, double v3, double v5, double v6) {
+        return part_of(sc, v0, v1, v2, v3, v5, v6);
+    };
+    using slot0 = std::integral_constant<int, 0>; using slot1 = std::integral_constant<int, 1>; using slot2 = std::integral_constant<int, 2>;
+    // the NBL slot values of a z-ordered vector for this lane
+    auto slots_of = [&](const double (&v)[7], double (&out)[NBL]) {
+        out[0] = zpart_of(slot0{}, v[0], v[1], v[2], v[3], v[5], v[6]);
+        out[1] = zpart_of(slot1{}, v[0], v[1], v[2], v[3], v[5], v[6]);
+        if constexpr (NBL > 2) out[2] = zpart_of(slot2{}, v[0], v[1], v[2], v[3], v[5], v[6]);
     };
 
 #ifdef MPC_PHASE_TIMING
@@ -427,10 +432,11 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
         double smu;
         {
             double rmax = 0.0, rmaxd = 0.0;      // largest -dt/t (primal) and -dlam/lam (dual) ratios
-            double dtl_[NBL], dth_[NBL], dll_[NBL], dlh_[NBL];
+            double dtl_[NBL], dth_[NBL], dll_[NBL], dlh_[NBL], zas[NBL];
+            slots_of(za, zas);
 #pragma unroll
             for (int s = 0; s < NBL; s++) {
-                const double dzk = zpart_of(za, s);
+                const double dzk = zas[s];
                 dtl_[s] = dzk + rdl[s]; dth_[s] = -dzk + rdh[s];
                 dll_[s] = -(ll[s] * tl[s] + ll[s] * dtl_[s]) * rtl[s]; dlh_[s] = -(lh[s] * th[s] + lh[s] * dth_[s]) * rth[s];
                 ppl[s] = dll_[s] * dtl_[s]; pph[s] = dlh_[s] * dth_[s];
@@ -562,9 +568,9 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
         {
             double rmax = 0.0, rmaxd = 0.0;
             double dzs[NBL], dtl_[NBL], dth_[NBL], dll_[NBL], dlh_[NBL];
+            slots_of(dz, dzs);
 #pragma unroll
             for (int s = 0; s < NBL; s++) {
-                dzs[s] = zpart_of(dz, s);
                 dtl_[s] = dzs[s] + rdl[s]; dth_[s] = -dzs[s] + rdh[s];
                 dll_[s] = -(ll[s] * tl[s] - smu + ppl[s] + ll[s] * dtl_[s]) * rtl[s];
                 dlh_[s] = -(lh[s] * th[s] - smu + pph[s] + lh[s] * dth_[s]) * rth[s];
