@@ -1238,19 +1238,24 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             for (int k = 0; k < NB; k++) OPAQUE(vals[k]);
             // Gauss-Newton gradient q and diagonal Hessian, z order (ua, ual, x, y, psi, v, om); robot_ocp_problem.py:59-83
             double Hd[7], gloc[7], cb[7];
-            if (has_u) {
+            {   // stage / terminal weights chosen per lane as a select of VALUES: the wave-uniform kernel arguments pass through an opaque
+                // scalar copy first -- written as if / else on the argument arrays, the optimiser selects the ADDRESS and issues five
+                // per-lane global loads from the kernel-argument segment inside the iteration loop
+                double hs[7], ht[5], wg[6], we[4];
 #pragma unroll
-                for (int c = 0; c < 7; c++) Hd[c] = p.Hd_stage[c];
-                gloc[0] = p.Wg[4] * vals[0]; gloc[1] = p.Wg[5] * vals[1];
-                gloc[2] = p.Wg[0] * (vals[2] - gl[0]); gloc[3] = p.Wg[1] * (vals[3] - gl[1]); gloc[4] = 0.0;
-                gloc[5] = p.Wg[2] * vals[4]; gloc[6] = p.Wg[3] * vals[5];
-            } else {
-                Hd[0] = Hd[1] = 0.0;
+                for (int c = 0; c < 7; c++) { hs[c] = p.Hd_stage[c]; asm volatile("" : "+s"(hs[c])); }
 #pragma unroll
-                for (int c = 0; c < 5; c++) Hd[2 + c] = p.Hd_term[c];
-                gloc[0] = gloc[1] = 0.0;
-                gloc[2] = p.Weg[0] * (vals[2] - gl[0]); gloc[3] = p.Weg[1] * (vals[3] - gl[1]); gloc[4] = 0.0;
-                gloc[5] = p.Weg[2] * vals[4]; gloc[6] = p.Weg[3] * vals[5];
+                for (int c = 0; c < 5; c++) { ht[c] = p.Hd_term[c]; asm volatile("" : "+s"(ht[c])); }
+#pragma unroll
+                for (int c = 0; c < 6; c++) { wg[c] = p.Wg[c]; asm volatile("" : "+s"(wg[c])); }
+#pragma unroll
+                for (int c = 0; c < 4; c++) { we[c] = p.Weg[c]; asm volatile("" : "+s"(we[c])); }
+                Hd[0] = has_u ? hs[0] : 0.0; Hd[1] = has_u ? hs[1] : 0.0;
+#pragma unroll
+                for (int c = 0; c < 5; c++) Hd[2 + c] = has_u ? hs[2 + c] : ht[c];
+                gloc[0] = (has_u ? wg[4] : 0.0) * vals[0]; gloc[1] = (has_u ? wg[5] : 0.0) * vals[1];
+                gloc[2] = (has_u ? wg[0] : we[0]) * (vals[2] - gl[0]); gloc[3] = (has_u ? wg[1] : we[1]) * (vals[3] - gl[1]); gloc[4] = 0.0;
+                gloc[5] = (has_u ? wg[2] : we[2]) * vals[4]; gloc[6] = (has_u ? wg[3] : we[3]) * vals[5];
             }
             double Hq[8] = {has_u ? Hd[0] : 1.0, has_u ? Hd[1] : 1.0, Hd[2], Hd[3], Hd[4], Hd[5], Hd[6], 0.0};   // diagonal in z order, then Qxy
 #pragma unroll
