@@ -425,6 +425,8 @@ struct RowLds {
     __device__ __forceinline__ RowLds(double *base, int N, double *results) : W(base), H(base + WS * N), R(results) {}
 };
 
+__device__ __forceinline__ uint32_t lds_address(const void *p) { return (uint32_t)(uintptr_t)p; }     // low half of a flat LDS address = LDS byte offset
+
 __device__ __forceinline__ void rowpar_factor(int lane, int N, const RowLds L, bool worker_row)
 {
     constexpr int WS = RowLds::WS, HS = RowLds::HS;
@@ -581,6 +583,372 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const RowLds L, b
         stepT(Wb, Pa, T); fetch(t - 2, Wa, Ha); stepM(t - 1, Wb, Hb, T, Pb);      // t - 2 = -1 reads the (dead) block in front
     }
     if (t == 0) { stepT(Wa, Pb, T); stepM(0, Wa, Ha, T, Pa); }
+}
+
+// THE SAME SWEEP AS ONE ASM BLOCK (rowpar_factor_fast; text generated from the three blocks above, identical arithmetic and results).
+// What it saves per stage: the eight accumulator copies (the H~aug column is requested straight INTO the accumulator registers -- inside
+// one block no compiler can touch a register with a load in flight), four address updates, and every wait is counted exactly
+// (s_waitcnt lgkmcnt(7) before a T block: the 4 accumulator requests and 3 stores younger than its W~ operands; lgkmcnt(10) before an M
+// block: 3 stores and the 7 requests of the next stage).  Two stages per loop pass (register sets a / b), the operands of a stage are
+// requested right after the T block of the stage before; an odd horizon ends with a single stage.  Fixed registers v100..v183.
+#define MPC_FACTOR_ASM \
+        "ds_read2_b64 v[116:119], %6 offset0:0 offset1:8\n" \
+        "ds_read2_b64 v[120:123], %6 offset0:16 offset1:24\n" \
+        "ds_read2_b64 v[124:127], %6 offset0:32 offset1:40\n" \
+        "ds_read2_b64 v[144:147], %0 offset0:41 offset1:49\n" \
+        "ds_read2_b64 v[148:151], %0 offset0:57 offset1:65\n" \
+        "ds_read_b64 v[152:153], %0 offset:584\n" \
+        "ds_read2_b64 v[100:103], %1 offset0:65 offset1:73\n" \
+        "ds_read2_b64 v[104:107], %1 offset0:81 offset1:89\n" \
+        "ds_read2_b64 v[108:111], %1 offset0:97 offset1:105\n" \
+        "ds_read2_b64 v[112:115], %1 offset0:113 offset1:121\n" \
+        "s_waitcnt lgkmcnt(0)\n" \
+        "s_nop 4\n" \
+        "s_cmp_eq_u32 %4, 0\n" \
+        "s_cbranch_scc1 2f\n" \
+        "1:\n" \
+        "s_waitcnt lgkmcnt(7)\n" \
+        "v_mul_f64 v[132:133], v[116:117], %5\n" \
+        "v_mul_f64 v[134:135], v[118:119], %5\n" \
+        "v_mul_f64 v[136:137], v[120:121], %5\n" \
+        "v_mul_f64 v[138:139], v[122:123], %5\n" \
+        "v_mul_f64 v[140:141], v[124:125], %5\n" \
+        "v_mul_f64 v[142:143], v[126:127], %5\n" \
+        "s_nop 1\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[144:145] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[116:117], v[144:145] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[116:117], v[144:145] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[116:117], v[144:145] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[116:117], v[144:145] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[116:117], v[144:145] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[146:147] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[118:119], v[146:147] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[118:119], v[146:147] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[118:119], v[146:147] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[118:119], v[146:147] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[118:119], v[146:147] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[148:149] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[118:119], v[148:149] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[120:121], v[148:149] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[120:121], v[148:149] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[120:121], v[148:149] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[120:121], v[148:149] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[118:119], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[120:121], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[122:123], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[122:123], v[150:151] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[122:123], v[150:151] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[118:119], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[120:121], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[122:123], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[124:125], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[124:125], v[152:153] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "ds_read2_b64 v[154:157], %0 offset0:0 offset1:8\n" \
+        "ds_read2_b64 v[158:161], %0 offset0:16 offset1:24\n" \
+        "ds_read_b64 v[162:163], %0 offset:256\n" \
+        "ds_read2_b64 v[116:119], %1 offset0:0 offset1:8\n" \
+        "ds_read2_b64 v[120:123], %1 offset0:16 offset1:24\n" \
+        "ds_read2_b64 v[124:127], %1 offset0:32 offset1:40\n" \
+        "ds_read2_b64 v[128:131], %1 offset0:48 offset1:56\n" \
+        "s_waitcnt lgkmcnt(10)\n" \
+        "s_nop 1\n" \
+        "v_fmac_f64_dpp v[112:113], v[144:145], v[132:133] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[114:115], v[144:145], v[132:133] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[112:113], v[146:147], v[134:135] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[114:115], v[146:147], v[134:135] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[114:115], v[148:149], v[136:137] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[112:113], v[150:151], v[138:139] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[114:115], v[152:153], v[140:141] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[100:101], v[144:145], v[132:133] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[104:105], v[144:145], v[132:133] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_dpp v[174:175], v[112:113] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_dpp v[176:177], v[112:113] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_dpp v[178:179], v[114:115] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[106:107], v[144:145], v[132:133] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_rcp_f64_e32 v[182:183], v[174:175]\n" \
+        "v_fmac_f64_dpp v[108:109], v[144:145], v[132:133] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[174:175], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[110:111], v[144:145], v[132:133] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[182:183], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[102:103], v[146:147], v[134:135] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[174:175], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[104:105], v[146:147], v[134:135] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[168:169], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[106:107], v[146:147], v[134:135] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_mul_f64 v[170:171], v[176:177], v[168:169]\n" \
+        "v_fmac_f64_dpp v[108:109], v[146:147], v[134:135] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[178:179], -v[170:171], v[176:177], v[178:179]\n" \
+        "v_fmac_f64_dpp v[110:111], v[146:147], v[134:135] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_rcp_f64_e32 v[182:183], v[178:179]\n" \
+        "v_fmac_f64_dpp v[104:105], v[148:149], v[136:137] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[178:179], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[108:109], v[148:149], v[136:137] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[182:183], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[110:111], v[148:149], v[136:137] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[178:179], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[106:107], v[150:151], v[138:139] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[172:173], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[110:111], v[150:151], v[138:139] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], v[170:171], v[112:113], -v[114:115]\n" \
+        "v_fmac_f64_dpp v[108:109], v[152:153], v[140:141] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_mul_f64 v[166:167], v[180:181], v[172:173]\n" \
+        "v_mul_f64 v[180:181], v[112:113], v[168:169]\n" \
+        "v_fmac_f64_dpp v[110:111], v[152:153], v[140:141] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[164:165], -v[170:171], v[166:167], -v[180:181]\n" \
+        "v_add_f64 v[110:111], v[110:111], v[142:143]\n" \
+        "ds_write2_b64 %2, v[164:165], v[166:167] offset0:65 offset1:73\n" \
+        "ds_write2_b64 %3, v[168:169], v[170:171] offset0:65 offset1:66\n" \
+        "ds_write_b64 %3, v[172:173] offset:584\n" \
+        "s_nop 1\n" \
+        "v_fmac_f64_dpp v[100:101], v[112:113], v[164:165] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[102:103], v[112:113], v[164:165] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[104:105], v[112:113], v[164:165] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[106:107], v[112:113], v[164:165] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[108:109], v[112:113], v[164:165] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[110:111], v[112:113], v[164:165] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[100:101], v[114:115], v[166:167] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[102:103], v[114:115], v[166:167] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[104:105], v[114:115], v[166:167] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[106:107], v[114:115], v[166:167] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[108:109], v[114:115], v[166:167] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[110:111], v[114:115], v[166:167] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "s_waitcnt lgkmcnt(7)\n" \
+        "v_mul_f64 v[132:133], v[100:101], %5\n" \
+        "v_mul_f64 v[134:135], v[102:103], %5\n" \
+        "v_mul_f64 v[136:137], v[104:105], %5\n" \
+        "v_mul_f64 v[138:139], v[106:107], %5\n" \
+        "v_mul_f64 v[140:141], v[108:109], %5\n" \
+        "v_mul_f64 v[142:143], v[110:111], %5\n" \
+        "s_nop 1\n" \
+        "v_fmac_f64_dpp v[132:133], v[100:101], v[154:155] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[100:101], v[154:155] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[100:101], v[154:155] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[100:101], v[154:155] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[100:101], v[154:155] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[100:101], v[154:155] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[100:101], v[156:157] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[102:103], v[156:157] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[102:103], v[156:157] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[102:103], v[156:157] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[102:103], v[156:157] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[102:103], v[156:157] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[100:101], v[158:159] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[102:103], v[158:159] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[104:105], v[158:159] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[104:105], v[158:159] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[104:105], v[158:159] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[104:105], v[158:159] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[100:101], v[160:161] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[102:103], v[160:161] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[104:105], v[160:161] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[106:107], v[160:161] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[106:107], v[160:161] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[106:107], v[160:161] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[100:101], v[162:163] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[102:103], v[162:163] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[104:105], v[162:163] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[106:107], v[162:163] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[108:109], v[162:163] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[108:109], v[162:163] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_add_u32_e32 %0, 0xfffffd70, %0\n" \
+        "v_add_u32_e32 %1, 0xfffffbf0, %1\n" \
+        "ds_read2_b64 v[144:147], %0 offset0:41 offset1:49\n" \
+        "ds_read2_b64 v[148:151], %0 offset0:57 offset1:65\n" \
+        "ds_read_b64 v[152:153], %0 offset:584\n" \
+        "ds_read2_b64 v[100:103], %1 offset0:65 offset1:73\n" \
+        "ds_read2_b64 v[104:107], %1 offset0:81 offset1:89\n" \
+        "ds_read2_b64 v[108:111], %1 offset0:97 offset1:105\n" \
+        "ds_read2_b64 v[112:115], %1 offset0:113 offset1:121\n" \
+        "s_waitcnt lgkmcnt(10)\n" \
+        "s_nop 1\n" \
+        "v_fmac_f64_dpp v[128:129], v[154:155], v[132:133] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[130:131], v[154:155], v[132:133] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[128:129], v[156:157], v[134:135] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[130:131], v[156:157], v[134:135] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[130:131], v[158:159], v[136:137] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[128:129], v[160:161], v[138:139] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[130:131], v[162:163], v[140:141] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[116:117], v[154:155], v[132:133] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[120:121], v[154:155], v[132:133] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_dpp v[174:175], v[128:129] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_dpp v[176:177], v[128:129] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_dpp v[178:179], v[130:131] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[122:123], v[154:155], v[132:133] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_rcp_f64_e32 v[182:183], v[174:175]\n" \
+        "v_fmac_f64_dpp v[124:125], v[154:155], v[132:133] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[174:175], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[126:127], v[154:155], v[132:133] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[182:183], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[118:119], v[156:157], v[134:135] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[174:175], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[120:121], v[156:157], v[134:135] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[168:169], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[122:123], v[156:157], v[134:135] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_mul_f64 v[170:171], v[176:177], v[168:169]\n" \
+        "v_fmac_f64_dpp v[124:125], v[156:157], v[134:135] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[178:179], -v[170:171], v[176:177], v[178:179]\n" \
+        "v_fmac_f64_dpp v[126:127], v[156:157], v[134:135] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_rcp_f64_e32 v[182:183], v[178:179]\n" \
+        "v_fmac_f64_dpp v[120:121], v[158:159], v[136:137] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[178:179], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[124:125], v[158:159], v[136:137] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[182:183], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[126:127], v[158:159], v[136:137] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[178:179], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[122:123], v[160:161], v[138:139] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[172:173], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[126:127], v[160:161], v[138:139] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], v[170:171], v[128:129], -v[130:131]\n" \
+        "v_fmac_f64_dpp v[124:125], v[162:163], v[140:141] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_mul_f64 v[166:167], v[180:181], v[172:173]\n" \
+        "v_mul_f64 v[180:181], v[128:129], v[168:169]\n" \
+        "v_fmac_f64_dpp v[126:127], v[162:163], v[140:141] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[164:165], -v[170:171], v[166:167], -v[180:181]\n" \
+        "v_add_f64 v[126:127], v[126:127], v[142:143]\n" \
+        "ds_write2_b64 %2, v[164:165], v[166:167] offset0:0 offset1:8\n" \
+        "ds_write2_b64 %3, v[168:169], v[170:171] offset0:0 offset1:1\n" \
+        "ds_write_b64 %3, v[172:173] offset:64\n" \
+        "v_add_u32_e32 %2, 0xfffffbf0, %2\n" \
+        "v_add_u32_e32 %3, 0xfffffbf0, %3\n" \
+        "s_nop 1\n" \
+        "v_fmac_f64_dpp v[116:117], v[128:129], v[164:165] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[118:119], v[128:129], v[164:165] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[120:121], v[128:129], v[164:165] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[122:123], v[128:129], v[164:165] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[124:125], v[128:129], v[164:165] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[126:127], v[128:129], v[164:165] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[116:117], v[130:131], v[166:167] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[118:119], v[130:131], v[166:167] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[120:121], v[130:131], v[166:167] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[122:123], v[130:131], v[166:167] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[124:125], v[130:131], v[166:167] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[126:127], v[130:131], v[166:167] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "s_sub_u32 %4, %4, 1\n" \
+        "s_cmp_lg_u32 %4, 0\n" \
+        "s_cbranch_scc1 1b\n" \
+        "2:\n" \
+        "s_cmp_eq_u32 %7, 0\n" \
+        "s_cbranch_scc1 3f\n" \
+        "s_waitcnt lgkmcnt(7)\n" \
+        "v_mul_f64 v[132:133], v[116:117], %5\n" \
+        "v_mul_f64 v[134:135], v[118:119], %5\n" \
+        "v_mul_f64 v[136:137], v[120:121], %5\n" \
+        "v_mul_f64 v[138:139], v[122:123], %5\n" \
+        "v_mul_f64 v[140:141], v[124:125], %5\n" \
+        "v_mul_f64 v[142:143], v[126:127], %5\n" \
+        "s_nop 1\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[144:145] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[116:117], v[144:145] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[116:117], v[144:145] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[116:117], v[144:145] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[116:117], v[144:145] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[116:117], v[144:145] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[146:147] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[118:119], v[146:147] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[118:119], v[146:147] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[118:119], v[146:147] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[118:119], v[146:147] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[118:119], v[146:147] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[148:149] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[118:119], v[148:149] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[120:121], v[148:149] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[120:121], v[148:149] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[120:121], v[148:149] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[120:121], v[148:149] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[118:119], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[120:121], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[122:123], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[122:123], v[150:151] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[122:123], v[150:151] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[118:119], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[120:121], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[122:123], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[124:125], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[124:125], v[152:153] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "s_waitcnt lgkmcnt(3)\n" \
+        "s_nop 1\n" \
+        "v_fmac_f64_dpp v[112:113], v[144:145], v[132:133] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[114:115], v[144:145], v[132:133] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[112:113], v[146:147], v[134:135] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[114:115], v[146:147], v[134:135] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[114:115], v[148:149], v[136:137] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[112:113], v[150:151], v[138:139] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[114:115], v[152:153], v[140:141] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[100:101], v[144:145], v[132:133] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[104:105], v[144:145], v[132:133] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_dpp v[174:175], v[112:113] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_dpp v[176:177], v[112:113] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_dpp v[178:179], v[114:115] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[106:107], v[144:145], v[132:133] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_rcp_f64_e32 v[182:183], v[174:175]\n" \
+        "v_fmac_f64_dpp v[108:109], v[144:145], v[132:133] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[174:175], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[110:111], v[144:145], v[132:133] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[182:183], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[102:103], v[146:147], v[134:135] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[174:175], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[104:105], v[146:147], v[134:135] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[168:169], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[106:107], v[146:147], v[134:135] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_mul_f64 v[170:171], v[176:177], v[168:169]\n" \
+        "v_fmac_f64_dpp v[108:109], v[146:147], v[134:135] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[178:179], -v[170:171], v[176:177], v[178:179]\n" \
+        "v_fmac_f64_dpp v[110:111], v[146:147], v[134:135] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_rcp_f64_e32 v[182:183], v[178:179]\n" \
+        "v_fmac_f64_dpp v[104:105], v[148:149], v[136:137] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[178:179], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[108:109], v[148:149], v[136:137] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[182:183], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[110:111], v[148:149], v[136:137] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[178:179], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[106:107], v[150:151], v[138:139] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[172:173], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[110:111], v[150:151], v[138:139] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], v[170:171], v[112:113], -v[114:115]\n" \
+        "v_fmac_f64_dpp v[108:109], v[152:153], v[140:141] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_mul_f64 v[166:167], v[180:181], v[172:173]\n" \
+        "v_mul_f64 v[180:181], v[112:113], v[168:169]\n" \
+        "v_fmac_f64_dpp v[110:111], v[152:153], v[140:141] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[164:165], -v[170:171], v[166:167], -v[180:181]\n" \
+        "v_add_f64 v[110:111], v[110:111], v[142:143]\n" \
+        "ds_write2_b64 %2, v[164:165], v[166:167] offset0:65 offset1:73\n" \
+        "ds_write2_b64 %3, v[168:169], v[170:171] offset0:65 offset1:66\n" \
+        "ds_write_b64 %3, v[172:173] offset:584\n" \
+        "s_nop 1\n" \
+        "v_fmac_f64_dpp v[100:101], v[112:113], v[164:165] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[102:103], v[112:113], v[164:165] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[104:105], v[112:113], v[164:165] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[106:107], v[112:113], v[164:165] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[108:109], v[112:113], v[164:165] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[110:111], v[112:113], v[164:165] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[100:101], v[114:115], v[166:167] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[102:103], v[114:115], v[166:167] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[104:105], v[114:115], v[166:167] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[106:107], v[114:115], v[166:167] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[108:109], v[114:115], v[166:167] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[110:111], v[114:115], v[166:167] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "3:\n" \
+        "s_waitcnt lgkmcnt(0)\n"
+
+#define MPC_FACTOR_ASM_CLOBBERS "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "scc", "vcc", "memory"
+
+__device__ __forceinline__ void rowpar_factor_fast(int lane, int N, const RowLds L, bool worker_row)
+{
+    constexpr int WS = RowLds::WS, HS = RowLds::HS;
+    const int j = lane & 7, l15 = lane & 15;
+    const bool store = worker_row && l15 < 6, store0 = worker_row && l15 == 0;
+    const double d5 = (j == 5) ? 1.0 : 0.0;
+    // base pointers: the LOWER stage of the first pair (stage N - 2; the upper one sits one block above, as an immediate offset)
+    uint32_t wp = lds_address(L.W + j + WS * (N - 2)), hp = lds_address(L.H + j + HS * (N - 2));
+    uint32_t kp = lds_address(L.R + (store ? j : 48) + HS * (N - 2)), fp = lds_address(L.R + (store0 ? 6 : 50) + HS * (N - 2));
+    const uint32_t hN = lds_address(L.H + j + HS * N);
+    int passes = N >> 1;
+    const int odd = N & 1;
+    asm volatile(MPC_FACTOR_ASM : "+v"(wp), "+v"(hp), "+v"(kp), "+v"(fp), "+s"(passes) : "v"(d5), "v"(hN), "s"(odd) : MPC_FACTOR_ASM_CLOBBERS);
 }
 
 // ROW-PARALLEL VECTOR RECURSIONS.  With the closed-loop matrix Acl_t = A_t + B_t K_t (5 x 5, computed by the lane that owns
@@ -786,8 +1154,6 @@ __device__ __forceinline__ void rowpar_vector(int lane, int N, const RowLds L, b
         "s_waitcnt lgkmcnt(0)\n"
 
 #define MPC_VEC_ASM_CLOBBERS "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v228", "v229", "v230", "v231", "scc", "memory"
-
-__device__ __forceinline__ uint32_t lds_address(const void *p) { return (uint32_t)(uintptr_t)p; }     // low half of a flat LDS address = LDS byte offset
 
 template <bool FWD>
 __device__ __forceinline__ void rowpar_vector_fast(int lane, int N, const RowLds L, bool worker_row)
@@ -1332,7 +1698,11 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 }
                 __syncthreads();
                 MPC_TICK(9);
+#ifdef MPC_FACTOR_PLAIN
                 rowpar_factor(lane, N, RL, i < 16);
+#else
+                rowpar_factor_fast(lane, N, RL, i < 16);
+#endif
                 __syncthreads();
                 F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;
 #pragma unroll
