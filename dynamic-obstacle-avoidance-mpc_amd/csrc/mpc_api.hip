@@ -108,16 +108,18 @@ int pick_lanes(mpc_handle *h, int batch)
     return G;
 }
 
-// Lanes per horizon stage.  A batch of at most one instance per SIMD of the chip cannot fill the machine by packing instances
-// into wavefronts; each wavefront is then bound by the length of its own instruction stream, and dealing the inequality rows
-// of a stage out to 3 (N <= 20) or 2 (N <= 31) lanes shortens that stream (rti_split_kernel.hpp).  Larger batches keep one lane
-// per stage and 64/G instances per wavefront.
+// Lanes per horizon stage.  A batch of about one instance per SIMD cannot fill the machine by packing instances into wavefronts; each
+// wavefront is then bound by the length of its own instruction stream, and dealing the inequality rows of a stage out to 3 (N <= 20)
+// or 2 (N <= 31) lanes shortens that stream (rti_split_kernel.hpp).  With one instance per wavefront every instance also stops at its
+// own iteration, so the mapping keeps winning while the batch is a few waves of wavefronts deep -- measured on the randomized C3
+// workload (scripts/split_at_scale.py): +26 % at 1536, +15 % at 2048, +13 % at 4096, +3 % at 8192, -7 % at 16384, -16 % at 65536.
+// Larger batches keep one lane per stage and 64/G instances per wavefront.
 int pick_split(mpc_handle *h, int batch)
 {
     if (h->use_mfma || !h->row_parallel || h->lanes_override) return 1;
     const int N = h->cfg.N;
     const int fit = N <= 20 ? 3 : (N <= 31 ? 2 : 1);
-    if (h->split_override == 0) return batch <= h->simd_count ? fit : 1;
+    if (h->split_override == 0) return batch <= 8 * h->simd_count ? fit : 1;
     return h->split_override <= fit ? h->split_override : fit;
 }
 

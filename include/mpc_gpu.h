@@ -183,11 +183,12 @@ int mpc_set_matrix_cores(mpc_handle *h, int on);
  * 0: one-lane systolic sweeps (no LDS), the independent implementation the default is tested against.
  * No reference counterpart (tuning / test hook). */
 int mpc_set_row_parallel(mpc_handle *h, int on);
-/* Lanes per horizon stage.  0 (default): automatic -- a batch of at most one instance per SIMD of the device (1024 on
+/* Lanes per horizon stage.  0 (default): automatic -- a batch of at most eight instances per SIMD of the device (8192 on
  * MI355X) runs one instance per wavefront with the inequality rows of every stage dealt out to 3 (N <= 20) or 2 (N <= 31)
- * neighbouring lanes, which shortens the instruction stream such a latency-bound wavefront is limited by; larger batches
- * keep one lane per stage and pack 64/G instances into a wavefront.  1: always one lane per stage.  2 / 3: the split
- * mapping whenever the horizon fits (any batch).  Setting lanes per INSTANCE, matrix cores or the systolic sweep implies 1.
+ * neighbouring lanes, which shortens the instruction stream such a latency-bound wavefront is limited by (and lets every
+ * instance stop at its own iteration); larger batches keep one lane per stage and pack 64/G instances into a wavefront
+ * (measured crossover between 8192 and 16384 instances).  1: always one lane per stage.  2 / 3: the split mapping whenever
+ * the horizon fits (any batch).  Setting lanes per INSTANCE, matrix cores or the systolic sweep implies 1.
  * Same arithmetic specification either way.  No reference counterpart (tuning / test hook). */
 int mpc_set_lanes_per_stage(mpc_handle *h, int lanes);
 int mpc_get_lanes_per_stage(mpc_handle *h, int batch);

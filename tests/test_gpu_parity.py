@@ -382,7 +382,7 @@ def test_stage_split_is_the_automatic_choice_for_small_batches_only(env):
     try:
         with mpc_gpu.BatchedMpc(20, 3, 2.0, max_batch=70000) as s:
             assert s.lanes_per_stage(1) == 3 and s.lanes_per_stage(1024) == 3 and s.lanes_per_instance(1024) == 64
-            assert s.lanes_per_stage(1025) == 1 and s.lanes_per_instance(65536) == 32
+            assert s.lanes_per_stage(8192) == 3 and s.lanes_per_stage(8193) == 1 and s.lanes_per_instance(65536) == 32
             s.set_lanes_per_instance(64)
             assert s.lanes_per_stage(8) == 1
         with mpc_gpu.BatchedMpc(31, 3, 3.1, max_batch=8) as s:
