@@ -9,7 +9,7 @@ Workload (default, BASELINE.json configs[1] = "C2"): batch = 1024 identical scen
 `--workload c3` runs 65536 randomized scenarios instead.
 
 N > 1 GPUs (launched by torch.distributed.run, one rank per GPU): the batch is replicated per rank (weak scaling, no
-data-path collective); the per-scenario costs are all-gathered over RCCL on a side stream, 25 control steps per message.
+data-path collective); the per-scenario costs are all-gathered over RCCL on a side stream, 50 control steps per message.
 """
 import argparse
 import json
@@ -231,7 +231,7 @@ def main():
     # on a side stream.  Not every step: at batch 1024 the solve kernel fills every SIMD of the chip with exactly one 512-register
     # wavefront, so any kernel running beside it (the collective's) holds back the workgroups of the CUs it occupies -- one message
     # of GATHER_EVERY x 8 KB per rank costs that once instead of GATHER_EVERY times.
-    GATHER_EVERY = 25
+    GATHER_EVERY = 50
     # (the kernel writes each step's costs straight into its row of the history; two histories alternate, so that one can be in
     # flight while the next fills)
     cost_hist = torch.zeros(2, GATHER_EVERY, batch, dtype=torch.float64, device=dev) if world > 1 else None
@@ -315,7 +315,7 @@ def main():
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": desc, "per_gpu_batch": batch, "N": N, "n_obst": no, "qp_tol": 1e-8, "qp_iter_max": 50,
                       "step": "one fused launch: obstacle look-ahead + RTI solve + plant step + obstacle motion + warm-start shift, device resident; episodes of 100 control steps",
-                      "parallelism": f"replicas x{world}, cost all-gather (RCCL, 25 control steps per message)" if world > 1 else "single GPU"},
+                      "parallelism": f"replicas x{world}, cost all-gather (RCCL, 50 control steps per message)" if world > 1 else "single GPU"},
            "mean_ipm_iters": mean_iters, "qp_failure_frac": float((st_acc % 65536).double().sum().item()) / (batch * args.steps),
            "qp_iter_cap_frac": float((st_acc // 65536).double().sum().item()) / (batch * args.steps),
            "lanes_per_instance": lanes, "lanes_per_stage": lps, "roofline": roof}
