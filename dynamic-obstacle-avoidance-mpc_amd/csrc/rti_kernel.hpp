@@ -65,6 +65,7 @@ struct KParams {
     double slack_a, slack_b, ss;  // ss: penalty scale for stages < N (dt or 1)
     double tol, mu0, thr0;
     const double *x0, *P, *goal;
+    const double *alpha;      // optional [B][N+1]: explicit slack weights zl_i = Zl_i (mpc_set_slack_schedule); null = the schedule of robot_ocp_problem.py:145-148
     double *X, *U, *u0, *cost;
     int32_t *status, *iters;
     int32_t *iters_acc, *status_acc;   // optional running sums over launches: IPM iterations; (status == 4) + 65536 * (status == 2)
@@ -1422,7 +1423,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     {
         const double ex = x0v[0] - gl[0], ey = x0v[1] - gl[1];
         const double scale = p.slack_a * (ex * ex + ey * ey + x0v[3] * x0v[3] + x0v[4] * x0v[4] + p.slack_b);
-        const double alpha_i = scale * (double)(N - i) / (double)N;
+        const double alpha_i = p.alpha ? p.alpha[(size_t)inst * (N + 1) + (act ? i : N)] : scale * (double)(N - i) / (double)N;
         zpen = alpha_i * (has_u ? p.ss : 1.0);
     }
     const bool vs = act && (i >= 1) && (p.soft_h ? (zpen > 0.0) : true);   // obstacle rows present at this stage

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
     {
         const double ex = x0v[0] - gl[0], ey = x0v[1] - gl[1];
         const double scale = p.slack_a * (ex * ex + ey * ey + x0v[3] * x0v[3] + x0v[4] * x0v[4] + p.slack_b);
-        const double alpha_i = scale * (double)(N - i) / (double)N;
+        const double alpha_i = p.alpha ? p.alpha[(size_t)inst * (N + 1) + (act ? i : N)] : scale * (double)(N - i) / (double)N;
         zpen = alpha_i * (has_u ? p.ss : 1.0);
     }
     const bool vs = act && (i >= 1) && (p.soft_h ? (zpen > 0.0) : true);

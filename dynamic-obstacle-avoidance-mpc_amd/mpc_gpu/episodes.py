@@ -17,11 +17,13 @@ from .solver import BatchedMpc
 
 
 def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, init_guess_when_error=True,
-                 bug_compat_alias=True, seed=0, device=0, solver=None, n_obst=5, first_seed=0, record=False, **cfg):
+                 bug_compat_alias=True, seed=0, device=0, solver=None, n_obst=5, first_seed=0, record=False, noise=None, **cfg):
     """x0 (B,5), goal (B,2), obst (B,n_obst,4) -- or a scenario name ("RANDOM" | "CENTER" | "EDGE"): instance s then starts
     from the reference generator's draw for np.random.seed(first_seed + s), produced on the device (experiments.py:26-29).
     record=True also returns simX (steps+1,B,5), obst_traj (steps+1,B,n_obst,4) and pred (steps,B,N+1,5): what the reference keeps
     for its visualisation (robot_ocp_problem.py:232-240,270-276).
+    noise: None -> standard normals from torch's generator (`seed`); an array (steps, B, n_obst, 2) -> exactly these normals, control step
+    k using noise[k] (world.reference_streams gives the sequences the reference's own runs consumed, per seed).
     Returns dict(table (B,6), x_last (B,5), steps_run, solves)."""
     import torch
     x0 = np.ascontiguousarray(x0, dtype=np.float64); B = x0.shape[0]
@@ -48,11 +50,22 @@ def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, i
         if init_guess_when_error:
             fl |= _lib.STEP_RESET_ON_FAIL | (_lib.STEP_ALIAS_BUG if bug_compat_alias else 0)
         gen = torch.Generator(device=dev); gen.manual_seed(seed)
+        dnoise = None
+        if noise is not None and random_move:
+            noise = np.ascontiguousarray(noise, dtype=np.float64)
+            if noise.shape[1:] != (B, n_obst, 2) or noise.shape[0] < max_iter:
+                raise ValueError(f"noise must be (>= {max_iter}, {B}, {n_obst}, 2), got {noise.shape}")
+            dnoise = torch.from_numpy(noise).to(dev)
         k = 0
         rec_x, rec_o, rec_p = [dx0.clone()], [dobst.clone()], []
         while k < max_iter:
-            noise = torch.randn(B, n_obst, 2, dtype=torch.float64, device=dev, generator=gen) if random_move else None
-            m.closed_loop_step_dev(B, dx0, dobst, dgoal, X, U, None, None, status, iters, noise, flags=fl,
+            if not random_move:
+                nz = None
+            elif dnoise is not None:
+                nz = dnoise[k]
+            else:
+                nz = torch.randn(B, n_obst, 2, dtype=torch.float64, device=dev, generator=gen)
+            m.closed_loop_step_dev(B, dx0, dobst, dgoal, X, U, None, None, status, iters, nz, flags=fl,
                                    min_margin=margin, ep_flags=flags, ep_steps=steps, stream=s)
             k += 1
             if record:      # X holds the shifted prediction: stage j of the solve is X[j - 1], stage N is kept (:253-258)

@@ -127,3 +127,20 @@ def obstacle_states(obstacles):
     if obstacles and hasattr(obstacles[0], "vx"):
         return np.array([[o.x, o.y, o.vx, o.vy] for o in obstacles], dtype=np.float64)
     return np.ascontiguousarray(obstacles, dtype=np.float64)
+
+
+def reference_streams(scenario, seeds, n_obst=N_OBST, steps=400):
+    """What the reference's experiment loop draws from numpy's global legacy stream for each seed i (experiments.py:33-36):
+    after np.random.seed(i) the generator's uniform blocks (obstacle_generator.py:10-22: x, y for RANDOM only, then vx, vy), then
+    one np.random.normal(size=2) per obstacle per control step in `for o in self.obstacles: o.step()` (robot_ocp_problem.py:217-218,
+    visualization.py:31).  The legacy Gaussian generator hands out its pairs in order, so one normal(size=(steps, n_obst, 2)) call is
+    that sequence.  Plain numpy, no reference code: reproducible on any box.
+    Returns obst (S, n_obst, 4) and noise (steps, S, n_obst, 2) -- the layout mpc_closed_loop_step_dev takes per control step."""
+    seeds = list(seeds)
+    obst = np.zeros((len(seeds), n_obst, 4))
+    noise = np.zeros((steps, len(seeds), n_obst, 2))
+    for k, seed in enumerate(seeds):
+        rs = np.random.RandomState(int(seed))
+        obst[k] = np.array([o.state for o in generate_random_moving_obstacles(scenario, True, n_obst=n_obst, rng=rs)])
+        noise[:, k] = rs.normal(size=(steps, n_obst, 2))
+    return obst, noise

@@ -353,13 +353,15 @@ void orc_linearize(const orc_config *c, const double *x0, const double *P, const
     }
 }
 
-double orc_cost(const orc_config *c, const double *x0, const double *P, const double *goal,
-                const double *X, const double *U)
+/* alpha_in: explicit per-stage slack weights zl_i = Zl_i (what a caller of cost_set(i,'zl'/'Zl') supplies, robot_ocp_problem.py:149-152),
+ * or NULL for the reference's own schedule of :145-148 */
+static double cost_with_alpha(const orc_config *c, const double *x0, const double *P, const double *goal,
+                              const double *X, const double *U, const double *alpha_in)
 {
     int N = c->N, no = c->n_obst; double cs = stage_cs(c), ss = stage_ss(c);
     double *alpha = (double *)malloc(sizeof(double) * (N + 1));
     double *h = (double *)malloc(sizeof(double) * no);
-    orc_slack_alpha(c, x0, goal, alpha);
+    if (alpha_in) memcpy(alpha, alpha_in, sizeof(double) * (N + 1)); else orc_slack_alpha(c, x0, goal, alpha);
     double J = 0;
     for (int i = 0; i <= N; i++) {
         const double *x = X + 5 * i;
@@ -380,6 +382,12 @@ double orc_cost(const orc_config *c, const double *x0, const double *P, const do
     }
     free(alpha); free(h);
     return J;
+}
+
+double orc_cost(const orc_config *c, const double *x0, const double *P, const double *goal,
+                const double *X, const double *U)
+{
+    return cost_with_alpha(c, x0, P, goal, X, U, NULL);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -421,7 +429,7 @@ static void add_box(qp_t *Q, int stage, int zidx, double val, double lo, double 
 
 /* Build the QP of one RTI step */
 static void build_qp(const orc_config *c, const double *x0, const double *P, const double *goal,
-                     const double *X, const double *U, qp_t *Q)
+                     const double *X, const double *U, qp_t *Q, const double *alpha_in)
 {
     int N = c->N, no = c->n_obst; double dt = c->Tf / N;
     Q->N = N;
@@ -433,7 +441,7 @@ static void build_qp(const orc_config *c, const double *x0, const double *P, con
     Q->s_stage = malloc(sizeof(int) * (N + 1) * no); Q->n_s = 0;
     double *alpha = malloc(sizeof(double) * (N + 1));
     double *h = malloc(sizeof(double) * no), *dh = malloc(sizeof(double) * 2 * no);
-    orc_slack_alpha(c, x0, goal, alpha);
+    if (alpha_in) memcpy(alpha, alpha_in, sizeof(double) * (N + 1)); else orc_slack_alpha(c, x0, goal, alpha);
     for (int k = 0; k < 5; k++) Q->d0[k] = x0[k] - X[k];    /* lbx_0 = ubx_0 = x0, robot_ocp_problem.py:191-192 */
     for (int i = 0; i < N; i++) {
         double xn[5];
@@ -752,11 +760,11 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
 }
 
 /* robot_ocp_problem.py:186-198 around ocp_solver.solve(): one SQP_RTI iteration = QP + full step */
-int orc_rti_solve(const orc_config *c, const double *x0, const double *P, const double *goal,
-                  double *X, double *U, double *u0, double *cost, int *iters, double *kkt)
+int orc_rti_solve_alpha(const orc_config *c, const double *x0, const double *P, const double *goal, const double *alpha,
+                        double *X, double *U, double *u0, double *cost, int *iters, double *kkt)
 {
     int N = c->N;
-    qp_t Q; build_qp(c, x0, P, goal, X, U, &Q);
+    qp_t Q; build_qp(c, x0, P, goal, X, U, &Q, alpha);
     iter_t I;
     I.z = malloc(sizeof(double[NZ]) * (N + 1)); I.pi = malloc(sizeof(double[NX]) * (N + 1)); I.s = malloc(sizeof(double) * (Q.n_s + 1));
     int status = ipm_solve(c, &Q, &I, iters, kkt);
@@ -765,9 +773,15 @@ int orc_rti_solve(const orc_config *c, const double *x0, const double *P, const 
         for (int i = 0; i < N; i++) for (int k = 0; k < 2; k++) U[2 * i + k] += I.z[i][k];
     }
     if (u0) { u0[0] = U[0]; u0[1] = U[1]; }
-    if (cost) *cost = orc_cost(c, x0, P, goal, X, U);
+    if (cost) *cost = cost_with_alpha(c, x0, P, goal, X, U, alpha);
     free(I.z); free(I.pi); free(I.s); qp_free(&Q);
     return status;
+}
+
+int orc_rti_solve(const orc_config *c, const double *x0, const double *P, const double *goal,
+                  double *X, double *U, double *u0, double *cost, int *iters, double *kkt)
+{
+    return orc_rti_solve_alpha(c, x0, P, goal, NULL, X, U, u0, cost, iters, kkt);
 }
 
 void orc_rti_solve_batch(const orc_config *c, int batch, const double *x0, const double *P, const double *goal,
@@ -795,7 +809,7 @@ int orc_export_qp(const orc_config *c, const double *x0, const double *P, const 
                   double *Cs, double *hs, double *zs, double *Zs)
 {
     int N = c->N; int nv = 7 * N;
-    qp_t Q; build_qp(c, x0, P, goal, X, U, &Q);
+    qp_t Q; build_qp(c, x0, P, goal, X, U, &Q, NULL);
     /* variable map: du_i -> 7i + {0,1} ; dx_i (i>=1) -> 7(i-1) + 2 + k */
     memset(H, 0, sizeof(double) * nv * nv); memset(g, 0, sizeof(double) * nv);
     memset(Aeq, 0, sizeof(double) * 5 * N * nv); memset(beq, 0, sizeof(double) * 5 * N);

@@ -102,6 +102,11 @@ double orc_cost(const orc_config *c, const double *x0, const double *P, const do
 int orc_rti_solve(const orc_config *c, const double *x0, const double *P, const double *goal,
                   double *X, double *U, double *u0, double *cost, int *iters, double *kkt);
 
+/* the same with explicit per-stage slack weights alpha[N+1] (zl_i = Zl_i = alpha_i, what the reference uploads with
+ * cost_set(i,'zl'/'Zl'), robot_ocp_problem.py:149-152); alpha = NULL is orc_rti_solve */
+int orc_rti_solve_alpha(const orc_config *c, const double *x0, const double *P, const double *goal, const double *alpha,
+                        double *X, double *U, double *u0, double *cost, int *iters, double *kkt);
+
 /* batched driver (OpenMP over instances); arrays are [batch][...] contiguous. */
 void orc_rti_solve_batch(const orc_config *c, int batch, const double *x0, const double *P, const double *goal,
                          double *X, double *U, double *u0, double *cost, int *status, int *iters,

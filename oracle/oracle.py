@@ -59,6 +59,8 @@ def lib():
         L.orc_cost.restype = _d
         L.orc_rti_solve.argtypes = [cp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _dp]
         L.orc_rti_solve.restype = C.c_int
+        L.orc_rti_solve_alpha.argtypes = [cp, _dp, _dp, _dp, C.c_void_p, _dp, _dp, _dp, _dp, _ip, _dp]
+        L.orc_rti_solve_alpha.restype = C.c_int
         L.orc_rti_solve_batch.argtypes = [cp, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int]
         L.orc_export_qp.argtypes = [cp] + [_dp] * 15
         L.orc_export_qp.restype = C.c_int
@@ -143,11 +145,13 @@ def cost(cfg, x0, P, goal, X, U):
     return lib().orc_cost(C.byref(cfg), _a(x0), _a(P), _a(goal), _a(X), _a(U))
 
 
-def rti_solve(cfg, x0, P, goal, X, U):
-    """One RTI step.  Returns dict(X, U, u0, cost, status, iters, kkt)."""
+def rti_solve(cfg, x0, P, goal, X, U, alpha=None):
+    """One RTI step.  alpha: explicit slack weights zl_i = Zl_i per stage (N+1,), default the reference's schedule.
+    Returns dict(X, U, u0, cost, status, iters, kkt)."""
     X, U = _a(X).copy(), _a(U).copy()
     u0, cst, it, kkt = np.zeros(2), np.zeros(1), np.zeros(1, np.int32), np.zeros(4)
-    st = lib().orc_rti_solve(C.byref(cfg), _a(x0), _a(P), _a(goal), X, U, u0, cst, it, kkt)
+    al = None if alpha is None else _a(alpha)
+    st = lib().orc_rti_solve_alpha(C.byref(cfg), _a(x0), _a(P), _a(goal), None if al is None else al.ctypes.data, X, U, u0, cst, it, kkt)
     return dict(X=X, U=U, u0=u0, cost=float(cst[0]), status=int(st), iters=int(it[0]), kkt=kkt)
 
 

@@ -102,9 +102,11 @@ def main():
         stem = os.path.basename(f).replace("_experiment_data.csv", "")
         d = np.loadtxt(f, delimiter=";")
         spec = json.load(open(f.replace("_data.csv", "_spec.json")))
+        # rows: the full 100 x 6 table (data the reference holds: [hit, reached, min_margin, dist_to_goal, iters, out_of_bounds] per seed,
+        # robot_ocp_problem.py:277 sliced [1:] at experiments.py:36), so that closed loops can be replayed PER SEED
         tables[stem] = dict(spec=spec, hit=float(d[:, 0].mean()), reached=float(d[:, 1].mean()),
                             mean_iters=float(d[:, 4].mean()), oob=float(d[:, 5].mean()),
-                            min_margin_mean=float(d[:, 2].mean()), rows_0_4=d[:5].tolist())
+                            min_margin_mean=float(d[:, 2].mean()), rows_0_4=d[:5].tolist(), rows=d.tolist())
     json.dump(dict(constants=consts, tables=tables), open(os.path.join(OUT, "reference_tables.json"), "w"), indent=1)
     print("wrote", {k: v.shape for k, v in out.items()})
 
