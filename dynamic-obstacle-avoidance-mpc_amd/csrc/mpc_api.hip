@@ -47,6 +47,8 @@ struct mpc_handle {
     int launch_count;
     double *d_trace;                  // optional debug trace buffer (mpc_debug_trace)
     int32_t *d_iters_acc, *d_status_acc;   // optional accumulators (mpc_set_accumulators)
+    double *d_alpha_own;              // handle-owned copy of a host slack schedule (mpc_set_slack_schedule)
+    const double *d_alpha;            // slack schedule in effect: d_alpha_own, a caller's device array, or null (the reference's formula)
     std::vector<hipEvent_t> ev_start, ev_stop;
     int ev_used;
 };
@@ -123,27 +125,54 @@ int pick_split(mpc_handle *h, int batch)
     return h->split_override <= fit ? h->split_override : fit;
 }
 
-template <int NO, int LPS>
-int launch_split(mpc_handle *, const mpc::KParams &p, hipStream_t s)
+// More than 64 KB of dynamic LDS has to be granted per kernel function and device; the grant is remembered (largest size so far per
+// kernel and device) instead of being re-issued on every launch.
+constexpr int kMaxDevices = 64;
+template <typename K>
+int grant_lds(K kernel, int (&granted)[kMaxDevices], int device, size_t lds)
 {
+    if (lds <= 65536) return MPC_OK;
+    const int d = device < kMaxDevices ? device : kMaxDevices - 1;
+    if (device < kMaxDevices && granted[d] >= (int)lds) return MPC_OK;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    granted[d] = (int)lds;
+    return MPC_OK;
+}
+
+template <int NO, int LPS>
+int launch_split(mpc_handle *h, const mpc::KParams &p, hipStream_t s)
+{
+    static int granted[kMaxDevices] = {};
     const size_t lds = (size_t)mpc::SplitLds<LPS, NO>::total(p.N, p.obst != nullptr) * sizeof(double);
-    if (lds > 65536) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&mpc::rti_split_kernel<NO, LPS>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int rc = grant_lds(&mpc::rti_split_kernel<NO, LPS>, granted, h->device, lds); if (rc) return rc;
     hipLaunchKernelGGL((mpc::rti_split_kernel<NO, LPS>), dim3(p.batch), dim3(64), lds, s, p);
     return MPC_OK;
 }
 
-int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
+template <int NO, int G, int FACT>
+int launch_one_lane(mpc_handle *h, const mpc::KParams &p, hipStream_t s, dim3 grid, size_t lds)
 {
-    p.iters_acc = h->d_iters_acc; p.status_acc = h->d_status_acc;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->profiling && (h->launch_count++ % h->profiling) == 0 && h->ev_used < (int)h->ev_start.size()) {   // pool is created by mpc_profile_enable, never here
-        e0 = h->ev_start[h->ev_used]; e1 = h->ev_stop[h->ev_used]; h->ev_used++;
-        HIPCHK(hipEventRecord(e0, s));
-    }
+    static int granted[kMaxDevices] = {};
+    int rc = grant_lds(&mpc::rti_solve_kernel<NO, G, FACT>, granted, h->device, lds); if (rc) return rc;
+    hipLaunchKernelGGL((mpc::rti_solve_kernel<NO, G, FACT>), grid, dim3(64), lds, s, p);
+    return MPC_OK;
+}
+
+template <int NO>
+int launch_one_lane_g(mpc_handle *h, const mpc::KParams &p, hipStream_t s, dim3 grid, size_t lds, int G, bool use_mfma, bool rowpar)
+{
+    if (G == 16) return rowpar ? launch_one_lane<NO, 16, 2>(h, p, s, grid, lds) : launch_one_lane<NO, 16, 0>(h, p, s, grid, lds);
+    if (G == 32) return rowpar ? launch_one_lane<NO, 32, 2>(h, p, s, grid, lds) : launch_one_lane<NO, 32, 0>(h, p, s, grid, lds);
+    if (use_mfma) return launch_one_lane<NO, 64, 1>(h, p, s, grid, lds);
+    return rowpar ? launch_one_lane<NO, 64, 2>(h, p, s, grid, lds) : launch_one_lane<NO, 64, 0>(h, p, s, grid, lds);
+}
+
+// picks the lane mapping and launches; no event handling here
+int dispatch_solve(mpc_handle *h, const mpc::KParams &p, hipStream_t s)
+{
     const int lps = pick_split(h, p.batch);
+    int rc = MPC_OK;
     if (lps > 1) {
-        int rc = MPC_OK;
         switch (h->cfg.n_obst * 10 + lps) {
         case 32: rc = launch_split<3, 2>(h, p, s); break;
         case 33: rc = launch_split<3, 3>(h, p, s); break;
@@ -153,35 +182,65 @@ int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
         case 103: rc = launch_split<10, 3>(h, p, s); break;
         default: return fail(MPC_ERR_ARG, "n_obst must be 3, 5 or 10");
         }
-        if (rc) return rc;
-        HIPCHK(hipGetLastError());
-        if (e1) HIPCHK(hipEventRecord(e1, s));
-        return MPC_OK;
+    } else {
+        const int G = pick_lanes(h, p.batch);
+        const dim3 grid((p.batch + 64 / G - 1) / (64 / G));
+        const bool use_mfma = (G == 64) && h->use_mfma;
+        const bool rowpar = !use_mfma && h->row_parallel;
+        const size_t lds = ((p.obst ? (size_t)(64 / G) * (p.N + 1) * h->cfg.n_obst * 2 : 0) + (use_mfma ? (size_t)mpc::MfmaLds::doubles(p.N) : 0) +
+                            (rowpar ? (size_t)mpc::RowLds::total(p.N, 64 / G) : 0)) * sizeof(double);
+        switch (h->cfg.n_obst) {
+        case 3: rc = launch_one_lane_g<3>(h, p, s, grid, lds, G, use_mfma, rowpar); break;
+        case 5: rc = launch_one_lane_g<5>(h, p, s, grid, lds, G, use_mfma, rowpar); break;
+        case 10: rc = launch_one_lane_g<10>(h, p, s, grid, lds, G, use_mfma, rowpar); break;
+        default: return fail(MPC_ERR_ARG, "n_obst must be 3, 5 or 10");
+        }
     }
-    const int G = pick_lanes(h, p.batch);
-    const dim3 grid((p.batch + 64 / G - 1) / (64 / G)), block(64);
-    const bool use_mfma = (G == 64) && h->use_mfma;
-    const bool rowpar = !use_mfma && h->row_parallel;
-    const size_t lds = ((p.obst ? (size_t)(64 / G) * (p.N + 1) * h->cfg.n_obst * 2 : 0) + (use_mfma ? (size_t)mpc::MfmaLds::doubles(p.N) : 0) +
-                        (rowpar ? (size_t)mpc::RowLds::total(p.N, 64 / G) : 0)) * sizeof(double);
-    // more than 64 KB of dynamic LDS (long horizons with 10 obstacles) has to be granted per kernel function
-#define MPC_LAUNCH(NO, GG, MF) do { \
-        if (lds > 65536) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&mpc::rti_solve_kernel<NO, GG, MF>), \
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((mpc::rti_solve_kernel<NO, GG, MF>), grid, block, lds, s, p); } while (0)
-#define MPC_LAUNCH_G(NO) do { if (G == 16) { if (rowpar) MPC_LAUNCH(NO, 16, 2); else MPC_LAUNCH(NO, 16, 0); } \
-                              else if (G == 32) { if (rowpar) MPC_LAUNCH(NO, 32, 2); else MPC_LAUNCH(NO, 32, 0); } \
-                              else if (use_mfma) MPC_LAUNCH(NO, 64, 1); else if (rowpar) MPC_LAUNCH(NO, 64, 2); else MPC_LAUNCH(NO, 64, 0); } while (0)
-    switch (h->cfg.n_obst) {
-    case 3: MPC_LAUNCH_G(3); break;
-    case 5: MPC_LAUNCH_G(5); break;
-    case 10: MPC_LAUNCH_G(10); break;
-    default: return fail(MPC_ERR_ARG, "n_obst must be 3, 5 or 10");
-    }
-#undef MPC_LAUNCH_G
-#undef MPC_LAUNCH
+    if (rc) return rc;
     HIPCHK(hipGetLastError());
-    if (e1) HIPCHK(hipEventRecord(e1, s));
+    return MPC_OK;
+}
+
+int create_resources(mpc_handle *h)
+{
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, h->device));
+    h->simd_count = 4 * prop.multiProcessorCount;
+    const size_t B = (size_t)h->max_batch, N = (size_t)h->cfg.N, no = (size_t)h->cfg.n_obst;
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc(&h->dX, B * (N + 1) * 5 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->dU, B * N * 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_x0, B * 5 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_P, B * (N + 1) * no * 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_goal, B * 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_obst, B * no * 4 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_u0, B * 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_cost, B * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_xa, B * 5 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_ua, B * 2 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_xb, B * 5 * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_status, B * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&h->d_iters, B * sizeof(int32_t)));
+    HIPCHK(hipMemsetAsync(h->dX, 0, B * (N + 1) * 5 * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->dU, 0, B * N * 2 * sizeof(double), h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPC_OK;
+}
+
+int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
+{
+    p.iters_acc = h->d_iters_acc; p.status_acc = h->d_status_acc;
+    p.alpha = h->d_alpha;
+    // profiling: a start / stop event pair from the pool (created by mpc_profile_enable, never here) around every k-th launch; the pair
+    // counts only when both records and the launch between them succeeded
+    const bool timed = h->profiling && (h->launch_count++ % h->profiling) == 0 && h->ev_used < (int)h->ev_start.size();
+    if (timed) HIPCHK(hipEventRecord(h->ev_start[h->ev_used], s));
+    int rc = dispatch_solve(h, p, s);
+    if (rc) return rc;
+    if (timed) {
+        HIPCHK(hipEventRecord(h->ev_stop[h->ev_used], s));
+        h->ev_used++;
+    }
     return MPC_OK;
 }
 
@@ -213,7 +272,7 @@ int mpc_default_config(mpc_config *c, int N, int n_obst, double Tf)
     c->slack_a = 1e4; c->slack_b = 50.0;                               // :146
     c->qp_iter_max = 50;                                               // world_specification.py:48
     c->qp_tol = 1e-8;
-    c->cost_scale_dt = 1; c->slack_scale_dt = 1; c->lm_scaled = 1; c->bx_terminal = 0; c->soft_h = 1;   // lm_scaled: DESIGN.md section 2 (statistical pin)
+    c->cost_scale_dt = 1; c->slack_scale_dt = 1; c->lm_scaled = 1; c->bx_terminal = 0; c->soft_h = 1;   // the switch set that replays the reference's recorded tables per seed (profiles/r02_seed_replay.json)
     c->arena[0] = -8.0; c->arena[1] = 8.0; c->arena[2] = -8.0; c->arena[3] = 8.0;   // world_specification.py:7-10
     c->bug_compat_predict = 1;
     c->mu0 = 1e4; c->thr0 = 1e-1;
@@ -232,33 +291,11 @@ int mpc_create(const mpc_config *cfg, int device, int max_batch, mpc_handle **ou
         return fail(MPC_ERR_NODEVICE, "no HIP device visible: libmpcgpu has no CPU path");
     if (device < 0 || device >= ndev) return fail(MPC_ERR_ARG, "device index out of range");
     HIPCHK(hipSetDevice(device));
-    mpc_handle *h = new mpc_handle();
+    mpc_handle *h = new mpc_handle();     // value-initialised: every pointer null, so mpc_destroy can release a half-built handle
     h->cfg = *cfg; h->device = device; h->max_batch = max_batch;
-    {
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, device));
-        h->simd_count = 4 * prop.multiProcessorCount;
-    }
-    h->split_override = 0;
-    h->lanes_override = 0; h->use_mfma = 0; h->row_parallel = 1; h->profiling = 0; h->launch_count = 0; h->ev_used = 0; h->d_trace = nullptr; h->d_iters_acc = nullptr; h->d_status_acc = nullptr;
-    const size_t B = (size_t)max_batch, N = (size_t)cfg->N, no = (size_t)cfg->n_obst;
-    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIPCHK(hipMalloc(&h->dX, B * (N + 1) * 5 * sizeof(double)));
-    HIPCHK(hipMalloc(&h->dU, B * N * 2 * sizeof(double)));
-    HIPCHK(hipMalloc(&h->d_x0, B * 5 * sizeof(double)));
-    HIPCHK(hipMalloc(&h->d_P, B * (N + 1) * no * 2 * sizeof(double)));
-    HIPCHK(hipMalloc(&h->d_goal, B * 2 * sizeof(double)));
-    HIPCHK(hipMalloc(&h->d_obst, B * no * 4 * sizeof(double)));
-    HIPCHK(hipMalloc(&h->d_u0, B * 2 * sizeof(double)));
-    HIPCHK(hipMalloc(&h->d_cost, B * sizeof(double)));
-    HIPCHK(hipMalloc(&h->d_xa, B * 5 * sizeof(double)));
-    HIPCHK(hipMalloc(&h->d_ua, B * 2 * sizeof(double)));
-    HIPCHK(hipMalloc(&h->d_xb, B * 5 * sizeof(double)));
-    HIPCHK(hipMalloc(&h->d_status, B * sizeof(int32_t)));
-    HIPCHK(hipMalloc(&h->d_iters, B * sizeof(int32_t)));
-    HIPCHK(hipMemsetAsync(h->dX, 0, B * (N + 1) * 5 * sizeof(double), h->stream));
-    HIPCHK(hipMemsetAsync(h->dU, 0, B * N * 2 * sizeof(double), h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    h->row_parallel = 1;
+    int rc = create_resources(h);
+    if (rc) { mpc_destroy(h); return rc; }     // (mpc_destroy leaves g_err alone when nothing fails inside it)
     *out = h;
     return MPC_OK;
 }
@@ -266,14 +303,14 @@ int mpc_create(const mpc_config *cfg, int device, int max_batch, mpc_handle **ou
 int mpc_destroy(mpc_handle *h)
 {
     if (!h) return MPC_OK;
-    hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->dX, h->dU, h->d_x0, h->d_P, h->d_goal, h->d_obst, h->d_u0, h->d_cost, h->d_xa, h->d_ua, h->d_xb, h->d_status, h->d_iters};
-    for (void *b : bufs) if (b) hipFree(b);
-    if (h->d_trace) hipFree(h->d_trace);
-    for (auto e : h->ev_start) hipEventDestroy(e);
-    for (auto e : h->ev_stop) hipEventDestroy(e);
-    hipStreamDestroy(h->stream);
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void *bufs[] = {h->dX, h->dU, h->d_x0, h->d_P, h->d_goal, h->d_obst, h->d_u0, h->d_cost, h->d_xa, h->d_ua, h->d_xb, h->d_status, h->d_iters,
+                    h->d_trace, h->d_alpha_own};
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    for (auto e : h->ev_start) (void)hipEventDestroy(e);
+    for (auto e : h->ev_stop) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MPC_OK;
 }
@@ -534,6 +571,31 @@ int mpc_generate_scenarios(mpc_handle *h, int count, int scenario, unsigned seed
     int rc = mpc_generate_scenarios_dev(h, count, scenario, seed0, box, h->d_obst, nullptr); if (rc) return rc;
     HIPCHK(hipMemcpyAsync(obst, h->d_obst, (size_t)count * h->cfg.n_obst * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return MPC_OK;
+}
+
+/* ------------------------------------------------- slack schedule -------------------------------------------------- */
+
+int mpc_set_slack_schedule_dev(mpc_handle *h, const double *d_alpha)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    h->d_alpha = d_alpha;
+    return MPC_OK;
+}
+
+int mpc_set_slack_schedule(mpc_handle *h, int batch, const double *alpha)
+{
+    int rc = check_batch(h, batch); if (rc) return rc;
+    if (!alpha) { h->d_alpha = nullptr; return MPC_OK; }
+    if (batch == 0) return fail(MPC_ERR_ARG, "a slack schedule needs batch >= 1");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t row = (size_t)h->cfg.N + 1;
+    for (size_t k = 0; k < (size_t)batch * row; k++)
+        if (!(alpha[k] >= 0.0) || !(alpha[k] <= 1e300)) return fail(MPC_ERR_ARG, "slack weights must be finite and >= 0");
+    if (!h->d_alpha_own) HIPCHK(hipMalloc(&h->d_alpha_own, (size_t)h->max_batch * row * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(h->d_alpha_own, alpha, (size_t)batch * row * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->d_alpha = h->d_alpha_own;
     return MPC_OK;
 }
 

@@ -51,6 +51,8 @@ SYMBOLS = {
     "mpc_shift": (C.c_int, [_vp, C.c_int]),
     "mpc_solve": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mpc_solve_obst": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mpc_set_slack_schedule": (C.c_int, [_vp, C.c_int, _vp]),
+    "mpc_set_slack_schedule_dev": (C.c_int, [_vp, _vp]),
     "mpc_plant_step": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "mpc_predict": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "mpc_solve_dev": (C.c_int, [_vp, C.c_int] + [_vp] * 10),

@@ -21,6 +21,7 @@ class AcadosOcpSolverShim:
         self.goal = np.array(goal, dtype=np.float64)
         self.x0 = np.zeros(5) if x0 is None else np.array(x0, dtype=np.float64)   # constraints.x0, :87
         self.zl = np.zeros((N + 1, n_obst)); self.Zl = np.zeros((N + 1, n_obst))
+        self._slack_touched = False     # until cost_set('zl'|'Zl') is called the kernel's built-in schedule (:145-148) applies
         self.status = 0; self.iters = 0; self.cost = 0.0
 
     # -- setters ---------------------------------------------------------------------------------------------------
@@ -45,10 +46,12 @@ class AcadosOcpSolverShim:
 
     def cost_set(self, stage, field, value):
         v = np.asarray(value, dtype=np.float64)
-        if field == "zl":
-            self.zl[stage] = v          # the kernel recomputes the schedule of :145-152 from (x0, goal) itself;
-        elif field == "Zl":
-            self.Zl[stage] = v          # values are kept so a caller can check them against slack_schedule()
+        if field in ("zl", "Zl"):       # parameterize_slack, :149-152: forwarded to the solve (mpc_set_slack_schedule) at solve()
+            v = np.broadcast_to(v, (self.n_obst,))
+            if not np.all(v == v[0]) or not (v[0] >= 0 and np.isfinite(v[0])):
+                raise ValueError("libmpcgpu takes one finite slack weight >= 0 per stage (zl_i = Zl_i = alpha_i * ones, robot_ocp_problem.py:149-150)")
+            (self.zl if field == "zl" else self.Zl)[stage] = v
+            self._slack_touched = True
         elif field == "yref":
             self.goal = v[:2].copy()    # set_subgoal writes [x, y, 0, 0, 0] (:284): only the position is meaningful
         else:
@@ -62,6 +65,10 @@ class AcadosOcpSolverShim:
 
     # -- solve / get -----------------------------------------------------------------------------------------------
     def solve(self):
+        if self._slack_touched:         # the caller's schedule goes to the kernel as it is
+            if not np.array_equal(self.zl, self.Zl):
+                raise ValueError("zl and Zl differ: libmpcgpu implements the reference's zl_i = Zl_i (robot_ocp_problem.py:149-152)")
+            self.mpc.set_slack_schedule(self.zl[None, :, 0])
         self.mpc.set_warmstart(self.X[None], self.U[None])
         out = self.mpc.solve(self.x0[None], self.P[None], self.goal[None])
         X, U = self.mpc.get_traj(1)

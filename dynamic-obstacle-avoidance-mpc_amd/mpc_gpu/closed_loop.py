@@ -1,132 +1,167 @@
-"""RobotOcpProblem: the reference's closed-loop RTI simulator (src/simulation/robot_ocp_problem.py:13-311) with
-the acados objects replaced by the libmpcgpu shims.  The loop body follows the reference line by line in behaviour
-(citations inline); horizon, obstacle count and QP cap are constructor arguments instead of module constants.
+"""Single-scenario closed loop driven through the acados-shaped shims: the host-side check that a caller written against
+`AcadosOcpSolver` / `AcadosSimSolver` (the reference's src/simulation/robot_ocp_problem.py) gets the same closed loop from
+libmpcgpu.  It issues exactly the solver calls the reference issues per control step (`set(i,'p')`,
+`cost_set(i,'zl'|'Zl')`, `set(0,'lbx'|'ubx')`, `solve()`, `get(0,'u')`, integrator `set/solve/get`, per-stage `get/set` for the
+warm-start shift, `reset()`), organised here as a small state machine -- `EpisodeState` + `control_step()` + `rollout()` -- rather
+than as the reference's monolithic `step()`.  The batched, device-resident equivalent is `episodes.run_episodes`.
 
-Reference defects are reproduced behind switches so recorded statistics can be compared:
-  D1 predictor uses vy for vx          -> bug_compat_predict (default True)
-  D2 x_guess aliases self.x0           -> bug_compat_alias   (default True)
+`RobotOcpProblem` keeps the reference's constructor / `step()` / `set_subgoal()` / `set_up_new_experiment()` surface on top of it
+so that scripts written for the reference run; horizon, obstacle count and QP cap are arguments instead of module constants.
+Reference defects behind switches: D1 look-ahead `vx = vy` (bug_compat_predict), D2 `x_guess` aliases the
+plant state (bug_compat_alias).
 """
+from dataclasses import dataclass, field
+
 import numpy as np
 
 from . import world as W
 from .acados_shim import AcadosOcpSolverShim, AcadosSimSolverShim
 from .solver import BatchedMpc
 
+_BOXED = [0, 1, 3, 4]          # state entries that enter the slack scale (robot_ocp_problem.py:146)
+
+
+@dataclass
+class EpisodeState:
+    x: np.ndarray                                   # plant state
+    goal: np.ndarray                                # current sub-goal
+    obstacles: list
+    steps: int = 0                                  # completed control steps (the reference's `i`)
+    reached: bool = False
+    left_arena: bool = False
+    min_margin: float = np.inf
+    u_peak: float = 0.0
+    xs: list = field(default_factory=list)          # visited plant states, starting with the initial one
+    us: list = field(default_factory=list)
+    predictions: list = field(default_factory=list)
+
+    def table_row(self):
+        """[hit, reached, min_margin, dist_to_goal, iters, out_of_bounds], robot_ocp_problem.py:277 / experiments.py:36"""
+        return [self.min_margin <= 0, self.reached, self.min_margin, float(np.linalg.norm(self.x[:2] - self.goal)), self.steps,
+                self.left_arena]
+
+
+class ShimLoop:
+    """One MPC instance in closed loop over (ocp_solver, ocp_integrator) objects with acados' method surface."""
+
+    def __init__(self, ocp_solver, ocp_integrator, N, soft=True, reset_on_failure=False, alias_guess=True, keep_predictions=False):
+        self.ocp, self.sim, self.N = ocp_solver, ocp_integrator, N
+        self.soft, self.reset_on_failure, self.alias_guess, self.keep_predictions = soft, reset_on_failure, alias_guess, keep_predictions
+
+    # -- uploads in front of a solve ------------------------------------------------------------------------------
+    def upload_forecast(self, st):                  # parameterize_model, :154-166
+        P = np.stack([o.predict_trajectory(self.N) for o in st.obstacles], axis=1)            # (N+1, n_obst, 2)
+        for i, row in enumerate(P.reshape(self.N + 1, -1)):
+            self.ocp.set(i, "p", row)
+
+    def upload_slack(self, st):                     # parameterize_slack, :145-152
+        dev = st.x[_BOXED] - np.concatenate([st.goal, [0.0, 0.0]])
+        alpha = 1e4 * (dev @ dev + 50.0) * (self.N - np.arange(self.N + 1)) / self.N
+        ones = np.ones(len(st.obstacles))
+        for i, a in enumerate(alpha):
+            self.ocp.cost_set(i, "zl", a * ones)
+            self.ocp.cost_set(i, "Zl", a * ones)
+
+    def cold_start(self, st):                       # set_initial_guess, :286-306
+        self.ocp.reset()
+        guess = st.x if self.alias_guess else st.x.copy()
+        guess[3:] = 0.0                              # through the alias this also stops the plant (defect D2)
+        for i in range(self.N + 1):
+            self.ocp.set(i, "x", guess)
+            if i < self.N:
+                self.ocp.set(i, "u", np.zeros(2))
+
+    def shift_warm_start(self):                     # :253-258: stage j takes stage j+1, the last input is zero, x_N stays
+        xs = [self.ocp.get(j, "x") for j in range(1, self.N + 1)]
+        us = [self.ocp.get(j, "u") for j in range(1, self.N)] + [np.zeros(2)]
+        for j, (x, u) in enumerate(zip(xs, us)):
+            self.ocp.set(j, "x", x)
+            self.ocp.set(j, "u", u)
+
+    # -- one control step ------------------------------------------------------------------------------------------
+    def control_step(self, st):
+        """:186-250.  Returns the solver status; st.reached tells whether the episode is over."""
+        self.upload_forecast(st)
+        if self.soft:
+            self.upload_slack(st)
+        for bound in ("ubx", "lbx"):
+            self.ocp.set(0, bound, st.x)
+        status = self.ocp.solve()
+        u = self.ocp.get(0, "u")
+        st.u_peak = max(st.u_peak, float(np.abs(u).max()))
+        if status == 4 and self.reset_on_failure:
+            self.cold_start(st)
+        self.sim.set("x", st.x); self.sim.set("u", u); self.sim.solve()
+        st.x = self.sim.get("x")
+        st.left_arena |= bool(not (W.X_MIN <= st.x[0] <= W.X_MAX and W.Y_MIN <= st.x[1] <= W.Y_MAX))
+        for o in st.obstacles:
+            o.step()
+        centres = np.array([[o.x, o.y] for o in st.obstacles]); radii = np.array([o.r for o in st.obstacles])
+        st.min_margin = min(st.min_margin, float((np.linalg.norm(centres - st.x[:2], axis=1) - (radii + W.R_ROBOT)).min()))
+        st.xs.append(st.x.copy()); st.us.append(u.copy())
+        if self.keep_predictions:
+            st.predictions.append(np.array([self.ocp.get(j, "x")[:2] for j in range(self.N + 1)]))
+        st.reached = bool(np.linalg.norm(st.x[:2] - st.goal) <= W.TOL)
+        return status
+
+    def rollout(self, st, max_steps):
+        """:180-260: cold start, then control steps until the goal region is reached or max_steps are done."""
+        self.cold_start(st)
+        while st.steps < max_steps:
+            self.control_step(st)
+            if st.reached:
+                break                                # the reference leaves its loop before `i += 1`
+            self.shift_warm_start()
+            st.steps += 1
+        return st
+
 
 class RobotOcpProblem:
+    """The reference's class surface (robot_ocp_problem.py:13-311) over ShimLoop and the libmpcgpu shims."""
+
     def __init__(self, robot_init, robot_end, scenario="RANDOM", slack=True, init_guess_when_error=False,
                  random_move=False, show_pred=False, N=W.N_SOLV, Tf=W.TF, n_obst=W.N_OBST, qp_iter=W.QP_ITER,
                  bug_compat_predict=True, bug_compat_alias=True, device=0, verbose=False):
         self.robot_init = np.array(robot_init, dtype=np.float64)
         self.robot_end = np.array(robot_end, dtype=np.float64)
-        self.slack = slack
-        self.N, self.Tf, self.n_obst = N, Tf, n_obst
-        self.nx, self.nu = 5, 2
-        self.bug_compat_predict, self.bug_compat_alias = bug_compat_predict, bug_compat_alias
-        self.verbose = verbose
+        self.slack, self.N, self.Tf, self.n_obst = slack, N, Tf, n_obst
+        self.bug_compat_predict, self.bug_compat_alias, self.verbose = bug_compat_predict, bug_compat_alias, verbose
         self.mpc = BatchedMpc(N, n_obst, Tf, max_batch=1, device=device, qp_iter_max=qp_iter,
                               soft_h=1 if slack else 0, bug_compat_predict=1 if bug_compat_predict else 0)
-        self.init_experiment(scenario, init_guess_when_error, random_move, show_pred)
         self.ocp_solver = AcadosOcpSolverShim(N, n_obst, Tf, goal=self.robot_end, x0=self.robot_init, mpc=self.mpc)   # :135
         self.ocp_integrator = AcadosSimSolverShim(self.mpc)                                                          # :136
-        if self.slack:
-            self.parameterize_slack()
+        self.init_experiment(scenario, init_guess_when_error, random_move, show_pred)
 
     def init_experiment(self, scenario, init_guess_when_error, random_move=False, show_pred=False):   # :35-51
-        self.subgoal = self.robot_end
-        self.init_guess_when_error = init_guess_when_error
-        self.show_pred = show_pred
-        self.obstacles = W.generate_random_moving_obstacles(scenario, random_move, n_obst=self.n_obst, dt=self.Tf / self.N)
-        for o in self.obstacles:
+        obstacles = W.generate_random_moving_obstacles(scenario, random_move, n_obst=self.n_obst, dt=self.Tf / self.N)
+        for o in obstacles:
             o.bug_compat_predict = self.bug_compat_predict
-        self.simX = np.ndarray((0, self.nx)); self.simU = np.ndarray((0, self.nu))
-        self.pred = np.ndarray((0, self.N + 1, 2))
-        self.x0 = self.robot_init if self.bug_compat_alias else self.robot_init.copy()
-        self.simX = np.append(self.simX, self.x0.reshape((1, self.nx)), axis=0)
-        self.reached_goal = False
-        self.min_margin_traj = np.inf
+        start = self.robot_init if self.bug_compat_alias else self.robot_init.copy()
+        self.state = EpisodeState(x=start, goal=self.robot_end.copy(), obstacles=obstacles, xs=[start.copy()])
+        self.loop = ShimLoop(self.ocp_solver, self.ocp_integrator, self.N, soft=self.slack, reset_on_failure=init_guess_when_error,
+                             alias_guess=self.bug_compat_alias, keep_predictions=show_pred)
 
-    def parameterize_slack(self):                                                                     # :145-152
-        scale = 1e4 * (np.sum((np.take(self.x0, [0, 1, 3, 4]) - np.append(self.subgoal, np.zeros(2))) ** 2) + 50)
-        for i in range(self.N + 1):
-            alpha_i = scale * (self.N - i) / self.N
-            self.ocp_solver.cost_set(i, "zl", alpha_i * np.ones(len(self.obstacles)))
-            self.ocp_solver.cost_set(i, "Zl", alpha_i * np.ones(len(self.obstacles)))
+    def set_up_new_experiment(self, scenario="RANDOM", init_guess_when_error=False, random_move=False, show_pred=False):   # :309-311
+        self.ocp_solver.reset()
+        self.init_experiment(scenario, init_guess_when_error, random_move, show_pred)
 
-    def parameterize_model(self):                                                                     # :154-166
-        P = np.ndarray((self.N + 1, self.n_obst, 2))
-        for i, o in enumerate(self.obstacles):
-            P[:, i, :] = o.predict_trajectory(self.N)
-        for i in range(self.N + 1):
-            self.ocp_solver.set(i, "p", P[i].flatten())
-
-    def step(self, max_iter, visualize=False):                                                        # :168-277
-        reached_subgoal = False
-        out_of_bounds = False
-        self.set_initial_guess()
-        distance_to_goal = np.linalg.norm(np.take(self.x0, [0, 1, 3, 4]) - np.append(self.subgoal, [0, 0]))
-        u_max = 0
-        i = 0
-        N = self.N
-        while i < max_iter:
-            self.parameterize_model()
-            if self.slack:
-                self.parameterize_slack()
-            self.ocp_solver.set(0, "ubx", self.x0)
-            self.ocp_solver.set(0, "lbx", self.x0)
-            stat_solv = self.ocp_solver.solve()                                                       # :195
-            u = self.ocp_solver.get(0, "u")
-            u_max = max(u_max, np.max(np.abs(u)))
-            if stat_solv in [4] and self.init_guess_when_error:                                       # :203-205
-                self.set_initial_guess()
-            self.ocp_integrator.set("x", self.x0)
-            self.ocp_integrator.set("u", u)
-            self.ocp_integrator.solve()
-            self.x0 = self.ocp_integrator.get("x")                                                    # :212
-            if self.x0[0] < W.X_MIN or self.x0[0] > W.X_MAX or self.x0[1] < W.Y_MIN or self.x0[1] > W.Y_MAX:
-                out_of_bounds = True
-            for o in self.obstacles:
-                o.step()
-            min_margin = np.inf
-            for o in self.obstacles:
-                margin = np.sqrt((self.x0[0] - o.x) ** 2 + (self.x0[1] - o.y) ** 2) - (o.r + W.R_ROBOT)
-                min_margin = min(min_margin, margin)
-            self.min_margin_traj = min(self.min_margin_traj, min_margin)
-            self.simX = np.append(self.simX, self.x0.reshape((1, self.nx)), axis=0)
-            self.simU = np.append(self.simU, u.reshape((1, self.nu)), axis=0)
-            if self.show_pred:
-                self.pred = np.append(self.pred, self.ocp_solver.X[None, :, :2], axis=0)
-            distance_to_goal = np.linalg.norm(self.x0[:2] - self.subgoal)                             # :247
-            if distance_to_goal <= W.TOL:
-                reached_subgoal = True
-                break
-            for j in range(N - 1):                                                                    # :253-258
-                self.ocp_solver.set(j, "x", self.ocp_solver.get(j + 1, "x"))
-                self.ocp_solver.set(j, "u", self.ocp_solver.get(j + 1, "u"))
-            self.ocp_solver.set(N - 1, "x", self.ocp_solver.get(N, "x"))
-            self.ocp_solver.set(N - 1, "u", np.array([0, 0]))
-            i += 1
-        if self.verbose:
-            print(f"Min margin to obstacle {self.min_margin_traj}")
-            print(f"Final difference to sub goal state: {np.linalg.norm((self.simX[-1][0:2] - self.subgoal))}")
-            print(f"maximal control along trajectory: {u_max}")
-            print(f"left bounds: {out_of_bounds}")
-        return (self.simX[-1], (self.min_margin_traj <= 0), reached_subgoal, self.min_margin_traj, distance_to_goal, i,
-                out_of_bounds)
-
-    def set_subgoal(self, x, y):                                                                      # :279-284
-        self.subgoal = np.array([x, y], dtype=np.float64)
+    def set_subgoal(self, x, y):                     # :279-284 (the shim applies the position to stage and terminal reference)
+        self.state.goal = np.array([x, y], dtype=np.float64)
         self.ocp_solver.cost_set(self.N, "yref", np.array([x, y, 0, 0, 0]))
 
-    def set_initial_guess(self):                                                                      # :286-306
-        self.ocp_solver.reset()
-        x_guess = self.x0 if self.bug_compat_alias else self.x0.copy()
-        x_guess[3:] = np.zeros(1)          # with aliasing this zeroes the plant's v, omega (reference defect D2)
-        for i in range(self.N + 1):
-            if i < self.N:
-                self.ocp_solver.set(i, "u", np.zeros(2))
-            self.ocp_solver.set(i, "x", x_guess)
+    def step(self, max_iter, visualize=False):       # :168-277
+        st = self.loop.rollout(self.state, max_iter)
+        if self.verbose:
+            print(f"min margin {st.min_margin}, distance to sub-goal {np.linalg.norm(st.x[:2] - st.goal)}, peak control {st.u_peak}, "
+                  f"left the arena: {st.left_arena}")
+        hit, reached, margin, dist, iters, oob = st.table_row()
+        return st.xs[-1], hit, reached, margin, dist, iters, oob
 
-    def set_up_new_experiment(self, scenario="RANDOM", init_guess_when_error=False, random_move=False, show_pred=False):
-        self.ocp_solver.reset()                                                                       # :309-311
-        self.init_experiment(scenario, init_guess_when_error, random_move, show_pred)
+    # views the reference's callers read
+    obstacles = property(lambda self: self.state.obstacles)
+    x0 = property(lambda self: self.state.x)
+    subgoal = property(lambda self: self.state.goal)
+    simX = property(lambda self: np.array(self.state.xs))
+    simU = property(lambda self: np.array(self.state.us).reshape(-1, 2))
+    pred = property(lambda self: np.array(self.state.predictions))
+    min_margin_traj = property(lambda self: self.state.min_margin)

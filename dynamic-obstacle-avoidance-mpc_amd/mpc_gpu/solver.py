@@ -100,6 +100,21 @@ class BatchedMpc:
         _lib.check(fn(self._h, B, _ptr(x0), _ptr(obstacles), _ptr(goal), _ptr(u0), _ptr(cost), _ptr(status), _ptr(iters)))
         return dict(u0=u0, cost=cost, status=status, iters=iters)
 
+    def set_slack_schedule(self, alpha):
+        """parameterize_slack(), robot_ocp_problem.py:145-152: explicit zl_i = Zl_i = alpha[b, i] for the following solves
+        (alpha (B, N+1), or a device tensor of shape (max_batch, N+1) used in place); None = the reference's schedule, in-kernel."""
+        if alpha is None:
+            _lib.check(_lib.lib().mpc_set_slack_schedule(self._h, 0, None))
+        elif isinstance(alpha, np.ndarray) or isinstance(alpha, (list, tuple)):
+            alpha = _f64(np.atleast_2d(alpha))
+            if alpha.shape[1] != self.N + 1:
+                raise ValueError(f"alpha must be (B, {self.N + 1})")
+            _lib.check(_lib.lib().mpc_set_slack_schedule(self._h, alpha.shape[0], _ptr(alpha)))
+        else:
+            if tuple(alpha.shape) != (self.max_batch, self.N + 1):
+                raise ValueError(f"a device schedule must be ({self.max_batch}, {self.N + 1})")
+            _lib.check(_lib.lib().mpc_set_slack_schedule_dev(self._h, _ptr(alpha)))
+
     def plant_step(self, x, u):
         """ocp_integrator set/solve/get, robot_ocp_problem.py:207-212."""
         x = _f64(np.atleast_2d(x)); u = _f64(np.atleast_2d(u), (x.shape[0], 2))

@@ -59,7 +59,7 @@ typedef struct mpc_config {
     /* acados-semantics switches; defaults reproduce 2022-era acados           */
     int32_t cost_scale_dt;  /* stage cost x dt                                      default 1   */
     int32_t slack_scale_dt; /* slack penalties x dt for stages < N                  default 1   */
-    int32_t lm_scaled;      /* LM term x dt for stages < N  default 1   */
+    int32_t lm_scaled;      /* LM term x dt for stages < N (pinned per seed) default 1 */
     int32_t bx_terminal;    /* path box also at stage N                              default 0   */
     int32_t soft_h;         /* obstacle rows softened (slack=True, :106)             default 1   */
     double arena[4];        /* X_MIN, X_MAX, Y_MIN, Y_MAX  world_specification.py:7-10           */
@@ -105,6 +105,15 @@ int mpc_solve(mpc_handle *h, int batch, const double *x0, const double *P, const
  * (Obstacle.predict_trajectory, src/utils/visualization.py:62-79 + parameterize_model, :154-166) */
 int mpc_solve_obst(mpc_handle *h, int batch, const double *x0, const double *obst, const double *goal,
                    double *u0, double *cost, int32_t *status, int32_t *iters);
+
+/* parameterize_slack(), robot_ocp_problem.py:145-152: the reference uploads zl_i = Zl_i = alpha_i * ones(n_obst) for every stage i
+ * before every solve (cost_set(i,'zl'|'Zl')).  By default the solve kernel evaluates that schedule itself from (x0, goal, slack_a,
+ * slack_b); a caller who changes parameterize_slack passes the weights here instead: alpha[batch][N+1] (host; copied) applies to all
+ * following solves of the first `batch` instances until it is replaced; alpha = NULL returns to the built-in schedule.  Weights must be
+ * finite and >= 0 (0 = the row is vacuous, as at the reference's terminal stage).  slack_scale_dt still multiplies stages < N.
+ * _dev: a device array [max_batch][N+1] used in place (not copied; NULL = built-in). */
+int mpc_set_slack_schedule(mpc_handle *h, int batch, const double *alpha);
+int mpc_set_slack_schedule_dev(mpc_handle *h, const double *d_alpha);
 
 /* Plant integrator, ocp_integrator.set/solve/get, robot_ocp_problem.py:207-212 (same IRK as the OCP) */
 int mpc_plant_step(mpc_handle *h, int batch, const double *x, const double *u, double *x_next);

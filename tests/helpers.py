@@ -27,3 +27,74 @@ def oracle_P(orc, cfg, obst):
 def oracle_guess(orc, cfg, x0):
     Xs, Us = zip(*[orc.initial_guess(cfg, x) for x in x0])
     return np.stack(Xs), np.stack(Us)
+
+
+def qp_merit(orc, cfg, x0, P, goal, X, U, Xn, Un):
+    """Solver-independent judgement of one RTI step (X, U) -> (Xn, Un): the step as a point of the QP the oracle assembles from
+    (x0, P, goal, X, U) (orc_export_qp; slacks eliminated in closed form, s = max(0, -(Cs v + hs))).
+    Returns (objective, max equality residual, max bound violation)."""
+    q = orc.export_qp(cfg, x0, P, goal, X, U)
+    N = cfg.N
+    v = np.zeros(7 * N)
+    for i in range(N):
+        v[7 * i: 7 * i + 2] = Un[i] - U[i]
+    for i in range(1, N + 1):
+        v[7 * (i - 1) + 2: 7 * (i - 1) + 7] = Xn[i] - X[i]
+    s = np.maximum(0.0, -(q["Cs"] @ v + q["hs"])) if len(q["hs"]) else np.zeros(0)
+    f = 0.5 * v @ q["H"] @ v + q["g"] @ v + float((q["zs"] * s + 0.5 * q["Zs"] * s * s).sum())
+    eq = float(np.abs(q["Aeq"] @ v - q["beq"]).max())
+    bnd = float(max((q["lb"] - v).max(), (v - q["ub"]).max(), 0.0))
+    return float(f), eq, bnd
+
+
+class OracleLoop:
+    """Oracle-side closed loop of ONE instance: the body of RobotOcpProblem.step (robot_ocp_problem.py:184-260) spelled out on the
+    oracle's functions -- look-ahead, RTI solve, status-4 reset (with the aliasing defect D2 when alias=True), plant step, noisy
+    obstacle motion, margin / arena / goal bookkeeping, warm-start shift.  Test infrastructure (checker for the fused GPU step)."""
+
+    def __init__(self, orc, cfg, x0, goal, obst, reset_on_fail=True, alias=True, randomness=0.1, vmax=2.0):
+        self.orc, self.cfg = orc, cfg
+        self.x = np.array(x0, dtype=np.float64); self.goal = np.array(goal, dtype=np.float64)
+        self.obst = np.array(obst, dtype=np.float64)
+        self.reset_on_fail, self.alias, self.randomness, self.vmax = reset_on_fail, alias, randomness, vmax
+        if alias:
+            self.x[3:] = 0.0                      # set_initial_guess() at the start of step() zeroes v, omega through the alias (:301-302)
+        self.X, self.U = orc.initial_guess(cfg, self.x)
+        self.min_margin, self.flags, self.steps = np.inf, 0, 0
+        self.last = None
+
+    def step(self, noise=None):
+        """one control step; returns the oracle's solve result"""
+        orc, cfg = self.orc, self.cfg
+        dt = cfg.Tf / cfg.N
+        if self.flags & 1:
+            return None                           # goal reached: the episode is over, the instance idles
+        P = orc.predict_params(cfg, self.obst)
+        r = orc.rti_solve(cfg, self.x, P, self.goal, self.X, self.U)
+        self.X, self.U = r["X"], r["U"]
+        u = r["u0"].copy()
+        if r["status"] == 4 and self.reset_on_fail:
+            if self.alias:
+                self.x[3:] = 0.0
+            self.X, self.U = orc.initial_guess(cfg, self.x)
+        self.x = orc.dynamics(self.x, u, dt)[0]
+        for j in range(cfg.n_obst):
+            self.obst[j] = orc.obstacle_step(cfg, self.obst[j], dt, None if noise is None else noise[j], self.randomness, self.vmax)
+        a = cfg.arena
+        if self.x[0] < a[0] or self.x[0] > a[1] or self.x[1] < a[2] or self.x[1] > a[3]:
+            self.flags |= 2
+        margin = min(np.sqrt((self.x[0] - o[0]) ** 2 + (self.x[1] - o[1]) ** 2) - 1.2 for o in self.obst)
+        self.min_margin = min(self.min_margin, margin)
+        if self.min_margin <= 0:
+            self.flags |= 4
+        if np.linalg.norm(self.x[:2] - self.goal) <= 0.15:
+            self.flags |= 1
+        else:
+            self.steps += 1
+        self.X, self.U = orc.shift(cfg, self.X, self.U)
+        self.last = r
+        return r
+
+    def row(self):
+        return [float(bool(self.flags & 4)), float(bool(self.flags & 1)), self.min_margin, float(np.linalg.norm(self.x[:2] - self.goal)),
+                float(self.steps), float(bool(self.flags & 2))]

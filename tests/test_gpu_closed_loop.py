@@ -1,0 +1,242 @@
+"""The fused closed-loop control step (mpc_closed_loop_step_dev) against an ORACLE-side closed loop
+(tests/helpers.py::OracleLoop = RobotOcpProblem.step's body, robot_ocp_problem.py:184-260, on the oracle's functions), plus the
+sub-goal hook (set_subgoal, :279-284; x_N read-back, :232) and the explicit slack schedule (parameterize_slack, :145-152)."""
+import numpy as np
+import pytest
+
+from helpers import OracleLoop, oracle_P, oracle_guess, qp_merit, random_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=["stage-split", "one-lane-per-stage"])
+def env(built, request):
+    import mpc_gpu
+    from oracle import oracle as orc
+    mpc_gpu.BatchedMpc.default_lanes_per_stage = 0 if request.param == "stage-split" else 1
+    yield mpc_gpu, orc
+    mpc_gpu.BatchedMpc.default_lanes_per_stage = 0
+
+
+class GpuLoop:
+    """device-resident closed loop on the handle-owned iterate, one launch per control step"""
+
+    def __init__(self, mpc_gpu, N, no, Tf, x0, goal, obst, alias=True, **cfg):
+        import torch
+        from mpc_gpu import _lib
+        self.torch, self.B = torch, x0.shape[0]
+        self.m = mpc_gpu.BatchedMpc(N, no, Tf, max_batch=self.B, **cfg)
+        dev = torch.device("cuda:0")
+        self.stream = torch.cuda.Stream(device=dev)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        z = lambda *s, dt=torch.float64: torch.zeros(*s, dtype=dt, device=dev)
+        with torch.cuda.stream(self.stream):
+            self.x0, self.goal, self.obst = t(x0), t(goal), t(obst)
+            if alias:
+                self.x0[:, 3:] = 0.0
+            self.u0, self.cost = z(self.B, 2), z(self.B)
+            self.status, self.iters = z(self.B, dt=torch.int32), z(self.B, dt=torch.int32)
+            self.margin = torch.full((self.B,), float("inf"), dtype=torch.float64, device=dev)
+            self.flags, self.steps = z(self.B, dt=torch.int32), z(self.B, dt=torch.int32)
+        self.stream.synchronize()
+        self.dX, self.dU, _ = self.m.iterate_ptrs()              # the handle-owned iterate: terminal_state() / get_traj() see it
+        self.m.reset_guess_dev(self.B, self.x0, self.dX, self.dU, stream=self.stream.cuda_stream)
+        self.fl = (_lib.STEP_SHIFT | _lib.STEP_PLANT | _lib.STEP_OBSTACLES | _lib.STEP_METRICS | _lib.STEP_RESET_ON_FAIL
+                   | (_lib.STEP_ALIAS_BUG if alias else 0))
+        self.dev = dev
+
+    def step(self, noise=None):
+        nz = None if noise is None else self.torch.from_numpy(np.ascontiguousarray(noise)).to(self.dev)
+        self.m.closed_loop_step_dev(self.B, self.x0, self.obst, self.goal, self.dX, self.dU, self.u0, self.cost, self.status, self.iters,
+                                    nz, flags=self.fl, min_margin=self.margin, ep_flags=self.flags, ep_steps=self.steps,
+                                    stream=self.stream.cuda_stream)
+        self.stream.synchronize()
+
+    def host(self):
+        c = lambda a: a.cpu().numpy()
+        X, U = self.m.get_traj(self.B)
+        return dict(x0=c(self.x0), obst=c(self.obst), X=X, U=U, u0=c(self.u0), status=c(self.status), iters=c(self.iters),
+                    margin=c(self.margin), flags=c(self.flags), steps=c(self.steps))
+
+    def set_goal(self, goal):
+        with self.torch.cuda.stream(self.stream):
+            self.goal.copy_(self.torch.from_numpy(np.ascontiguousarray(goal)).to(self.dev))
+        self.stream.synchronize()
+
+    def close(self):
+        self.m.close()
+
+
+def test_fused_step_against_the_oracle_loop_with_resync(env):
+    """24 instances x 70 control steps, moving noisy obstacles that interact with the robots (the reference's RANDOM draws), the
+    oracle loop re-seeded with the GPU's state before every step: every control step is then ONE comparison of everything the
+    fused launch does -- solve, u*, plant state, obstacle states (bit for bit), shifted warm start, margin, flags, step counter.
+    At step 25 every instance gets a new sub-goal (set_subgoal); x_N is read back (terminal_state) after every step."""
+    mpc_gpu, orc = env
+    from mpc_gpu.world import reference_streams
+    N, no, Tf, B, K = 20, 5, 2.0, 24, 70
+    obst, noise = reference_streams("RANDOM", range(B), no, K)
+    x0 = np.tile([-7.0, -7.0, np.pi / 4, 0, 0], (B, 1)); goal = np.tile([7.0, 7.0], (B, 1))
+    x0[B // 2:, :2] = [[-6.0, 5.0]]; goal[B // 2:] = [5.0, -6.0]
+    cfg = orc.config(N, no, Tf, qp_tol=1e-8)
+    g = GpuLoop(mpc_gpu, N, no, Tf, x0, goal, obst)
+    loops = [OracleLoop(orc, cfg, x0[b], goal[b], obst[b]) for b in range(B)]
+    worst = dict(X=0.0, x=0.0, u=0.0, margin=0.0)
+    n_fail = n_cmp = n_out = 0
+    for k in range(K):
+        if k == 25:
+            goal = goal[:, ::-1].copy() * 0.8                       # mid-episode sub-goal change on both sides
+            g.set_goal(goal)
+            for L in loops:
+                L.goal = goal[loops.index(L)].copy()
+        before = g.host()
+        for b, L in enumerate(loops):                               # resync: the oracle continues from the GPU's state
+            L.x, L.obst = before["x0"][b].copy(), before["obst"][b].copy()
+            L.X, L.U = before["X"][b].copy(), before["U"][b].copy()
+            L.min_margin, L.flags, L.steps = float(before["margin"][b]), int(before["flags"][b]), int(before["steps"][b])
+        g.step(noise[k])
+        after = g.host()
+        xN = g.m.terminal_state(B)
+        assert np.array_equal(xN, after["X"][:, -1])
+        for b, L in enumerate(loops):
+            r = L.step(noise[k, b])
+            if r is None:                                           # finished episodes idle on both sides
+                for key in ("x0", "obst", "X", "U"):
+                    assert np.array_equal(after[key][b], before[key][b]), (k, b, key)
+                assert after["steps"][b] == before["steps"][b]
+                continue
+            n_cmp += 1
+            assert after["status"][b] == r["status"], (k, b, after["status"][b], r["status"])
+            assert np.array_equal(after["obst"][b], L.obst), (k, b)                 # same noise, IEEE-exact obstacle motion
+            assert after["flags"][b] == L.flags and after["steps"][b] == L.steps, (k, b)
+            if r["status"] == 4:
+                n_fail += 1
+            if r["status"] != 0:
+                continue                                            # capped / failed QPs: iterates need not agree (the statuses did)
+            d = max(np.abs(after["X"][b] - L.X).max(), np.abs(after["U"][b] - L.U).max())
+            if d > 1e-6:
+                # an ill-conditioned QP at the float64 floor of the interior point (0.03-0.1 % of the solves at this size):
+                # judged by the QP itself -- the GPU's step, un-shifted, must satisfy the linearised dynamics and the boxes of the QP the
+                # oracle assembles from the same inputs, with an objective not above the oracle's
+                n_out += 1
+                Xn = np.vstack([before["x0"][b][None], after["X"][b][:N]]); Un = np.vstack([after["u0"][b][None], after["U"][b][:N - 1]])
+                P = orc.predict_params(cfg, before["obst"][b])
+                fg, eqg, bg = qp_merit(orc, cfg, before["x0"][b], P, goal[b], before["X"][b], before["U"][b], Xn, Un)
+                fo, _, _ = qp_merit(orc, cfg, before["x0"][b], P, goal[b], before["X"][b], before["U"][b], r["X"], r["U"])
+                assert eqg <= 1e-7 and bg <= 1e-7 and fg <= fo + 1e-7 * max(1.0, abs(fo)) and d < 2e-2, (k, b, d, fg, fo, eqg, bg)
+                continue
+            worst["X"] = max(worst["X"], d)
+            worst["x"] = max(worst["x"], np.abs(after["x0"][b] - L.x).max())
+            worst["u"] = max(worst["u"], np.abs(after["u0"][b] - r["u0"]).max())
+            worst["margin"] = max(worst["margin"], abs(after["margin"][b] - L.min_margin))
+            assert abs(after["iters"][b] - r["iters"]) <= 1, (k, b)
+    g.close()
+    assert n_cmp > 0.7 * B * K and n_out <= 0.01 * n_cmp, (n_cmp, n_out)
+    assert worst["X"] <= 1e-6 and worst["u"] <= 8e-6 and worst["x"] <= 1e-6 and worst["margin"] <= 1e-6, worst
+
+
+def test_free_running_episodes_three_way(env):
+    """No resync: the GPU episode harness, the oracle loop and the RECORDED reference rows for 12 seeds on which acados' QP always
+    converged -- three independent computations of the same closed loop land on the same table rows."""
+    import json
+    import os
+    mpc_gpu, orc = env
+    from mpc_gpu.world import reference_streams
+    rows = np.array(json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_tables.json")))["tables"]["20221031_215846"]["rows"])
+    seeds = [0, 2, 3, 4, 5, 24, 25, 36, 41, 53, 63, 65]
+    N, no, Tf = 20, 5, 2.0
+    obst, noise = reference_streams("RANDOM", seeds, no, 400)
+    B = len(seeds)
+    x0 = np.tile([-7.0, -7.0, np.pi / 4, 0, 0], (B, 1)); goal = np.tile([7.0, 7.0], (B, 1))
+    tb = mpc_gpu.run_episodes(x0, goal, obst, N=N, Tf=Tf, max_iter=400, noise=noise, qp_iter_max=100)["table"]
+    cfg = orc.config(N, no, Tf, qp_tol=1e-8, qp_iter_max=100)
+    for b in range(B):
+        L = OracleLoop(orc, cfg, x0[b], goal[b], obst[b])
+        for k in range(400):
+            if L.step(noise[k, b]) is None:
+                break
+        o = np.array(L.row())
+        assert np.array_equal(o[[0, 1, 4, 5]], tb[b, [0, 1, 4, 5]]) and np.abs(o[2:4] - tb[b, 2:4]).max() <= 1e-5, (seeds[b], o, tb[b])
+        assert np.array_equal(tb[b, [0, 1, 4, 5]], rows[seeds[b], [0, 1, 4, 5]]) and np.abs(tb[b, 2:4] - rows[seeds[b], 2:4]).max() <= 1e-5
+
+
+def test_explicit_slack_schedule(env):
+    """mpc_set_slack_schedule: (i) the reference's own schedule passed explicitly changes nothing (to rounding); (ii) a different
+    schedule (constant weight, zero on the last three stages) agrees with the oracle given the same weights; (iii) NULL restores
+    the built-in schedule; (iv) the shim forwards cost_set('zl'|'Zl') and refuses what the kernel cannot represent."""
+    mpc_gpu, orc = env
+    N, no, B = 20, 3, 48
+    x0, goal, obst = random_batch(B, no, seed=77)
+    cfg = orc.config(N, no, 2.0, qp_tol=1e-8)
+    P = oracle_P(orc, cfg, obst); Xg, Ug = oracle_guess(orc, cfg, x0)
+    own = np.stack([orc.slack_alpha(cfg, x0[b], goal[b]) for b in range(B)])
+    other = np.full((B, N + 1), 3.0e5); other[:, -3:] = 0.0
+    with mpc_gpu.BatchedMpc(N, no, 2.0, max_batch=B) as s:
+        s.set_warmstart(Xg, Ug); a = s.solve(x0, P, goal); Xa, Ua = s.get_traj(B)
+        s.set_slack_schedule(own)
+        s.set_warmstart(Xg, Ug); b = s.solve(x0, P, goal); Xb, Ub = s.get_traj(B)
+        # (to rounding: the kernel evaluates the schedule with fused multiply-adds, the host formula without)
+        assert np.abs(Xa - Xb).max() <= 1e-9 and np.abs(Ua - Ub).max() <= 1e-9 and np.array_equal(a["iters"], b["iters"]) and np.array_equal(a["status"], b["status"])
+        s.set_slack_schedule(other)
+        s.set_warmstart(Xg, Ug); c = s.solve(x0, P, goal); Xc, Uc = s.get_traj(B)
+        s.set_slack_schedule(None)
+        s.set_warmstart(Xg, Ug); d = s.solve(x0, P, goal); Xd, _ = s.get_traj(B)
+        assert np.array_equal(Xa, Xd)
+        with pytest.raises(mpc_gpu.MpcError):
+            s.set_slack_schedule(-other)
+    moved = 0
+    for i in range(B):
+        r = orc.rti_solve(cfg, x0[i], P[i], goal[i], Xg[i], Ug[i], alpha=other[i])
+        assert r["status"] == c["status"][i]
+        if r["status"] == 0:
+            assert np.abs(r["X"] - Xc[i]).max() <= 1e-6 and np.abs(r["U"] - Uc[i]).max() <= 8e-6
+            assert abs(r["cost"] - c["cost"][i]) <= 1e-8 * max(1.0, abs(r["cost"]))
+            moved += np.abs(Xc[i] - Xa[i]).max() > 1e-4
+    assert moved >= 3                                               # the schedule matters wherever an obstacle row is active
+    # the shim: what the caller sets is what the solve uses
+    from mpc_gpu.acados_shim import AcadosOcpSolverShim
+    with mpc_gpu.BatchedMpc(N, no, 2.0, max_batch=1) as m:
+        sh = AcadosOcpSolverShim(N, no, 2.0, goal=goal[0], x0=x0[0], mpc=m)
+        for i in range(N + 1):
+            sh.set(i, "x", Xg[0, i]); sh.set(i, "p", P[0, i].reshape(-1))
+            sh.cost_set(i, "zl", other[0, i] * np.ones(no)); sh.cost_set(i, "Zl", other[0, i] * np.ones(no))
+            if i < N:
+                sh.set(i, "u", Ug[0, i])
+        assert sh.solve() == c["status"][0]
+        assert np.array_equal(np.array([sh.get(i, "x") for i in range(N + 1)]), Xc[0])
+        sh.cost_set(3, "Zl", 2 * other[0, 3] * np.ones(no))
+        with pytest.raises(ValueError):
+            sh.solve()                                              # zl != Zl is not the reference's schedule
+        with pytest.raises(ValueError):
+            sh.cost_set(2, "zl", np.array([1.0, 2.0, 3.0]))         # per-obstacle weights neither
+
+
+def test_outliers_are_judged_by_the_qp_not_by_a_count(env):
+    """N = 50 with 10 obstacles (C5's problem): a percent of the instances differ from the oracle by more than 1e-6 -- ill-conditioned
+    QPs at the float64 floor of any interior point.  For EVERY converged instance the GPU's step must be a point of
+    the QP the oracle assembles that is as good as the oracle's own: dynamics satisfied, inside the boxes, objective not worse."""
+    mpc_gpu, orc = env
+    N, no, B = 50, 10, 96
+    x0, goal, obst = random_batch(B, no, seed=1234)
+    cfg = orc.config(N, no, 5.0, qp_tol=1e-8)
+    P = oracle_P(orc, cfg, obst); Xg, Ug = oracle_guess(orc, cfg, x0)
+    with mpc_gpu.BatchedMpc(N, no, 5.0, max_batch=B) as s:
+        s.set_warmstart(Xg, Ug); g = s.solve(x0, P, goal); X1, U1 = s.get_traj(B)
+        s.shift(B); Xs, Us = s.get_traj(B)
+        g2 = s.solve(x0, P, goal); X2, U2 = s.get_traj(B)
+    o1 = orc.rti_solve_batch(cfg, x0, P, goal, Xg, Ug)
+    o2 = orc.rti_solve_batch(cfg, x0, P, goal, Xs, Us)
+    n_out = 0
+    for (gg, Xa, Ua, oo, Xin, Uin) in ((g, X1, U1, o1, Xg, Ug), (g2, X2, U2, o2, Xs, Us)):
+        assert (gg["status"] == oo["status"]).mean() >= 0.97
+        for b in np.nonzero((gg["status"] == 0) & (oo["status"] == 0))[0]:
+            d = np.abs(Xa[b] - oo["X"][b]).max()
+            if d <= 1e-6:
+                continue
+            n_out += 1
+            fg, eqg, bg = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xin[b], Uin[b], Xa[b], Ua[b])
+            fo, eqo, bo = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xin[b], Uin[b], oo["X"][b], oo["U"][b])
+            assert eqg <= 1e-7 and bg <= 1e-7, (b, d, eqg, bg)
+            assert fg <= fo + 1e-7 * max(1.0, abs(fo)), (b, d, fg, fo)
+            assert d < 5e-3
+    print("outliers judged by the QP:", n_out)

@@ -7,7 +7,7 @@ qp_tol = 1e-8 and cap QP_ITER = 50, so the observed differences are far below th
 import numpy as np
 import pytest
 
-from helpers import oracle_P, oracle_guess, random_batch
+from helpers import oracle_P, oracle_guess, qp_merit, random_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -362,9 +362,15 @@ def test_stage_split_matches_one_lane_per_stage_and_oracle(env, N, no, B):
         assert (g["iters"][ok] == o["iters"][ok]).mean() > 0.95
         tol = 1e-6 if N <= 20 else 5e-5           # longer horizons: an ill-conditioned instance or two sit at 1e-6 on either mapping
         d = np.abs(X - o["X"]).reshape(B, -1).max(1)[ok]; dU = np.abs(U - o["U"]).reshape(B, -1).max(1)[ok]
-        # an ill-conditioned QP or two per batch (10 obstacles, long horizons) sit at the float64 floor of the interior point
-        # on EVERY mapping: at most 2 instances may exceed the tolerance, and then by less than 1e-3
-        assert (d > tol).sum() <= (2 if no == 10 else 0) and d.max() < 1e-3 and np.quantile(d, 0.9) < 1e-8 and (dU > 8 * tol).sum() <= (2 if no == 10 else 0)
+        # an ill-conditioned QP or two per batch (10 obstacles, long horizons) sit at the float64 floor of the interior point on EVERY
+        # mapping.  Such an instance is judged by the QP itself, not by a count: the GPU's step must satisfy the
+        # linearised dynamics and the boxes and its QP objective must not exceed the oracle's (helpers.qp_merit, orc_export_qp)
+        assert d.max() < 1e-3 and np.quantile(d, 0.9) < 1e-8
+        for b in np.nonzero(ok)[0][(d > tol) | (dU > 8 * tol)]:
+            assert no == 10 or N > 20, (b, d.max())
+            fg, eqg, bg = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xg[b], Ug[b], X[b], U[b])
+            fo, _, _ = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xg[b], Ug[b], o["X"][b], o["U"][b])
+            assert eqg <= 1e-7 and bg <= 1e-7 and fg <= fo + 1e-7 * max(1.0, abs(fo)), (b, fg, fo, eqg, bg)
         rel = np.abs(g["cost"] - o["cost"])[ok] / np.maximum(1.0, np.abs(o["cost"][ok]))
         assert np.sort(rel)[-3 if no == 10 else -1] < (1e-8 if N <= 20 else 1e-6)
         if lps > 1:
