@@ -39,10 +39,39 @@ def build(force=False):
     return so
 
 
+_BENCH = False
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def use_bench_build():
+    """bench.py's cpu_baseline leg only: switch this process to liborc_bench.so, the same source built -O3 -march=native ON THE BOX THAT
+    RUNS IT (rebuilt when the CPU model differs from the one it was built on).  The checker the tests use stays -O2 -ffp-contract=off."""
+    global _LIB, _BENCH
+    so, tag = os.path.join(_HERE, "liborc_bench.so"), os.path.join(_HERE, "liborc_bench.host")
+    src = [os.path.join(_HERE, f) for f in ("mpc_oracle.c", "mpc_oracle.h")]
+    stale = (not os.path.exists(so) or not os.path.exists(tag) or open(tag).read() != _cpu_model()
+             or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src))
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liborc_bench.so"], stdout=subprocess.DEVNULL)
+        open(tag, "w").write(_cpu_model())
+    _BENCH = True
+    _LIB = None
+    return so
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
+        _LIB = C.CDLL(os.path.join(_HERE, "liborc_bench.so") if _BENCH else build())
         L = _LIB
         cp = C.POINTER(OrcConfig)
         L.orc_default_config.argtypes = [cp, C.c_int, C.c_int, _d]

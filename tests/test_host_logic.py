@@ -77,3 +77,21 @@ def test_cost_allgather_world_size_2_gloo(built, tmp_path):
                         "--master-port", "29533", str(script)], env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+@pytest.mark.parametrize("workload,total", [("c4", 262144), ("c5", 32768), ("c2", 2048)])
+def test_bench_multi_rank_path_world_size_2_gloo(built, workload, total):
+    """`python bench.py --gpus 2` starts its two ranks itself (torch.distributed.run), every rank takes its shard_slice of the
+    workload's ONE global batch and the per-scenario costs of 50 control steps are exchanged with sharding.gather_costs -- rehearsed
+    on CPU with gloo (--dry-run: the same plumbing, no kernels; each cost is the instance's global index, so a wrong slice or a
+    wrong gather order is visible)."""
+    import json
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--workload", workload, "--steps", "1",
+                        "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["gather_check"] is True and line["config"]["global_batch"] == total
+    assert line["config"]["rank0_slice"] == [0, total // 2] and line["scaling"] == ("weak" if workload == "c2" else "strong")
