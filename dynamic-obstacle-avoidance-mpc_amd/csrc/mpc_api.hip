@@ -42,6 +42,7 @@ struct mpc_handle {
     int use_mfma;                     // matrix-core Riccati factorisation when one instance per wavefront is chosen
     int row_parallel;                 // row-parallel (64-bit DPP) Riccati factorisation instead of the one-lane systolic sweep
     int split_override;               // lanes per horizon stage: 0 automatic, 1 one lane per stage, 2 / 3 split kernel (mpc_set_lanes_per_stage)
+    int waves_override;               // wavefronts per SIMD of the split kernel: 0 automatic, 1, 2 (mpc_set_waves_per_simd)
     int simd_count;                   // SIMDs of the device (4 per compute unit)
     int profiling;                    // 0 off, k > 0: HIP events around every k-th solve launch
     int launch_count;
@@ -106,23 +107,36 @@ int pick_lanes(mpc_handle *h, int batch)
     // the matrix-core factorisation (opt-in, mpc_set_matrix_cores) maps one instance per wavefront; it is used for
     // batches of up to one instance per SIMD (1024 on MI355X), beyond that packing instances per wavefront wins
     if (batch <= 1024 && h->use_mfma) G = 64;
+    if (h->lanes_override == 21) return 21;       // three instances per wavefront (N <= 20, row-parallel sweeps)
     if (h->lanes_override >= G || (h->lanes_override && h->lanes_override >= need)) G = h->lanes_override;
     return G;
 }
 
-// Lanes per horizon stage.  A batch of about one instance per SIMD cannot fill the machine by packing instances into wavefronts; each
-// wavefront is then bound by the length of its own instruction stream, and dealing the inequality rows of a stage out to 3 (N <= 20)
-// or 2 (N <= 31) lanes shortens that stream (rti_split_kernel.hpp).  With one instance per wavefront every instance also stops at its
-// own iteration, so the mapping keeps winning while the batch is a few waves of wavefronts deep -- measured on the randomized C3
-// workload (scripts/split_at_scale.py): +26 % at 1536, +15 % at 2048, +13 % at 4096, +3 % at 8192, -7 % at 16384, -16 % at 65536.
-// Larger batches keep one lane per stage and 64/G instances per wavefront.
+// Which lane mapping runs a batch (measured on MI355X, randomized C3-style workloads, scripts/w2_probe.py -> profiles/r02_w2_probe_*.json;
+// M solves/s at a batch of 65536, split 1 wavefront/SIMD | split 2 wavefronts/SIMD | one lane per stage):
+//     N = 20,  3 obstacles: 10.5 | 13.3 | 12.6        N = 20,  5 obstacles: 8.8 | 9.0 | 8.7        N = 20, 10 obstacles: 6.2 | 4.4 | 3.0
+//     N = 31,  3 obstacles:  5.0 |  6.2 |  5.7        N = 10,  3 obstacles: 16.0 | 19.9 | 26.4      N = 10,  5 obstacles: 13.4 | 12.4 | 14.0
+// * the stage-split mapping (rows of a stage over 3 lanes for N <= 20, 2 for N <= 31, one instance per wavefront; rti_split_kernel.hpp)
+//   wins wherever the horizon fits it, at every batch size, with one exception: 3 obstacles and N + 2 <= 16, where the one-lane mapping packs
+//   FOUR instances into a wavefront and overtakes beyond ~8 instances per SIMD;
+// * with 5 or 10 obstacles the one-lane mapping's row state no longer fits the register file (44 - 790 bytes of scratch per lane), which the
+//   split mapping avoids -- 2.1x at 10 obstacles;
+// * two wavefronts per SIMD (256 registers, compact LDS blocks) pay for 3 obstacles once the batch is more than ~4 instances per SIMD deep
+//   (+26 % over one wavefront at 65536); with more obstacles the 256-register build spills 500 - 1150 bytes per lane and loses.
 int pick_split(mpc_handle *h, int batch)
 {
     if (h->use_mfma || !h->row_parallel || h->lanes_override) return 1;
     const int N = h->cfg.N;
     const int fit = N <= 20 ? 3 : (N <= 31 ? 2 : 1);
-    if (h->split_override == 0) return batch <= 8 * h->simd_count ? fit : 1;
-    return h->split_override <= fit ? h->split_override : fit;
+    if (h->split_override) return h->split_override <= fit ? h->split_override : fit;
+    if (h->cfg.n_obst == 3 && N + 2 <= 16 && batch > 8 * h->simd_count) return 1;
+    return fit;
+}
+
+int pick_waves(mpc_handle *h, int batch)
+{
+    if (h->waves_override) return h->waves_override;
+    return (h->cfg.n_obst == 3 && batch > 4 * h->simd_count) ? 2 : 1;
 }
 
 // More than 64 KB of dynamic LDS has to be granted per kernel function and device; the grant is remembered (largest size so far per
@@ -139,14 +153,20 @@ int grant_lds(K kernel, int (&granted)[kMaxDevices], int device, size_t lds)
     return MPC_OK;
 }
 
+template <int NO, int LPS, bool W2>
+int launch_split_w(mpc_handle *h, const mpc::KParams &p, hipStream_t s)
+{
+    static int granted[kMaxDevices] = {};
+    const size_t lds = (size_t)mpc::SplitLds<LPS, NO, W2>::total(p.N, p.obst != nullptr) * sizeof(double);
+    int rc = grant_lds(&mpc::rti_split_kernel<NO, LPS, W2>, granted, h->device, lds); if (rc) return rc;
+    hipLaunchKernelGGL((mpc::rti_split_kernel<NO, LPS, W2>), dim3(p.batch), dim3(64), lds, s, p);
+    return MPC_OK;
+}
+
 template <int NO, int LPS>
 int launch_split(mpc_handle *h, const mpc::KParams &p, hipStream_t s)
 {
-    static int granted[kMaxDevices] = {};
-    const size_t lds = (size_t)mpc::SplitLds<LPS, NO>::total(p.N, p.obst != nullptr) * sizeof(double);
-    int rc = grant_lds(&mpc::rti_split_kernel<NO, LPS>, granted, h->device, lds); if (rc) return rc;
-    hipLaunchKernelGGL((mpc::rti_split_kernel<NO, LPS>), dim3(p.batch), dim3(64), lds, s, p);
-    return MPC_OK;
+    return pick_waves(h, p.batch) == 2 ? launch_split_w<NO, LPS, true>(h, p, s) : launch_split_w<NO, LPS, false>(h, p, s);
 }
 
 template <int NO, int G, int FACT>
@@ -161,6 +181,7 @@ int launch_one_lane(mpc_handle *h, const mpc::KParams &p, hipStream_t s, dim3 gr
 template <int NO>
 int launch_one_lane_g(mpc_handle *h, const mpc::KParams &p, hipStream_t s, dim3 grid, size_t lds, int G, bool use_mfma, bool rowpar)
 {
+    if (G == 21) return launch_one_lane<NO, 21, 2>(h, p, s, grid, lds);
     if (G == 16) return rowpar ? launch_one_lane<NO, 16, 2>(h, p, s, grid, lds) : launch_one_lane<NO, 16, 0>(h, p, s, grid, lds);
     if (G == 32) return rowpar ? launch_one_lane<NO, 32, 2>(h, p, s, grid, lds) : launch_one_lane<NO, 32, 0>(h, p, s, grid, lds);
     if (use_mfma) return launch_one_lane<NO, 64, 1>(h, p, s, grid, lds);
@@ -187,7 +208,10 @@ int dispatch_solve(mpc_handle *h, const mpc::KParams &p, hipStream_t s)
         const dim3 grid((p.batch + 64 / G - 1) / (64 / G));
         const bool use_mfma = (G == 64) && h->use_mfma;
         const bool rowpar = !use_mfma && h->row_parallel;
-        const size_t lds = ((p.obst ? (size_t)(64 / G) * (p.N + 1) * h->cfg.n_obst * 2 : 0) + (use_mfma ? (size_t)mpc::MfmaLds::doubles(p.N) : 0) +
+        if (G == 21 && !rowpar) return fail(MPC_ERR_ARG, "three instances per wavefront need the row-parallel sweeps");
+        // G = 21: compact stage blocks, look-ahead staged inside them (13.5 KB per instance at N = 20: four wavefronts of three per CU)
+        const size_t lds = G == 21 ? (size_t)mpc::RowLdsC::total(p.N, 3) * sizeof(double) :
+                           ((p.obst ? (size_t)(64 / G) * (p.N + 1) * h->cfg.n_obst * 2 : 0) + (use_mfma ? (size_t)mpc::MfmaLds::doubles(p.N) : 0) +
                             (rowpar ? (size_t)mpc::RowLds::total(p.N, 64 / G) : 0)) * sizeof(double);
         switch (h->cfg.n_obst) {
         case 3: rc = launch_one_lane_g<3>(h, p, s, grid, lds, G, use_mfma, rowpar); break;
@@ -658,8 +682,8 @@ int mpc_debug_trace(mpc_handle *h, int enable, int batch, double *host_out)
 int mpc_set_lanes_per_instance(mpc_handle *h, int lanes)
 {
     if (!h) return fail(MPC_ERR_ARG, "null handle");
-    if (lanes != 0 && lanes != 16 && lanes != 32 && lanes != 64) return fail(MPC_ERR_ARG, "lanes must be 0 (automatic), 16, 32 or 64");
-    if (lanes != 0 && lanes < h->cfg.N + 2) return fail(MPC_ERR_ARG, "lanes per instance must exceed N + 1");
+    if (lanes != 0 && lanes != 16 && lanes != 21 && lanes != 32 && lanes != 64) return fail(MPC_ERR_ARG, "lanes must be 0 (automatic), 16, 21, 32 or 64");
+    if (lanes == 21 ? h->cfg.N > 20 : (lanes != 0 && lanes < h->cfg.N + 2)) return fail(MPC_ERR_ARG, "lanes per instance must exceed N + 1 (21 lanes: N <= 20)");
     h->lanes_override = lanes;
     return MPC_OK;
 }
@@ -697,6 +721,20 @@ int mpc_get_lanes_per_stage(mpc_handle *h, int batch)
 {
     if (!h) return fail(MPC_ERR_ARG, "null handle");
     return pick_split(h, batch);
+}
+
+int mpc_set_waves_per_simd(mpc_handle *h, int waves)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    if (waves < 0 || waves > 2) return fail(MPC_ERR_ARG, "wavefronts per SIMD must be 0 (automatic), 1 or 2");
+    h->waves_override = waves;
+    return MPC_OK;
+}
+
+int mpc_get_waves_per_simd(mpc_handle *h, int batch)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    return pick_split(h, batch) > 1 ? pick_waves(h, batch) : 1;
 }
 
 }  // extern "C"

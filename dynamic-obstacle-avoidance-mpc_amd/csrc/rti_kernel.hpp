@@ -25,6 +25,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 // Diagnostic build only (-DMPC_PHASE_TIMING, scripts/phase_timing.py): per-phase cycle counts into KParams::trace.
 #ifdef MPC_PHASE_TIMING
@@ -177,18 +178,22 @@ __device__ __forceinline__ double lane_value(double v, int src)
     return __hiloint2double(hi, lo);
 }
 // value held by the first lane (stage 0) of the calling lane's G-lane segment
+__device__ __forceinline__ int seg21_slot(int lane);
 template <int G>
 __device__ __forceinline__ double lane_value_seg(double v, int lane)
 {
+    if (G == 21) { const double a = lane_value(v, 0), b = lane_value(v, 21), c = lane_value(v, 42); return lane < 21 ? a : (lane < 42 ? b : c); }
     if (G == 64) return lane_value(v, 0);
     if (G == 32) { const double a = lane_value(v, 0), b = lane_value(v, 32); return lane < 32 ? a : b; }
     const double a = lane_value(v, 0), b = lane_value(v, 16), c = lane_value(v, 32), d = lane_value(v, 48);
     return lane < 16 ? a : (lane < 32 ? b : (lane < 48 ? c : d));
 }
-// G = lanes per instance (64, 32 or 16): the reduction is over the G-lane segment the calling lane belongs to.
+template <bool SUM> __device__ __forceinline__ double seg21_reduce(double v, int lane);
+// G = lanes per instance (64, 32, 21 or 16): the reduction is over the G-lane segment the calling lane belongs to.
 template <int G>
 __device__ __forceinline__ double seg_max(double v, int lane)
 {
+    if (G == 21) return seg21_reduce<false>(v, lane);
     v = fmax(v, dpp_f64<0xB1>(v));    // quad_perm [1,0,3,2]
     v = fmax(v, dpp_f64<0x4E>(v));    // quad_perm [2,3,0,1]
     v = fmax(v, dpp_f64<0x141>(v));   // row_half_mirror
@@ -201,6 +206,7 @@ __device__ __forceinline__ double seg_max(double v, int lane)
 template <int G>
 __device__ __forceinline__ double seg_sum(double v, int lane)
 {
+    if (G == 21) return seg21_reduce<true>(v, lane);
     v += dpp_f64<0xB1>(v);
     v += dpp_f64<0x4E>(v);
     v += dpp_f64<0x141>(v);
@@ -216,6 +222,7 @@ __device__ __forceinline__ double seg_sum(double v, int lane)
 template <int G, bool SUM_A>
 __device__ __forceinline__ void seg_reduce2(double &a, double &b, int lane)
 {
+    if (G == 21) { a = seg21_reduce<SUM_A>(a, lane); b = seg21_reduce<false>(b, lane); return; }
 #define MPC_RED2_STEP(CTRL) { const double a2 = dpp_f64<CTRL>(a), b2 = dpp_f64<CTRL>(b); a = SUM_A ? a + a2 : fmax(a, a2); b = fmax(b, b2); }
     MPC_RED2_STEP(0xB1) MPC_RED2_STEP(0x4E) MPC_RED2_STEP(0x141) MPC_RED2_STEP(0x140)
 #undef MPC_RED2_STEP
@@ -226,6 +233,37 @@ __device__ __forceinline__ void seg_reduce2(double &a, double &b, int lane)
     const double bl = fmax(b0, b1), bh = fmax(b2, b3);
     if (G == 32) { a = lane < 32 ? al : ah; b = lane < 32 ? bl : bh; return; }
     a = SUM_A ? al + ah : fmax(al, ah); b = fmax(bl, bh);
+}
+
+// G = 21: THREE instances per wavefront in lanes [0, 21), [21, 42), [42, 63) (lane 63 idles).  The segments do not coincide with the
+// 16-lane DPP rows -- rows 1 and 2 hold the tail of one instance and the head of the next -- so a reduction runs as two masked row
+// reductions (pass L: in every row the lanes of the row's lower instance, pass U: the others; the neutral element elsewhere) whose six
+// row results are combined per instance:  inst 0 = L0 + L1,  inst 1 = U1 + L2,  inst 2 = U2 + L3.  Fixed order: deterministic.
+__device__ __forceinline__ int seg21_slot(int lane) { return lane >= 42 ? 2 : (lane >= 21 ? 1 : 0); }
+__device__ __forceinline__ bool seg21_lower(int lane)
+{   // lower instance of row r: rows 0, 1 -> 0; row 2 -> 1; row 3 -> 2
+    const int row = lane >> 4, slot = seg21_slot(lane);
+    return slot == (row <= 1 ? 0 : row - 1);
+}
+template <bool SUM>
+__device__ __forceinline__ double row_reduce(double v)
+{
+#define MPC_ROW_STEP(CTRL) { const double w = dpp_f64<CTRL>(v); v = SUM ? v + w : fmax(v, w); }
+    MPC_ROW_STEP(0xB1) MPC_ROW_STEP(0x4E) MPC_ROW_STEP(0x141) MPC_ROW_STEP(0x140)
+#undef MPC_ROW_STEP
+    return v;
+}
+template <bool SUM>
+__device__ __forceinline__ double seg21_reduce(double v, int lane)
+{
+    const bool low = seg21_lower(lane);
+    const double id = SUM ? 0.0 : -INFINITY;
+    const double vl = row_reduce<SUM>(low ? v : id), vu = row_reduce<SUM>(low ? id : v);
+    const double l0 = lane_value(vl, 0), l1 = lane_value(vl, 16), l2 = lane_value(vl, 32), l3 = lane_value(vl, 48);
+    const double u1 = lane_value(vu, 16), u2 = lane_value(vu, 32);
+    const double r0 = SUM ? l0 + l1 : fmax(l0, l1), r1 = SUM ? u1 + l2 : fmax(u1, l2), r2 = SUM ? u2 + l3 : fmax(u2, l3);
+    const int slot = seg21_slot(lane);
+    return slot == 0 ? r0 : (slot == 1 ? r1 : r2);
 }
 
 // reciprocal: hardware seed + two Newton steps (1-2 ulp); used for 1/t of the inequality rows
@@ -414,6 +452,8 @@ struct RowLds {
     // instance's H that lands in a rear padding, in front of H in the instance's own W region (plus a front padding when
     // W is shorter than that).  Lanes that have nothing to store write into the unused tail [TAIL..HS) of the stage blocks.
     static constexpr int AHEAD = 3, TAIL = 48;
+    static constexpr int DEADK = 48, DEADF = 50;      // dead-store words of idle lanes: K~ rows go to [x], [x + 8]; factors to [x], [x + 1], [x + 8]
+    static constexpr bool COMPACT = false;
     static __host__ __device__ constexpr int per_instance(int N) { return WS * N + HS * (N + 1); }   // doubles
     static __host__ __device__ constexpr int pad_front(int N) { return AHEAD * HS > WS * (N - 1) ? AHEAD * HS - WS * (N - 1) : WS; }   // >= one W block
     static __host__ __device__ constexpr int pad_rear() { return AHEAD * HS; }
@@ -426,11 +466,34 @@ struct RowLds {
     __device__ __forceinline__ RowLds(double *base, int N, double *results) : W(base), H(base + WS * N), R(results) {}
 };
 
+// COMPACT LAYOUT (three instances per wavefront, G = 21): the dense blocks above cost 17.5 KB of LDS per instance, which lets a CU hold 8
+// instances (4 wavefronts x 2) -- 12 (4 x 3) need <= 13.6 KB each.  What is stored here is what the sweeps cannot synthesise:
+//   W~_t: rows 0, 1 of [A b B] (16 words) and b_t[2..4] (3 words) -- rows 2..4 are constants (0, 1, dt, dt^2/2) except their affine entry,
+//         so every lane but lane 5 reads them from a 24-word table shared by the wavefront (same instruction, per-lane base and stride);
+//   H~aug_t: rows 0..5 (48 words) + [48] = H66, [49] = [50] = 0, [51] = H77: rows 6, 7 are zero except H[6][5] = H[5][6], H[7][5] = H[5][7]
+//         (already in row 5, words 46, 47) and the two diagonal entries, so ONE ds_read2_b64 with a per-lane base
+//         (lanes 0..4: 49, lane 5: 46, lane 6: 48, lane 7: 50) delivers (H[6][j], H[7][j]) to every lane.
+// Results overlay the block exactly as in the dense layout (RowVec: words 0..44); dead-store words of idle lanes are 47, 48, 55.
+struct RowLdsC {
+    static constexpr int WS = 21, HS = 57;
+    static constexpr int AHEAD = 3, TAIL = 48;
+    static constexpr int DEADK = 47, DEADF = 47;      // K~ rows go to [x], [x + 8]; factors to [x], [x + 1], [x + 8]
+    static constexpr int CT = 24;                     // constant table: [3 j + m] = W~[2 + m][j] for j != 5
+    static constexpr bool COMPACT = true;
+    static __host__ __device__ constexpr int per_instance(int N) { return WS * N + HS * (N + 1); }
+    static __host__ __device__ constexpr int pad_front(int N) { return AHEAD * HS > WS * (N - 1) ? AHEAD * HS - WS * (N - 1) : WS; }
+    static __host__ __device__ constexpr int pad_rear() { return AHEAD * HS; }
+    static __host__ __device__ constexpr int total(int N, int instances) { return CT + pad_front(N) + instances * per_instance(N) + pad_rear(); }
+    double *W, *H, *R, *C;
+    __device__ __forceinline__ RowLdsC(double *base, int N, double *table) : W(base), H(base + WS * N), R(base + WS * N), C(table) {}
+};
+
 __device__ __forceinline__ uint32_t lds_address(const void *p) { return (uint32_t)(uintptr_t)p; }     // low half of a flat LDS address = LDS byte offset
 
-__device__ __forceinline__ void rowpar_factor(int lane, int N, const RowLds L, bool worker_row)
+template <class LT>
+__device__ __forceinline__ void rowpar_factor(int lane, int N, const LT L, bool worker_row)
 {
-    constexpr int WS = RowLds::WS, HS = RowLds::HS;
+    constexpr int WS = LT::WS, HS = LT::HS;
     const int j = lane & 7, l15 = lane & 15;    // column; lanes 8..15 of a row mirror 0..7
     const bool store = worker_row && l15 < 6, store0 = worker_row && l15 == 0;
     const double d5 = (j == 5) ? 1.0 : 0.0;     // row 5 of W~ is e_5'
@@ -438,13 +501,31 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const RowLds L, b
     // Stores are unconditional: lanes with nothing to store write into dead parts of the same block ([16..63]).
     // (two per-lane pointers, the rest are immediate offsets: K~[1][j] is 8 words behind K~[0][j], 1/d1 8 words behind 1/d0, and the
     // dead words an idle lane hits instead -- 48, 56 resp. 50, 51, 58 -- lie in rows 6, 7 of the block, consumed one stage earlier)
-    double *kp = L.R + (store ? j : 48), *fp = L.R + (store0 ? 6 : 50);
+    double *kp = L.R + (store ? j : LT::DEADK), *fp = L.R + (store0 ? 6 : LT::DEADF);
     const double *wp = L.W + j, *hp = L.H + j;
+    // compact layout only: rows 2..4 of W~ (lane 5: the stage's b[2..4], stride WS; other lanes: the wavefront's constant table, stride 0)
+    // and rows 6, 7 of H~aug through a per-lane base
+    const double *bp = nullptr, *h6p = nullptr;
+    int bstride = 0;
+    if constexpr (LT::COMPACT) {
+        bp = (j == 5) ? L.W + 16 : L.C + 3 * j;
+        bstride = (j == 5) ? WS : 0;
+        h6p = L.H + (j < 5 ? 49 : (j == 5 ? 46 : (j == 6 ? 48 : 50)));
+    }
     auto fetch = [&](int t, double Wc[5], double Hc[8]) {
+        if constexpr (LT::COMPACT) {
+            Wc[0] = wp[WS * t]; Wc[1] = wp[WS * t + 8];
 #pragma unroll
-        for (int k = 0; k < 5; k++) Wc[k] = wp[WS * t + k * 8];
+            for (int m = 0; m < 3; m++) Wc[2 + m] = bp[bstride * t + m];
 #pragma unroll
-        for (int i = 0; i < 8; i++) Hc[i] = hp[HS * t + i * 8];
+            for (int i = 0; i < 6; i++) Hc[i] = hp[HS * t + i * 8];
+            Hc[6] = h6p[HS * t]; Hc[7] = h6p[HS * t + 1];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 5; k++) Wc[k] = wp[WS * t + k * 8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) Hc[i] = hp[HS * t + i * 8];
+        }
     };
     // first half of a stage: T = P~ W~ from the previous stage's P~ (the upper-left 6 x 6 of its M registers)
     auto stepT = [&](const double Wc[5], const double Pc[8], double T[6]) {
@@ -1036,12 +1117,12 @@ __device__ __forceinline__ void rowpar_vector(int lane, int N, const RowLds L, b
 // (only the previous pair's store is younger than its operands).  The compiler never sees a register with a load in flight: the block
 // drains the LDS queue before it ends.  Four stages per loop pass; the leading N mod 4 stages run through the plain path; the adjoint
 // sweep also computes p_0 (unused) so that both directions take N steps.
-#define MPC_VEC_ASM_FWD \
+#define MPC_VEC_ASM_FWD_S(S) \
         "v_mov_b64_e32 v[230:231], %0\n" \
         "ds_read2_b64 v[180:183], %1 offset0:0 offset1:1\n" \
         "ds_read2_b64 v[184:187], %1 offset0:2 offset1:3\n" \
         "ds_read2_b64 v[188:191], %1 offset0:4 offset1:5\n" \
-        "v_add_u32_e32 %1, 0x410, %1\n" \
+        "v_add_u32_e32 %1, " S ", %1\n" \
         "s_waitcnt lgkmcnt(0)\n" \
         "1:\n" \
         "s_waitcnt lgkmcnt(1)\n" \
@@ -1052,7 +1133,7 @@ __device__ __forceinline__ void rowpar_vector(int lane, int N, const RowLds L, b
         "v_fmac_f64_dpp v[228:229], v[230:231], v[182:183] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
         "ds_read2_b64 v[200:203], %1 offset0:4 offset1:5\n" \
         "v_fmac_f64_dpp v[228:229], v[230:231], v[184:185] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_add_u32_e32 %1, 0x410, %1\n" \
+        "v_add_u32_e32 %1, " S ", %1\n" \
         "v_fmac_f64_dpp v[228:229], v[230:231], v[186:187] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
         "v_fmac_f64_dpp v[228:229], v[230:231], v[188:189] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
         "v_mov_b64_e32 v[230:231], v[190:191]\n" \
@@ -1066,7 +1147,7 @@ __device__ __forceinline__ void rowpar_vector(int lane, int N, const RowLds L, b
         "v_mov_b32_dpp v228, v230 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3\n" \
         "v_mov_b32_dpp v229, v231 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3\n" \
         "ds_write_b64 %2, v[228:229]\n" \
-        "v_add_u32_e32 %2, 0x410, %2\n" \
+        "v_add_u32_e32 %2, " S ", %2\n" \
         "s_waitcnt lgkmcnt(1)\n" \
         "v_mov_b64_e32 v[228:229], v[202:203]\n" \
         "ds_read2_b64 v[180:183], %1 offset0:0 offset1:1\n" \
@@ -1075,7 +1156,7 @@ __device__ __forceinline__ void rowpar_vector(int lane, int N, const RowLds L, b
         "v_fmac_f64_dpp v[228:229], v[230:231], v[194:195] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
         "ds_read2_b64 v[188:191], %1 offset0:4 offset1:5\n" \
         "v_fmac_f64_dpp v[228:229], v[230:231], v[196:197] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_add_u32_e32 %1, 0x410, %1\n" \
+        "v_add_u32_e32 %1, " S ", %1\n" \
         "v_fmac_f64_dpp v[228:229], v[230:231], v[198:199] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
         "v_fmac_f64_dpp v[228:229], v[230:231], v[200:201] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
         "v_mov_b64_e32 v[230:231], v[202:203]\n" \
@@ -1089,18 +1170,18 @@ __device__ __forceinline__ void rowpar_vector(int lane, int N, const RowLds L, b
         "v_mov_b32_dpp v228, v230 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3\n" \
         "v_mov_b32_dpp v229, v231 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3\n" \
         "ds_write_b64 %2, v[228:229]\n" \
-        "v_add_u32_e32 %2, 0x410, %2\n" \
+        "v_add_u32_e32 %2, " S ", %2\n" \
         "s_sub_u32 %3, %3, 1\n" \
         "s_cmp_lg_u32 %3, 0\n" \
         "s_cbranch_scc1 1b\n" \
         "s_waitcnt lgkmcnt(0)\n"
 
-#define MPC_VEC_ASM_BWD \
+#define MPC_VEC_ASM_BWD_S(S) \
         "v_mov_b64_e32 v[230:231], %0\n" \
         "ds_read2_b64 v[180:183], %1 offset0:0 offset1:6\n" \
         "ds_read2_b64 v[184:187], %1 offset0:12 offset1:18\n" \
         "ds_read2_b64 v[188:191], %1 offset0:24 offset1:30\n" \
-        "v_add_u32_e32 %1, 0xfffffbf0, %1\n" \
+        "v_add_u32_e32 %1, " S ", %1\n" \
         "s_waitcnt lgkmcnt(0)\n" \
         "1:\n" \
         "s_waitcnt lgkmcnt(1)\n" \
@@ -1111,7 +1192,7 @@ __device__ __forceinline__ void rowpar_vector(int lane, int N, const RowLds L, b
         "v_fmac_f64_dpp v[228:229], v[230:231], v[182:183] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
         "ds_read2_b64 v[200:203], %1 offset0:24 offset1:30\n" \
         "v_fmac_f64_dpp v[228:229], v[230:231], v[184:185] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_add_u32_e32 %1, 0xfffffbf0, %1\n" \
+        "v_add_u32_e32 %1, " S ", %1\n" \
         "v_fmac_f64_dpp v[228:229], v[230:231], v[186:187] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
         "v_fmac_f64_dpp v[228:229], v[230:231], v[188:189] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
         "v_mov_b64_e32 v[230:231], v[190:191]\n" \
@@ -1125,7 +1206,7 @@ __device__ __forceinline__ void rowpar_vector(int lane, int N, const RowLds L, b
         "v_mov_b32_dpp v228, v230 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3\n" \
         "v_mov_b32_dpp v229, v231 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3\n" \
         "ds_write_b64 %2, v[228:229]\n" \
-        "v_add_u32_e32 %2, 0xfffffbf0, %2\n" \
+        "v_add_u32_e32 %2, " S ", %2\n" \
         "s_waitcnt lgkmcnt(1)\n" \
         "v_mov_b64_e32 v[228:229], v[202:203]\n" \
         "ds_read2_b64 v[180:183], %1 offset0:0 offset1:6\n" \
@@ -1134,7 +1215,7 @@ __device__ __forceinline__ void rowpar_vector(int lane, int N, const RowLds L, b
         "v_fmac_f64_dpp v[228:229], v[230:231], v[194:195] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
         "ds_read2_b64 v[188:191], %1 offset0:24 offset1:30\n" \
         "v_fmac_f64_dpp v[228:229], v[230:231], v[196:197] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_add_u32_e32 %1, 0xfffffbf0, %1\n" \
+        "v_add_u32_e32 %1, " S ", %1\n" \
         "v_fmac_f64_dpp v[228:229], v[230:231], v[198:199] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
         "v_fmac_f64_dpp v[228:229], v[230:231], v[200:201] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
         "v_mov_b64_e32 v[230:231], v[202:203]\n" \
@@ -1148,18 +1229,25 @@ __device__ __forceinline__ void rowpar_vector(int lane, int N, const RowLds L, b
         "v_mov_b32_dpp v228, v230 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3\n" \
         "v_mov_b32_dpp v229, v231 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3\n" \
         "ds_write_b64 %2, v[228:229]\n" \
-        "v_add_u32_e32 %2, 0xfffffbf0, %2\n" \
+        "v_add_u32_e32 %2, " S ", %2\n" \
         "s_sub_u32 %3, %3, 1\n" \
         "s_cmp_lg_u32 %3, 0\n" \
         "s_cbranch_scc1 1b\n" \
         "s_waitcnt lgkmcnt(0)\n"
 
+// stride of two stage blocks in bytes: 2 * HS * 8 (dense layout HS = 65: 1040; compact layout HS = 57: 912), negative for the adjoint sweep
+#define MPC_VEC_ASM_FWD MPC_VEC_ASM_FWD_S("0x410")
+#define MPC_VEC_ASM_BWD MPC_VEC_ASM_BWD_S("0xfffffbf0")
+#define MPC_VEC_ASM_FWD_C MPC_VEC_ASM_FWD_S("0x390")
+#define MPC_VEC_ASM_BWD_C MPC_VEC_ASM_BWD_S("0xfffffc70")
+
 #define MPC_VEC_ASM_CLOBBERS "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v228", "v229", "v230", "v231", "scc", "memory"
 
-template <bool FWD>
-__device__ __forceinline__ void rowpar_vector_fast(int lane, int N, const RowLds L, bool worker_row)
+template <bool FWD, class LT>
+__device__ __forceinline__ void rowpar_vector_fast(int lane, int N, const LT L, bool worker_row)
 {
-    constexpr int HS = RowLds::HS, SS = FWD ? HS : -HS;
+    static_assert(LT::HS == 65 || LT::HS == 57, "the asm blocks carry the stage stride as a literal");
+    constexpr int HS = LT::HS, SS = FWD ? HS : -HS;
     const int r = lane & 7, rc = r < 5 ? r : 0;
     const bool store = worker_row && r < 5;
     double v = FWD ? L.R[RowVec::X + r] : L.R[HS * N + RowVec::CT + r];
@@ -1182,7 +1270,7 @@ __device__ __forceinline__ void rowpar_vector_fast(int lane, int N, const RowLds
                 "v_fmac_f64_dpp %0, %1, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
                 : "=&v"(acc) : "v"(v), "v"(cc), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]));
         v = acc;
-        dst[(worker_row && (lane & 15) < 5) ? (FWD ? RowVec::X : RowVec::P) + r : RowLds::TAIL] = v;
+        dst[(worker_row && (lane & 15) < 5) ? (FWD ? RowVec::X : RowVec::P) + r : LT::TAIL] = v;
         src += SS; dst += SS;
     }
     int passes = N >> 2;
@@ -1190,9 +1278,14 @@ __device__ __forceinline__ void rowpar_vector_fast(int lane, int N, const RowLds
         // lanes 8..15 of a row take the first stage of a pair, lanes 0..7 the second one
         const bool first = (lane & 8) != 0;
         uint32_t ra = lds_address(src + (first ? 0 : SS));
-        uint32_t rd = lds_address(dst + (first ? 0 : SS) + (store ? (FWD ? RowVec::X : RowVec::P) + r : RowLds::TAIL));
-        if (FWD) asm volatile(MPC_VEC_ASM_FWD : "+v"(v), "+v"(ra), "+v"(rd), "+s"(passes) : : MPC_VEC_ASM_CLOBBERS);
-        else     asm volatile(MPC_VEC_ASM_BWD : "+v"(v), "+v"(ra), "+v"(rd), "+s"(passes) : : MPC_VEC_ASM_CLOBBERS);
+        uint32_t rd = lds_address(dst + (first ? 0 : SS) + (store ? (FWD ? RowVec::X : RowVec::P) + r : LT::TAIL));
+        if constexpr (LT::HS == 65) {
+            if (FWD) asm volatile(MPC_VEC_ASM_FWD : "+v"(v), "+v"(ra), "+v"(rd), "+s"(passes) : : MPC_VEC_ASM_CLOBBERS);
+            else     asm volatile(MPC_VEC_ASM_BWD : "+v"(v), "+v"(ra), "+v"(rd), "+s"(passes) : : MPC_VEC_ASM_CLOBBERS);
+        } else {
+            if (FWD) asm volatile(MPC_VEC_ASM_FWD_C : "+v"(v), "+v"(ra), "+v"(rd), "+s"(passes) : : MPC_VEC_ASM_CLOBBERS);
+            else     asm volatile(MPC_VEC_ASM_BWD_C : "+v"(v), "+v"(ra), "+v"(rd), "+s"(passes) : : MPC_VEC_ASM_CLOBBERS);
+        }
     }
 }
 
@@ -1348,9 +1441,11 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 {
     constexpr bool USE_MFMA = FACT == 1, ROWPAR = FACT == 2;
     static_assert(!USE_MFMA || G == 64, "the matrix-core factorisation maps one instance per wavefront");
-    constexpr int IPW = 64 / G;               // instances per wavefront
+    static_assert(G != 21 || ROWPAR, "three instances per wavefront exist for the row-parallel sweeps only");
+    constexpr int IPW = 64 / G;               // instances per wavefront (G = 21: three, lanes [0,21), [21,42), [42,63); lane 63 idles)
+    using LT = typename std::conditional<G == 21, RowLdsC, RowLds>::type;     // LDS layout of the stage blocks
     const int lane = threadIdx.x;
-    const int slot = lane / G;
+    const int slot = (G == 21) ? seg21_slot(lane) : lane / G;
     const int inst_raw = blockIdx.x * IPW + slot;
     const bool valid = inst_raw < p.batch;    // tail wavefront: surplus slots replay the last instance and store nothing
     const int inst = valid ? inst_raw : p.batch - 1;
@@ -1372,11 +1467,20 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     // obstacle parameters of this stage: explicit P (reference API, parameterize_model) or the look-ahead computed here
     extern __shared__ double lds_raw[];
     const MfmaLds ML(lds_raw, N);             // used only when USE_MFMA (the launch sizes the allocation accordingly)
-    const RowLds RL(lds_raw + (ROWPAR ? RowLds::pad_front(N) + slot * RowLds::per_instance(N) : 0), N);     // used only when ROWPAR
+    // RL: the stage blocks of THIS lane's instance (row phases); RS: those of the instance whose sweeps this lane works on -- the same,
+    // except with three instances per wavefront, where the sweep of instance w runs in DPP row w (lanes 16 w .. 16 w + 15)
+    auto blocks_of = [&](int which) {
+        if constexpr (G == 21) return RowLdsC(lds_raw + RowLdsC::CT + RowLdsC::pad_front(N) + which * RowLdsC::per_instance(N), N, lds_raw);
+        else return RowLds(lds_raw + (ROWPAR ? RowLds::pad_front(N) + which * RowLds::per_instance(N) : 0), N);
+    };
+    const LT RL = blocks_of(slot);                                  // used only when ROWPAR
+    const LT RS = blocks_of(G == 21 ? (lane >> 4 < 3 ? lane >> 4 : 2) : slot);
+    const bool sweep_worker = (G == 21) ? lane < 48 : i < 16;
     double *lds_P = lds_raw + (USE_MFMA ? MfmaLds::doubles(N) : (ROWPAR ? RowLds::total(N, IPW) : 0));
     double pxy[NOBST][2];
     if (p.obst) {
-        double *Pl = lds_P + (size_t)slot * (N + 1) * NOBST * 2;
+        // (G = 21: the look-ahead is staged in the instance's own H~aug region, which is first written after the positions have been read)
+        double *Pl = (G == 21) ? RL.H : lds_P + (size_t)slot * (N + 1) * NOBST * 2;
         if (2 * NOBST <= G) {
             if (i < 2 * NOBST) {   // lane i walks coordinate i & 1 of obstacle i >> 1 through the horizon (Obstacle.predict_trajectory, visualization.py:62-79)
                 const int j = i >> 1, c = i & 1;
@@ -1466,6 +1570,24 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             w[MfmaLds::at(5, 5)] = 1.0;
         }
     }
+    if constexpr (G == 21) {    // compact blocks (RowLdsC): rows 0, 1 of W~_t, the shared table of the constant rows 2..4, the two zero words of H~aug_t
+        if (has_u) {
+            double *w = RL.W + LT::WS * i;
+            const double Wrow[2][8] = {{1.0, 0.0, S.a02, S.a03, S.a04, 0.0, S.b00, S.b01}, {0.0, 1.0, S.a12, S.a13, S.a14, 0.0, S.b10, S.b11}};
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+#pragma unroll
+                for (int c = 0; c < 8; c++) w[k * 8 + c] = Wrow[k][c];
+        }
+        if (act) { double *hc = RL.H + LT::HS * i; hc[49] = 0.0; hc[50] = 0.0; }      // (after the look-ahead positions staged here have been read)
+        if (lane < 8) {
+            const double c2[8] = {0.0, 0.0, 1.0, 0.0, dt, 0.0, 0.0, h2}, c3[8] = {0.0, 0.0, 0.0, 1.0, 0.0, 0.0, dt, 0.0}, c4[8] = {0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, dt};
+            double v2 = 0.0, v3 = 0.0, v4 = 0.0;
+#pragma unroll
+            for (int c = 0; c < 8; c++) if (lane == c) { v2 = c2[c]; v3 = c3[c]; v4 = c4[c]; }
+            RL.C[3 * lane] = v2; RL.C[3 * lane + 1] = v3; RL.C[3 * lane + 2] = v4;
+        }
+    } else
     if (ROWPAR && has_u) {      // W~_t = [A b B] rows 0..4 (cols: x0..x4, b, ua, ual); column 5 is rewritten every iteration
         double *w = RL.W + RowLds::WS * i;
         const double Wrow[5][8] = {{1.0, 0.0, S.a02, S.a03, S.a04, 0.0, S.b00, S.b01}, {0.0, 1.0, S.a12, S.a13, S.a14, 0.0, S.b10, S.b11},
@@ -1687,7 +1809,15 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                                                {0.0, 0.0, Hq[4], 0.0, 0.0, gxs[2], 0.0, 0.0}, {0.0, 0.0, 0.0, Hq[5], 0.0, gxs[3], 0.0, 0.0},
                                                {0.0, 0.0, 0.0, 0.0, Hq[6], gxs[4], 0.0, 0.0}, {gxs[0], gxs[1], gxs[2], gxs[3], gxs[4], 0.0, lu0, lu1},
                                                {0.0, 0.0, 0.0, 0.0, 0.0, lu0, Hq[0], 0.0}, {0.0, 0.0, 0.0, 0.0, 0.0, lu1, 0.0, Hq[1]}};
-                    double *hc = RL.H + RowLds::HS * i;
+                    double *hc = RL.H + LT::HS * i;
+                    if constexpr (G == 21) {    // rows 0..5, then H66 and H77 (rows 6, 7 are synthesised by the sweep, RowLdsC)
+#pragma unroll
+                        for (int r = 0; r < 6; r++)
+#pragma unroll
+                            for (int c = 0; c < 8; c++) hc[r * 8 + c] = Hrow[r][c];
+                        hc[48] = Hq[0]; hc[51] = Hq[1];
+                        if (has_u) { double *w = RL.W + LT::WS * i; w[5] = bbr[0]; w[13] = bbr[1]; w[16] = bbr[2]; w[17] = bbr[3]; w[18] = bbr[4]; }
+                    } else {
 #pragma unroll
                     for (int r = 0; r < 8; r++)
 #pragma unroll
@@ -1696,27 +1826,29 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #pragma unroll
                         for (int k = 0; k < 5; k++) RL.W[RowLds::WS * i + k * 8 + 5] = bbr[k];
                     }
+                    }
                 }
                 __syncthreads();
                 MPC_TICK(9);
 #ifdef MPC_FACTOR_PLAIN
-                rowpar_factor(lane, N, RL, i < 16);
+                rowpar_factor(lane, N, RS, sweep_worker);
 #else
-                rowpar_factor_fast(lane, N, RL, i < 16);
+                if constexpr (G == 21) rowpar_factor(lane, N, RS, sweep_worker);      // (the one-block asm variant carries the dense layout's offsets)
+                else rowpar_factor_fast(lane, N, RS, sweep_worker);
 #endif
                 __syncthreads();
                 F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;
 #pragma unroll
                 for (int c = 0; c < 5; c++) { F.K0[c] = 0.0; F.K1[c] = 0.0; }
                 if (has_u) {
-                    const double *ko = RL.H + RowLds::HS * i;
+                    const double *ko = RL.H + LT::HS * i;
 #pragma unroll
                     for (int c = 0; c < 5; c++) { F.K0[c] = ko[c]; F.K1[c] = ko[8 + c]; }
                     F.k0 = ko[5]; F.k1 = ko[13]; F.i00 = ko[6]; F.l = ko[7]; F.i11 = ko[14];
                 }
                 // (no barrier: every lane overwrites only the block it has just read, and a wavefront's LDS operations complete in order)
                 if (has_u) {    // closed-loop matrix Acl = A + B K of this stage, row-major, for the row-parallel vector recursions
-                    double *acl = RL.H + RowLds::HS * i + RowVec::ACL;
+                    double *acl = RL.H + LT::HS * i + RowVec::ACL;
                     const double Ar[2][5] = {{1.0, 0.0, S.a02, S.a03, S.a04}, {0.0, 1.0, S.a12, S.a13, S.a14}};
                     const double Br[2][2] = {{S.b00, S.b01}, {S.b10, S.b11}};
 #pragma unroll
@@ -1734,7 +1866,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         MPC_TICK(2);
         if (ROWPAR) {
             if (has_u) {        // c_t = r_b + B k
-                double *cc = RL.H + RowLds::HS * i + RowVec::ACL + 5;      // c[r] closes row r
+                double *cc = RL.H + LT::HS * i + RowVec::ACL + 5;      // c[r] closes row r
                 cc[0 * RowVec::RS] = bbr[0] + S.b00 * F.k0 + S.b01 * F.k1; cc[1 * RowVec::RS] = bbr[1] + S.b10 * F.k0 + S.b11 * F.k1;
                 cc[2 * RowVec::RS] = bbr[2] + h2 * F.k1; cc[3 * RowVec::RS] = bbr[3] + dt * F.k0; cc[4 * RowVec::RS] = bbr[4] + dt * F.k1;
             }
@@ -1743,10 +1875,10 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = x_init[c];
             }
             __syncthreads();
-            rowpar_vector_fast<true>(lane, N, RL, i < 16);
+            rowpar_vector_fast<true>(lane, N, RS, sweep_worker);
             __syncthreads();
             if (act) {
-                const double *xx = RL.H + RowLds::HS * i + RowVec::X;
+                const double *xx = RL.H + LT::HS * i + RowVec::X;
                 double u0 = F.k0, u1 = F.k1;
 #pragma unroll
                 for (int c = 0; c < 5; c++) { za[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }
@@ -1856,15 +1988,15 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             MPC_TICK(5);
             if (ROWPAR) {
                 if (act) {      // c~_t = gc_x + K' gc_u  (K = 0 in the terminal lane)
-                    double *cc = RL.H + RowLds::HS * i + RowVec::CT;
+                    double *cc = RL.H + LT::HS * i + RowVec::CT;
 #pragma unroll
                     for (int c = 0; c < 5; c++) cc[c] = gc[2 + c] + F.K0[c] * gc[0] + F.K1[c] * gc[1];
                 }
                 __syncthreads();
-                rowpar_vector_fast<false>(lane, N, RL, i < 16);
+                rowpar_vector_fast<false>(lane, N, RS, sweep_worker);
                 __syncthreads();
                 if (has_u) {    // feed-forward of the corrector right-hand side: k = -Muu^-1 (gc_u + B' p_{t+1})
-                    const double *pp = RL.H + RowLds::HS * (i + 1) + RowVec::P;
+                    const double *pp = RL.H + LT::HS * (i + 1) + RowVec::P;
                     const double pv[5] = {pp[0], pp[1], pp[2], pp[3], pp[4]};
                     const double m0 = gc[0] + S.dua(pv), m1 = gc[1] + S.dual(pv);
                     F.k1 = fma(F.l, m0, -m1) * F.i11;
@@ -1876,7 +2008,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         MPC_TICK(6);
         if (ROWPAR) {
             if (has_u) {        // homogeneous dynamics: c_t = B k
-                double *cc = RL.H + RowLds::HS * i + RowVec::ACL + 5;
+                double *cc = RL.H + LT::HS * i + RowVec::ACL + 5;
                 cc[0 * RowVec::RS] = S.b00 * F.k0 + S.b01 * F.k1; cc[1 * RowVec::RS] = S.b10 * F.k0 + S.b11 * F.k1;
                 cc[2 * RowVec::RS] = h2 * F.k1; cc[3 * RowVec::RS] = dt * F.k0; cc[4 * RowVec::RS] = dt * F.k1;
             }
@@ -1885,10 +2017,10 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = 0.0;
             }
             __syncthreads();
-            rowpar_vector_fast<true>(lane, N, RL, i < 16);
+            rowpar_vector_fast<true>(lane, N, RS, sweep_worker);
             __syncthreads();
             if (act) {
-                const double *xx = RL.H + RowLds::HS * i + RowVec::X;
+                const double *xx = RL.H + LT::HS * i + RowVec::X;
                 double u0 = F.k0, u1 = F.k1;
 #pragma unroll
                 for (int c = 0; c < 5; c++) { dz[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }

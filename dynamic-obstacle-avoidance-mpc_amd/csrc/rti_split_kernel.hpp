@@ -22,12 +22,21 @@
 
 namespace mpc {
 
-template <int LPS, int NOBST>
+// W2 = false: dense stage blocks (RowLds) plus a result region of their own, 31 KB of LDS per wavefront at N = 20 -- the small-batch
+//   variant, whose wavefront is alone on its SIMD anyway.
+// W2 = true: TWO WAVEFRONTS PER SIMD for batches that are many rounds of wavefronts deep: compact stage blocks (RowLdsC), results
+//   overlaying the consumed H~aug blocks (so every operand word is restaged per iteration) and the look-ahead staged in the same region:
+//   14.7 KB per wavefront at N = 20, eight wavefronts per CU; the register allocator is held to 256 registers per lane.
+template <int LPS, int NOBST, bool W2 = false>
 struct SplitLds {
+    using LT = typename std::conditional<W2, RowLdsC, RowLds>::type;
     static constexpr int NBL = 6 / LPS;                       // box variables per lane
     static constexpr int NSL = (NOBST + LPS - 1) / LPS;       // obstacle row pairs per lane
-    static __host__ __device__ constexpr int results(int N) { return (N + 1) * RowLds::HS; }     // result blocks of the sweeps, apart from the H~aug blocks
-    static __host__ __device__ constexpr int total(int N, bool lookahead) { return RowLds::total(N, 1) + results(N) + (lookahead ? (N + 1) * NOBST * 2 : 0); }
+    static __host__ __device__ constexpr int results(int N) { return W2 ? 0 : (N + 1) * RowLds::HS; }     // result blocks of the sweeps, apart from the H~aug blocks
+    static __host__ __device__ constexpr int total(int N, bool lookahead)
+    {
+        return LT::total(N, 1) + results(N) + ((lookahead && !W2) ? (N + 1) * NOBST * 2 : 0);
+    }
 };
 
 template <int K>
@@ -37,11 +46,19 @@ __device__ __forceinline__ double nth_of_six(double a0, double a1, double a2, do
     else if constexpr (K == 3) return a3; else if constexpr (K == 4) return a4; else return a5;
 }
 
-template <int NOBST, int LPS>
-__global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
+// Diagnostic build only (-DMPC_FORCE_WAVES2, scripts/waves2_experiment.py): the register allocator is told to fit TWO wavefronts per SIMD
+// (256 registers per lane instead of 512).  What that costs is recorded in profiles/r02_waves2_experiment.json; the product is built without it.
+#ifdef MPC_FORCE_WAVES2
+#define MPC_SPLIT_BOUNDS(W2) __launch_bounds__(64, 2)
+#else
+#define MPC_SPLIT_BOUNDS(W2) __launch_bounds__(64, (W2) ? 2 : 1)
+#endif
+template <int NOBST, int LPS, bool W2 = false>
+__global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
 {
     static_assert(LPS == 2 || LPS == 3, "two or three lanes per horizon stage");
-    using SL = SplitLds<LPS, NOBST>;
+    using SL = SplitLds<LPS, NOBST, W2>;
+    using LT = typename SL::LT;
     constexpr int NBL = SL::NBL, NSL = SL::NSL;
     constexpr int kKK = 45;                   // free words 45, 46 of a stage block (RowVec uses 0..44, dead-store words start at RowLds::TAIL)
     const int lane = threadIdx.x;
@@ -103,8 +120,12 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
         for (int c = 0; c < 5; c++) xnext[c] = Xg[(i + 1) * 5 + c];
     }
     extern __shared__ double lds_raw[];
-    const RowLds RL(lds_raw + RowLds::pad_front(N), N, lds_raw + RowLds::total(N, 1));
-    double *lds_P = lds_raw + RowLds::total(N, 1) + SL::results(N);
+    const LT RL = [&]() {
+        if constexpr (W2) return RowLdsC(lds_raw + RowLdsC::CT + RowLdsC::pad_front(N), N, lds_raw);
+        else return RowLds(lds_raw + RowLds::pad_front(N), N, lds_raw + RowLds::total(N, 1));
+    }();
+    // look-ahead staging: a region of its own, or (W2) the H~aug region, which is first written after the positions have been read
+    double *lds_P = W2 ? RL.H : lds_raw + LT::total(N, 1) + SL::results(N);
     // what part q of this lane's stage holds in the variable v: from_right shifts the whole wavefront by one lane, so the owner
     // (part 0) sees its neighbours' values; only the owner's result is meaningful
     auto of_part = [&](double v, int q) { return q == 0 ? v : (q == 1 ? from_right(v) : from_right(from_right(v))); };
@@ -173,19 +194,39 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
 #pragma unroll
         for (int c = 0; c < 5; c++) { d0[c] = x0v[c] - xi[c]; lin0 = fmax(lin0, fabs(d0[c])); }
     }
+    if constexpr (W2) {
+        // (the look-ahead positions staged in this region have been read above: LDS operations of a wavefront complete in order)
+        if (own && act) { double *hc = RL.H + LT::HS * i; hc[49] = 0.0; hc[50] = 0.0; }      // rows 6, 7 of H~aug read these as their zeros; nothing else writes them
+        if (lane < 8) {         // constant rows 2..4 of W~ for the columns other than the affine one: [3 j + m] = W~[2 + m][j]
+            const double c2[8] = {0.0, 0.0, 1.0, 0.0, dt, 0.0, 0.0, h2}, c3[8] = {0.0, 0.0, 0.0, 1.0, 0.0, 0.0, dt, 0.0}, c4[8] = {0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, dt};
+            double v2 = 0.0, v3 = 0.0, v4 = 0.0;
+#pragma unroll
+            for (int c = 0; c < 8; c++) if (lane == c) { v2 = c2[c]; v3 = c3[c]; v4 = c4[c]; }
+            RL.C[3 * lane] = v2; RL.C[3 * lane + 1] = v3; RL.C[3 * lane + 2] = v4;
+        }
+        if (own && has_u) {     // rows 0, 1 of W~_t = [A b B]; b_t (words 5, 13, 16..18) is rewritten every iteration
+            double *w = RL.W + LT::WS * i;
+            const double Wrow[2][8] = {{1.0, 0.0, S.a02, S.a03, S.a04, 0.0, S.b00, S.b01}, {0.0, 1.0, S.a12, S.a13, S.a14, 0.0, S.b10, S.b11}};
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+#pragma unroll
+                for (int c = 0; c < 8; c++) w[k * 8 + c] = Wrow[k][c];
+        }
+    } else {
     if (own && act) {           // H~aug_t: the structural zeros (and the constant psi diagonal) once; the 22 non-zeros are restaged every iteration
-        double *hc = RL.H + RowLds::HS * i;
+        double *hc = RL.H + LT::HS * i;
 #pragma unroll
         for (int e = 0; e < 64; e++) hc[e] = 0.0;
     }
     if (own && has_u) {         // W~_t = [A b B] rows 0..4 (cols: x0..x4, b, ua, ual); column 5 is rewritten every iteration
-        double *w = RL.W + RowLds::WS * i;
+        double *w = RL.W + LT::WS * i;
         const double Wrow[5][8] = {{1.0, 0.0, S.a02, S.a03, S.a04, 0.0, S.b00, S.b01}, {0.0, 1.0, S.a12, S.a13, S.a14, 0.0, S.b10, S.b11},
                                    {0.0, 0.0, 1.0, 0.0, dt, 0.0, 0.0, h2}, {0.0, 0.0, 0.0, 1.0, 0.0, 0.0, dt, 0.0}, {0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, dt}};
 #pragma unroll
         for (int k = 0; k < 5; k++)
 #pragma unroll
             for (int c = 0; c < 8; c++) w[k * 8 + c] = Wrow[k][c];
+    }
     }
 
     MPC_TICK(12);
@@ -364,14 +405,30 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
                 const double hxx = Hk[2] + Sxx, hyy = Hk[3] + Syy;
                 const double gxs[5] = {gk[2] + Sgx, gk[3] + Sgy, hd_psi * z[4], gk[4], gk[5]};
                 const double lu0 = gk[0], lu1 = gk[1];
-                double *hc = RL.H + RowLds::HS * i;      // row-major 8 x 8; everything else in the block is zero and stays zero
+                double *hc = RL.H + LT::HS * i;
+                if constexpr (W2) {     // rows 0..5 of the block in full (the results of the last iteration overlay it), then H66, H77
+                    const double Hrow[6][8] = {{hxx, Sxy, 0.0, 0.0, 0.0, gxs[0], 0.0, 0.0}, {Sxy, hyy, 0.0, 0.0, 0.0, gxs[1], 0.0, 0.0},
+                                               {0.0, 0.0, hd_psi, 0.0, 0.0, gxs[2], 0.0, 0.0}, {0.0, 0.0, 0.0, Hk[4], 0.0, gxs[3], 0.0, 0.0},
+                                               {0.0, 0.0, 0.0, 0.0, Hk[5], gxs[4], 0.0, 0.0}, {gxs[0], gxs[1], gxs[2], gxs[3], gxs[4], 0.0, lu0, lu1}};
+#pragma unroll
+                    for (int r = 0; r < 6; r++)
+#pragma unroll
+                        for (int c = 0; c < 8; c++) hc[r * 8 + c] = Hrow[r][c];
+                    hc[48] = Hk[0]; hc[51] = Hk[1];
+                    if (has_u) {
+                        double *w = RL.W + LT::WS * i;
+                        w[5] = bbr[0]; w[13] = bbr[1]; w[16] = bbr[2]; w[17] = bbr[3]; w[18] = bbr[4];
+                    }
+                } else {
+                // row-major 8 x 8; everything else in the block is zero and stays zero
                 hc[0] = hxx; hc[1] = Sxy; hc[8] = Sxy; hc[9] = hyy; hc[18] = hd_psi; hc[27] = Hk[4]; hc[36] = Hk[5]; hc[54] = Hk[0]; hc[63] = Hk[1];
 #pragma unroll
                 for (int c = 0; c < 5; c++) { hc[c * 8 + 5] = gxs[c]; hc[40 + c] = gxs[c]; }
                 hc[46] = lu0; hc[47] = lu1; hc[53] = lu0; hc[61] = lu1;
                 if (has_u) {
 #pragma unroll
-                    for (int k = 0; k < 5; k++) RL.W[RowLds::WS * i + k * 8 + 5] = bbr[k];
+                    for (int k = 0; k < 5; k++) RL.W[LT::WS * i + k * 8 + 5] = bbr[k];
+                }
                 }
             }
         }
@@ -386,7 +443,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
 #pragma unroll
         for (int c = 0; c < 5; c++) { F.K0[c] = 0.0; F.K1[c] = 0.0; }
         if (has_u) {
-            const double *ko = RL.R + RowLds::HS * i;
+            const double *ko = RL.R + LT::HS * i;
 #pragma unroll
             for (int c = 0; c < 5; c++) { F.K0[c] = ko[c]; F.K1[c] = ko[8 + c]; }
             F.k0 = ko[5]; F.k1 = ko[13]; F.i00 = ko[6]; F.l = ko[7]; F.i11 = ko[14];
@@ -394,7 +451,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
         // the parts of a stage must all have read the factors before the owner overwrites the block: LDS operations of one
         // wavefront complete in order, so no barrier is needed
         if (own && has_u) {     // closed-loop matrix Acl = A + B K, row-major, and c_t = r_b + B k, for the row-parallel vector recursions
-            double *acl = RL.R + RowLds::HS * i + RowVec::ACL;
+            double *acl = RL.R + LT::HS * i + RowVec::ACL;
             const double Ar[2][5] = {{1.0, 0.0, S.a02, S.a03, S.a04}, {0.0, 1.0, S.a12, S.a13, S.a14}};
             const double Br[2][2] = {{S.b00, S.b01}, {S.b10, S.b11}};
 #pragma unroll
@@ -421,7 +478,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
         __syncthreads();
         double za[7] = {0, 0, 0, 0, 0, 0, 0};
         if (act) {
-            const double *xx = RL.R + RowLds::HS * i + RowVec::X;
+            const double *xx = RL.R + LT::HS * i + RowVec::X;
             double u0 = F.k0, u1 = F.k1;
 #pragma unroll
             for (int c = 0; c < 5; c++) { za[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }
@@ -525,7 +582,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
             }
             gc[2] += Sgx; gc[3] += Sgy;
             if (own && act) {   // c~_t = gc_x + K' gc_u  (K = 0 in the terminal lane)
-                double *cc = RL.R + RowLds::HS * i + RowVec::CT;
+                double *cc = RL.R + LT::HS * i + RowVec::CT;
 #pragma unroll
                 for (int c = 0; c < 5; c++) cc[c] = gc[2 + c] + F.K0[c] * gc[0] + F.K1[c] * gc[1];
             }
@@ -533,7 +590,7 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
             rowpar_vector_fast<false>(lane, N, RL, lane < 16);
             __syncthreads();
             if (has_u) {        // feed-forward of the corrector right-hand side: k = -Muu^-1 (gc_u + B' p_{t+1}); owner lane (it has gc)
-                const double *pp = RL.R + RowLds::HS * (i + 1) + RowVec::P;
+                const double *pp = RL.R + LT::HS * (i + 1) + RowVec::P;
                 const double pv[5] = {pp[0], pp[1], pp[2], pp[3], pp[4]};
                 const double m0 = gc[0] + S.dua(pv), m1 = gc[1] + S.dual(pv);
                 F.k1 = fma(F.l, m0, -m1) * F.i11;
@@ -542,10 +599,10 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
         }
         MPC_TICK(6);
         if (own && has_u) {     // homogeneous dynamics: c_t = B k; k itself for the other parts of the stage
-            double *cc = RL.R + RowLds::HS * i + RowVec::ACL + 5;
+            double *cc = RL.R + LT::HS * i + RowVec::ACL + 5;
             cc[0 * RowVec::RS] = S.b00 * F.k0 + S.b01 * F.k1; cc[1 * RowVec::RS] = S.b10 * F.k0 + S.b11 * F.k1;
             cc[2 * RowVec::RS] = h2 * F.k1; cc[3 * RowVec::RS] = dt * F.k0; cc[4 * RowVec::RS] = dt * F.k1;
-            RL.R[RowLds::HS * i + kKK] = F.k0; RL.R[RowLds::HS * i + kKK + 1] = F.k1;
+            RL.R[LT::HS * i + kKK] = F.k0; RL.R[LT::HS * i + kKK + 1] = F.k1;
         }
         if (lane == 0) {
 #pragma unroll
@@ -556,8 +613,8 @@ __global__ __launch_bounds__(64) void rti_split_kernel(const KParams p)
         __syncthreads();
         double dz[7] = {0, 0, 0, 0, 0, 0, 0};
         if (act) {
-            const double *xx = RL.R + RowLds::HS * i + RowVec::X;
-            double u0 = has_u ? RL.R[RowLds::HS * i + kKK] : 0.0, u1 = has_u ? RL.R[RowLds::HS * i + kKK + 1] : 0.0;
+            const double *xx = RL.R + LT::HS * i + RowVec::X;
+            double u0 = has_u ? RL.R[LT::HS * i + kKK] : 0.0, u1 = has_u ? RL.R[LT::HS * i + kKK + 1] : 0.0;
 #pragma unroll
             for (int c = 0; c < 5; c++) { dz[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }
             dz[0] = u0; dz[1] = u1;

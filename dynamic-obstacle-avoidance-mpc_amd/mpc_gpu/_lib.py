@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(PKG_ROOT, "csrc")
-LIB_PATH = os.path.join(PKG_ROOT, "libmpcgpu.so")
+LIB_PATH = os.environ.get("MPC_GPU_LIB") or os.path.join(PKG_ROOT, "libmpcgpu.so")    # MPC_GPU_LIB: a diagnostic build (scripts/*_experiment.py)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 
 MPC_OK, MPC_ERR_ARG, MPC_ERR_HIP, MPC_ERR_NODEVICE = 0, -1, -2, -3
@@ -71,6 +71,8 @@ SYMBOLS = {
     "mpc_get_lanes_per_instance": (C.c_int, [_vp, C.c_int]),
     "mpc_set_lanes_per_stage": (C.c_int, [_vp, C.c_int]),
     "mpc_get_lanes_per_stage": (C.c_int, [_vp, C.c_int]),
+    "mpc_set_waves_per_simd": (C.c_int, [_vp, C.c_int]),
+    "mpc_get_waves_per_simd": (C.c_int, [_vp, C.c_int]),
     "mpc_set_matrix_cores": (C.c_int, [_vp, C.c_int]),
     "mpc_set_row_parallel": (C.c_int, [_vp, C.c_int]),
     "mpc_generate_scenarios_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint, _vp, _vp, _vp]),
@@ -91,6 +93,8 @@ def sources():
 
 def build(force=False, verbose=False):
     """Compile csrc/*.hip for gfx950 into libmpcgpu.so (in-tree).  hipcc cross-compiles without a GPU."""
+    if os.environ.get("MPC_GPU_LIB"):
+        return LIB_PATH                  # a diagnostic build supplied by the caller is used as it is
     srcs = sources()
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
         return LIB_PATH

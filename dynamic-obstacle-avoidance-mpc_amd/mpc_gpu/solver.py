@@ -28,8 +28,9 @@ def _ptr(a):
 
 
 class BatchedMpc:
-    # lanes per horizon stage applied to every new handle (0 = automatic, see set_lanes_per_stage); a test / tuning hook
+    # lanes per horizon stage / wavefronts per SIMD applied to every new handle (0 = automatic); test / tuning hooks
     default_lanes_per_stage = 0
+    default_waves_per_simd = 0
 
     def __init__(self, N=20, n_obst=3, Tf=2.0, max_batch=1, device=0, **cfg_overrides):
         self.cfg = _lib.default_config(N, n_obst, Tf, **cfg_overrides)
@@ -41,6 +42,8 @@ class BatchedMpc:
         _lib.check(_lib.lib().mpc_create(C.byref(self.cfg), self.device, self.max_batch, C.byref(self._h)))
         if BatchedMpc.default_lanes_per_stage:
             _lib.check(_lib.lib().mpc_set_lanes_per_stage(self._h, int(BatchedMpc.default_lanes_per_stage)))
+        if BatchedMpc.default_waves_per_simd:
+            _lib.check(_lib.lib().mpc_set_waves_per_simd(self._h, int(BatchedMpc.default_waves_per_simd)))
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -222,3 +225,10 @@ class BatchedMpc:
 
     def lanes_per_stage(self, batch):
         return _lib.lib().mpc_get_lanes_per_stage(self._h, batch)
+
+    def set_waves_per_simd(self, waves):
+        """stage-split mapping: 0 automatic, 1 one wavefront per SIMD (512 registers), 2 two (256 registers, compact LDS blocks)"""
+        _lib.check(_lib.lib().mpc_set_waves_per_simd(self._h, int(waves)))
+
+    def waves_per_simd(self, batch):
+        return _lib.lib().mpc_get_waves_per_simd(self._h, batch)

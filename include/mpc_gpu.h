@@ -201,6 +201,13 @@ int mpc_set_row_parallel(mpc_handle *h, int on);
  * Same arithmetic specification either way.  No reference counterpart (tuning / test hook). */
 int mpc_set_lanes_per_stage(mpc_handle *h, int lanes);
 int mpc_get_lanes_per_stage(mpc_handle *h, int batch);
+/* Wavefronts per SIMD of the stage-split mapping.  0 (default): automatic -- one (all 512 registers, dense LDS blocks) for a batch of at
+ * most two instances per SIMD, whose wavefronts are alone on their SIMDs anyway; two (256 registers per lane, compact LDS blocks: 14.7 KB
+ * per wavefront at N = 20, eight wavefronts per CU) for deeper batches, where a second resident wavefront fills the LDS and
+ * dependent-issue stalls of the first.  1 / 2: forced.  The one-lane-per-stage mapping always runs one wavefront per SIMD (449 registers).
+ * Same arithmetic specification either way.  No reference counterpart (tuning / test hook). */
+int mpc_set_waves_per_simd(mpc_handle *h, int waves);
+int mpc_get_waves_per_simd(mpc_handle *h, int batch);
 
 #ifdef __cplusplus
 }

@@ -382,20 +382,56 @@ def test_stage_split_matches_one_lane_per_stage_and_oracle(env, N, no, B):
 
 
 @pytest.mark.gpu
-def test_stage_split_is_the_automatic_choice_for_small_batches_only(env):
+def test_automatic_lane_mapping(env):
+    """the dispatcher's choices (mpc_api.hip::pick_split / pick_waves, measured crossovers): the stage-split mapping wherever the horizon
+    fits it, two wavefronts per SIMD for deep 3-obstacle batches, four instances per wavefront for short horizons at large batches"""
     mpc_gpu, orc = env
-    mpc_gpu.BatchedMpc.default_lanes_per_stage, keep = 0, mpc_gpu.BatchedMpc.default_lanes_per_stage
+    keep = (mpc_gpu.BatchedMpc.default_lanes_per_stage, mpc_gpu.BatchedMpc.default_waves_per_simd)
+    mpc_gpu.BatchedMpc.default_lanes_per_stage = mpc_gpu.BatchedMpc.default_waves_per_simd = 0
     try:
+        from mpc_gpu import _lib
         with mpc_gpu.BatchedMpc(20, 3, 2.0, max_batch=70000) as s:
             assert s.lanes_per_stage(1) == 3 and s.lanes_per_stage(1024) == 3 and s.lanes_per_instance(1024) == 64
-            assert s.lanes_per_stage(8192) == 3 and s.lanes_per_stage(8193) == 1 and s.lanes_per_instance(65536) == 32
+            assert s.lanes_per_stage(65536) == 3 and s.waves_per_simd(4096) == 1 and s.waves_per_simd(4097) == 2 and s.waves_per_simd(65536) == 2
+            s.set_waves_per_simd(1)
+            assert s.waves_per_simd(65536) == 1
+            assert _lib.lib().mpc_set_waves_per_simd(s._h, 3) == _lib.MPC_ERR_ARG
             s.set_lanes_per_instance(64)
-            assert s.lanes_per_stage(8) == 1
+            assert s.lanes_per_stage(8) == 1 and s.waves_per_simd(65536) == 1
+        with mpc_gpu.BatchedMpc(20, 10, 2.0, max_batch=70000) as s:
+            assert s.lanes_per_stage(65536) == 3 and s.waves_per_simd(65536) == 1           # 10 obstacles: never the 256-register build
+        with mpc_gpu.BatchedMpc(10, 3, 1.0, max_batch=70000) as s:
+            assert s.lanes_per_stage(8192) == 3 and s.lanes_per_stage(8193) == 1 and s.lanes_per_instance(65536) == 16
         with mpc_gpu.BatchedMpc(31, 3, 3.1, max_batch=8) as s:
             assert s.lanes_per_stage(8) == 2
         with mpc_gpu.BatchedMpc(32, 3, 3.2, max_batch=8) as s:
             assert s.lanes_per_stage(8) == 1
-            from mpc_gpu import _lib
             assert _lib.lib().mpc_set_lanes_per_stage(s._h, 2) == _lib.MPC_ERR_ARG
     finally:
-        mpc_gpu.BatchedMpc.default_lanes_per_stage = keep
+        mpc_gpu.BatchedMpc.default_lanes_per_stage, mpc_gpu.BatchedMpc.default_waves_per_simd = keep
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,no,B", [(20, 3, 700), (20, 5, 300), (31, 3, 200), (10, 10, 150), (2, 3, 33)])
+def test_two_wavefronts_per_simd_variant_is_bitwise_the_one_wavefront_variant(env, N, no, B):
+    """rti_split_kernel<.., W2 = true> (256 registers, compact LDS blocks, results overlaying the operand blocks, look-ahead staged in the
+    operand region) computes exactly what the 512-register / dense-LDS variant computes: same instructions on the same operands in the
+    same order, so every output agrees bit for bit -- over three closed-loop steps, explicit P and on-device look-ahead"""
+    mpc_gpu, orc = env
+    x0, goal, obst = random_batch(B, no, seed=900 + N + no)
+    cfg = orc.config(N, no, 0.1 * N)
+    P = oracle_P(orc, cfg, obst)
+    res = {}
+    for w in (1, 2):
+        with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
+            s.set_lanes_per_stage(3 if N <= 20 else 2); s.set_waves_per_simd(w)
+            assert s.waves_per_simd(B) == w
+            s.reset_guess(x0); outs = []
+            for k in range(3):
+                g = s.solve(x0, obst if k != 1 else P, goal); X, U = s.get_traj(B); s.shift(B)
+                outs.append((g, X, U))
+            res[w] = outs
+    for (ga, Xa, Ua), (gb, Xb, Ub) in zip(res[1], res[2]):
+        assert np.array_equal(Xa, Xb) and np.array_equal(Ua, Ub)
+        for key in ("u0", "cost", "status", "iters"):
+            assert np.array_equal(ga[key], gb[key]), key
