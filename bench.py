@@ -335,8 +335,7 @@ def roofline(loop, N, no, r):
     """FP64 vector ALU is the roof that binds this path (~175 flop per algorithmic byte); HBM is the secondary figure.
     Everything from THIS run: kernel time from HIP events on the launch stream, flops from the measured mean iteration count."""
     batch = loop.B
-    lanes, lps = loop.m.lanes_per_instance(batch), loop.m.lanes_per_stage(batch)
-    kname = f"rti_solve_kernel<{no}, {lanes}, 2>" if lps == 1 else f"rti_split_kernel<{no}, {lps}>"
+    kname = loop.m.kernel_name(batch)
     avg_s = r["kern_ms"] / max(1, r["launches"]) * 1e-3
     flops = algorithmic_flops_per_solve(N, no, r["mean_iters"]) * batch
     abytes = algorithmic_bytes_per_solve(N, no) * batch
@@ -352,8 +351,8 @@ def roofline(loop, N, no, r):
             "flop_model": "SURVEY.md 8(d): N*200 + K*[N*(7/3 nx^3 + 4 nx^2 nu + 2 nx nu^2 + nu^3/3) + N*(2 (nx+nu)^2 + 6 n_ineq)], K = mean_ipm_iters of this run",
             "hbm": {"achieved": abytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / avg_s / 1e9 / HBM_PEAK_GBS,
                     "algorithmic_bytes_per_launch": abytes},
-            "note": "one wavefront per SIMD (>= 354 registers per lane); the stage recursions keep 8-16 of 64 lanes busy, so the flop "
-                    "fraction is small by construction; what limits a wavefront is the issue rate of its own instruction stream (DESIGN.md section 5)"}
+            "note": "the stage recursions keep 8-24 of 64 lanes busy and a wavefront is limited by the issue rate of its own dependent "
+                    "instruction stream (one or two wavefronts per SIMD), so the flop fraction is small by construction (DESIGN.md section 5)"}
 
 
 def c1_latency(mpc_gpu, N, no):
@@ -493,6 +492,7 @@ def main():
            "ms_per_control_step": r["elapsed"] / (args.steps * EPISODE) * 1e3,
            "mean_ipm_iters": r["mean_iters"], "qp_failure_frac": r["fail"], "qp_iter_cap_frac": r["cap"],
            "lanes_per_instance": loop.m.lanes_per_instance(loop.B), "lanes_per_stage": loop.m.lanes_per_stage(loop.B),
+           "waves_per_simd": loop.m.waves_per_simd(loop.B),
            "roofline": roofline(loop, N, no, r)}
 
     if rank == 0 and world == 1 and not args.no_extra and args.workload == "c2":

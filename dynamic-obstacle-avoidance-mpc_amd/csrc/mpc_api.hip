@@ -108,6 +108,8 @@ int pick_lanes(mpc_handle *h, int batch)
     // batches of up to one instance per SIMD (1024 on MI355X), beyond that packing instances per wavefront wins
     if (batch <= 1024 && h->use_mfma) G = 64;
     if (h->lanes_override == 21) return 21;       // three instances per wavefront (N <= 20, row-parallel sweeps)
+    // automatic: 17 <= N + 2 <= 22 (two instances per wavefront otherwise) with 3 obstacles, batches of more than 12 instances per SIMD
+    if (!h->lanes_override && !h->use_mfma && h->row_parallel && h->cfg.n_obst == 3 && need > 16 && h->cfg.N <= 20 && batch > 12 * h->simd_count) return 21;
     if (h->lanes_override >= G || (h->lanes_override && h->lanes_override >= need)) G = h->lanes_override;
     return G;
 }
@@ -116,6 +118,8 @@ int pick_lanes(mpc_handle *h, int batch)
 // M solves/s at a batch of 65536, split 1 wavefront/SIMD | split 2 wavefronts/SIMD | one lane per stage):
 //     N = 20,  3 obstacles: 10.5 | 13.3 | 12.6        N = 20,  5 obstacles: 8.8 | 9.0 | 8.7        N = 20, 10 obstacles: 6.2 | 4.4 | 3.0
 //     N = 31,  3 obstacles:  5.0 |  6.2 |  5.7        N = 10,  3 obstacles: 16.0 | 19.9 | 26.4      N = 10,  5 obstacles: 13.4 | 12.4 | 14.0
+//   and, N = 20 with 3 obstacles, THREE instances per wavefront on compact LDS blocks (one lane per stage, G = 21): 14.8 (10.9 at 16384 against
+//   10.6 for the two-wavefront split variant, 8.0 against 8.5 at 8192)
 // * the stage-split mapping (rows of a stage over 3 lanes for N <= 20, 2 for N <= 31, one instance per wavefront; rti_split_kernel.hpp)
 //   wins wherever the horizon fits it, at every batch size, with one exception: 3 obstacles and N + 2 <= 16, where the one-lane mapping packs
 //   FOUR instances into a wavefront and overtakes beyond ~8 instances per SIMD;
@@ -129,7 +133,8 @@ int pick_split(mpc_handle *h, int batch)
     const int N = h->cfg.N;
     const int fit = N <= 20 ? 3 : (N <= 31 ? 2 : 1);
     if (h->split_override) return h->split_override <= fit ? h->split_override : fit;
-    if (h->cfg.n_obst == 3 && N + 2 <= 16 && batch > 8 * h->simd_count) return 1;
+    if (h->cfg.n_obst == 3 && N + 2 <= 16 && batch > 8 * h->simd_count) return 1;      // four instances per wavefront
+    if (h->cfg.n_obst == 3 && N <= 20 && batch > 12 * h->simd_count) return 1;          // three instances per wavefront (G = 21)
     return fit;
 }
 
@@ -178,23 +183,61 @@ int launch_one_lane(mpc_handle *h, const mpc::KParams &p, hipStream_t s, dim3 gr
     return MPC_OK;
 }
 
-template <int NO>
-int launch_one_lane_g(mpc_handle *h, const mpc::KParams &p, hipStream_t s, dim3 grid, size_t lds, int G, bool use_mfma, bool rowpar)
+// The lane mapping, kernel variant and dynamic-LDS size a batch runs with (one place: launches and mpc_get_kernel_name read it)
+struct SolvePlan {
+    int lps, waves;        // stage-split mapping: lanes per stage (> 1) and wavefronts per SIMD
+    int G, fact;           // one lane per stage: lanes per instance, sweep variant (0 systolic, 1 matrix cores, 2 row-parallel dense, 3 compact)
+    size_t lds;
+};
+
+SolvePlan plan_solve(mpc_handle *h, int batch, bool lookahead)
 {
-    if (G == 21) return launch_one_lane<NO, 21, 2>(h, p, s, grid, lds);
-    if (G == 16) return rowpar ? launch_one_lane<NO, 16, 2>(h, p, s, grid, lds) : launch_one_lane<NO, 16, 0>(h, p, s, grid, lds);
-    if (G == 32) return rowpar ? launch_one_lane<NO, 32, 2>(h, p, s, grid, lds) : launch_one_lane<NO, 32, 0>(h, p, s, grid, lds);
-    if (use_mfma) return launch_one_lane<NO, 64, 1>(h, p, s, grid, lds);
-    return rowpar ? launch_one_lane<NO, 64, 2>(h, p, s, grid, lds) : launch_one_lane<NO, 64, 0>(h, p, s, grid, lds);
+    SolvePlan q = {1, 1, 64, 2, 0};
+    const int N = h->cfg.N, no = h->cfg.n_obst;
+    q.lps = pick_split(h, batch);
+    if (q.lps > 1) {
+        q.waves = pick_waves(h, batch);
+        return q;          // (the LDS size of a split launch is a compile-time function of the kernel's template arguments: launch_split_w)
+    }
+    q.G = pick_lanes(h, batch);
+    const bool use_mfma = (q.G == 64) && h->use_mfma;
+    const bool rowpar = !use_mfma && h->row_parallel;
+    const int ipw = 64 / q.G;
+    const size_t dense = ((lookahead ? (size_t)ipw * (N + 1) * no * 2 : 0) + (use_mfma ? (size_t)mpc::MfmaLds::doubles(N) : 0) +
+                          (rowpar ? (size_t)mpc::RowLds::total(N, ipw) : 0)) * sizeof(double);
+    // Compact stage blocks (look-ahead staged inside them): always with three instances per wavefront (13.5 KB per instance at N = 20:
+    // four wavefronts of three per CU), and for long horizons on 64 lanes whenever the dense blocks would leave a CU fewer than the four
+    // wavefronts its SIMDs can hold (N = 50, 10 obstacles: 51 KB -> 3 per CU dense, 32 KB -> 4 compact)
+    const bool compact = rowpar && (q.G == 21 || (q.G == 64 && dense > 40960));
+    q.fact = use_mfma ? 1 : (rowpar ? (compact ? 3 : 2) : 0);
+    q.lds = compact ? (size_t)mpc::RowLdsC::total(N, ipw) * sizeof(double) : dense;
+    return q;
+}
+
+template <int NO>
+int launch_one_lane_g(mpc_handle *h, const mpc::KParams &p, hipStream_t s, dim3 grid, const SolvePlan &q)
+{
+    switch (q.G * 10 + q.fact) {
+    case 213: return launch_one_lane<NO, 21, 3>(h, p, s, grid, q.lds);
+    case 162: return launch_one_lane<NO, 16, 2>(h, p, s, grid, q.lds);
+    case 160: return launch_one_lane<NO, 16, 0>(h, p, s, grid, q.lds);
+    case 322: return launch_one_lane<NO, 32, 2>(h, p, s, grid, q.lds);
+    case 320: return launch_one_lane<NO, 32, 0>(h, p, s, grid, q.lds);
+    case 641: return launch_one_lane<NO, 64, 1>(h, p, s, grid, q.lds);
+    case 642: return launch_one_lane<NO, 64, 2>(h, p, s, grid, q.lds);
+    case 643: return launch_one_lane<NO, 64, 3>(h, p, s, grid, q.lds);
+    case 640: return launch_one_lane<NO, 64, 0>(h, p, s, grid, q.lds);
+    }
+    return fail(MPC_ERR_ARG, "no kernel variant for this lane mapping (three instances per wavefront need the row-parallel sweeps)");
 }
 
 // picks the lane mapping and launches; no event handling here
 int dispatch_solve(mpc_handle *h, const mpc::KParams &p, hipStream_t s)
 {
-    const int lps = pick_split(h, p.batch);
+    const SolvePlan q = plan_solve(h, p.batch, p.obst != nullptr);
     int rc = MPC_OK;
-    if (lps > 1) {
-        switch (h->cfg.n_obst * 10 + lps) {
+    if (q.lps > 1) {
+        switch (h->cfg.n_obst * 10 + q.lps) {
         case 32: rc = launch_split<3, 2>(h, p, s); break;
         case 33: rc = launch_split<3, 3>(h, p, s); break;
         case 52: rc = launch_split<5, 2>(h, p, s); break;
@@ -204,19 +247,11 @@ int dispatch_solve(mpc_handle *h, const mpc::KParams &p, hipStream_t s)
         default: return fail(MPC_ERR_ARG, "n_obst must be 3, 5 or 10");
         }
     } else {
-        const int G = pick_lanes(h, p.batch);
-        const dim3 grid((p.batch + 64 / G - 1) / (64 / G));
-        const bool use_mfma = (G == 64) && h->use_mfma;
-        const bool rowpar = !use_mfma && h->row_parallel;
-        if (G == 21 && !rowpar) return fail(MPC_ERR_ARG, "three instances per wavefront need the row-parallel sweeps");
-        // G = 21: compact stage blocks, look-ahead staged inside them (13.5 KB per instance at N = 20: four wavefronts of three per CU)
-        const size_t lds = G == 21 ? (size_t)mpc::RowLdsC::total(p.N, 3) * sizeof(double) :
-                           ((p.obst ? (size_t)(64 / G) * (p.N + 1) * h->cfg.n_obst * 2 : 0) + (use_mfma ? (size_t)mpc::MfmaLds::doubles(p.N) : 0) +
-                            (rowpar ? (size_t)mpc::RowLds::total(p.N, 64 / G) : 0)) * sizeof(double);
+        const dim3 grid((p.batch + 64 / q.G - 1) / (64 / q.G));
         switch (h->cfg.n_obst) {
-        case 3: rc = launch_one_lane_g<3>(h, p, s, grid, lds, G, use_mfma, rowpar); break;
-        case 5: rc = launch_one_lane_g<5>(h, p, s, grid, lds, G, use_mfma, rowpar); break;
-        case 10: rc = launch_one_lane_g<10>(h, p, s, grid, lds, G, use_mfma, rowpar); break;
+        case 3: rc = launch_one_lane_g<3>(h, p, s, grid, q); break;
+        case 5: rc = launch_one_lane_g<5>(h, p, s, grid, q); break;
+        case 10: rc = launch_one_lane_g<10>(h, p, s, grid, q); break;
         default: return fail(MPC_ERR_ARG, "n_obst must be 3, 5 or 10");
         }
     }
@@ -721,6 +756,15 @@ int mpc_get_lanes_per_stage(mpc_handle *h, int batch)
 {
     if (!h) return fail(MPC_ERR_ARG, "null handle");
     return pick_split(h, batch);
+}
+
+int mpc_get_kernel_name(mpc_handle *h, int batch, int lookahead, char *buf, int len)
+{
+    if (!h || !buf || len < 1) return fail(MPC_ERR_ARG, "null argument");
+    const SolvePlan q = plan_solve(h, batch, lookahead != 0);
+    if (q.lps > 1) snprintf(buf, (size_t)len, "rti_split_kernel<%d, %d, %s>", h->cfg.n_obst, q.lps, q.waves == 2 ? "true" : "false");
+    else snprintf(buf, (size_t)len, "rti_solve_kernel<%d, %d, %d>", h->cfg.n_obst, q.G, q.fact);
+    return MPC_OK;
 }
 
 int mpc_set_waves_per_simd(mpc_handle *h, int waves)

@@ -1435,15 +1435,17 @@ __device__ __forceinline__ void systolic_rollout(int stage, int N, const StageLi
 // ------------------------------------------------------------------------------------------------------------------
 // The solve kernel.  grid = ceil(batch / (64 / G)) workgroups of one wavefront; dynamic LDS: row-parallel operands + look-ahead staging.
 // ------------------------------------------------------------------------------------------------------------------
-// FACT selects the Riccati factorisation sweep: 0 one-lane systolic, 1 matrix cores (G = 64 only), 2 row-parallel DPP.
+// FACT selects the Riccati factorisation sweep: 0 one-lane systolic, 1 matrix cores (G = 64 only), 2 row-parallel DPP on dense LDS stage
+// blocks (RowLds), 3 row-parallel DPP on compact stage blocks (RowLdsC: what three instances per wavefront, G = 21, and long horizons need
+// to keep four wavefronts on a CU).
 template <int NOBST, int G, int FACT>
 __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 {
-    constexpr bool USE_MFMA = FACT == 1, ROWPAR = FACT == 2;
+    constexpr bool USE_MFMA = FACT == 1, ROWPAR = FACT >= 2, COMPACT = FACT == 3;
     static_assert(!USE_MFMA || G == 64, "the matrix-core factorisation maps one instance per wavefront");
-    static_assert(G != 21 || ROWPAR, "three instances per wavefront exist for the row-parallel sweeps only");
+    static_assert(G != 21 || COMPACT, "three instances per wavefront exist for the row-parallel sweeps on compact stage blocks only");
     constexpr int IPW = 64 / G;               // instances per wavefront (G = 21: three, lanes [0,21), [21,42), [42,63); lane 63 idles)
-    using LT = typename std::conditional<G == 21, RowLdsC, RowLds>::type;     // LDS layout of the stage blocks
+    using LT = typename std::conditional<COMPACT, RowLdsC, RowLds>::type;     // LDS layout of the stage blocks
     const int lane = threadIdx.x;
     const int slot = (G == 21) ? seg21_slot(lane) : lane / G;
     const int inst_raw = blockIdx.x * IPW + slot;
@@ -1470,7 +1472,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     // RL: the stage blocks of THIS lane's instance (row phases); RS: those of the instance whose sweeps this lane works on -- the same,
     // except with three instances per wavefront, where the sweep of instance w runs in DPP row w (lanes 16 w .. 16 w + 15)
     auto blocks_of = [&](int which) {
-        if constexpr (G == 21) return RowLdsC(lds_raw + RowLdsC::CT + RowLdsC::pad_front(N) + which * RowLdsC::per_instance(N), N, lds_raw);
+        if constexpr (COMPACT) return RowLdsC(lds_raw + RowLdsC::CT + RowLdsC::pad_front(N) + which * RowLdsC::per_instance(N), N, lds_raw);
         else return RowLds(lds_raw + (ROWPAR ? RowLds::pad_front(N) + which * RowLds::per_instance(N) : 0), N);
     };
     const LT RL = blocks_of(slot);                                  // used only when ROWPAR
@@ -1479,8 +1481,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     double *lds_P = lds_raw + (USE_MFMA ? MfmaLds::doubles(N) : (ROWPAR ? RowLds::total(N, IPW) : 0));
     double pxy[NOBST][2];
     if (p.obst) {
-        // (G = 21: the look-ahead is staged in the instance's own H~aug region, which is first written after the positions have been read)
-        double *Pl = (G == 21) ? RL.H : lds_P + (size_t)slot * (N + 1) * NOBST * 2;
+        // (compact blocks: the look-ahead is staged in the instance's own H~aug region, which is first written after the positions have been read)
+        double *Pl = COMPACT ? RL.H : lds_P + (size_t)slot * (N + 1) * NOBST * 2;
         if (2 * NOBST <= G) {
             if (i < 2 * NOBST) {   // lane i walks coordinate i & 1 of obstacle i >> 1 through the horizon (Obstacle.predict_trajectory, visualization.py:62-79)
                 const int j = i >> 1, c = i & 1;
@@ -1570,7 +1572,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             w[MfmaLds::at(5, 5)] = 1.0;
         }
     }
-    if constexpr (G == 21) {    // compact blocks (RowLdsC): rows 0, 1 of W~_t, the shared table of the constant rows 2..4, the two zero words of H~aug_t
+    if constexpr (COMPACT) {    // compact blocks (RowLdsC): rows 0, 1 of W~_t, the shared table of the constant rows 2..4, the two zero words of H~aug_t
         if (has_u) {
             double *w = RL.W + LT::WS * i;
             const double Wrow[2][8] = {{1.0, 0.0, S.a02, S.a03, S.a04, 0.0, S.b00, S.b01}, {0.0, 1.0, S.a12, S.a13, S.a14, 0.0, S.b10, S.b11}};
@@ -1810,7 +1812,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                                                {0.0, 0.0, 0.0, 0.0, Hq[6], gxs[4], 0.0, 0.0}, {gxs[0], gxs[1], gxs[2], gxs[3], gxs[4], 0.0, lu0, lu1},
                                                {0.0, 0.0, 0.0, 0.0, 0.0, lu0, Hq[0], 0.0}, {0.0, 0.0, 0.0, 0.0, 0.0, lu1, 0.0, Hq[1]}};
                     double *hc = RL.H + LT::HS * i;
-                    if constexpr (G == 21) {    // rows 0..5, then H66 and H77 (rows 6, 7 are synthesised by the sweep, RowLdsC)
+                    if constexpr (COMPACT) {    // rows 0..5, then H66 and H77 (rows 6, 7 are synthesised by the sweep, RowLdsC)
 #pragma unroll
                         for (int r = 0; r < 6; r++)
 #pragma unroll
@@ -1833,7 +1835,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #ifdef MPC_FACTOR_PLAIN
                 rowpar_factor(lane, N, RS, sweep_worker);
 #else
-                if constexpr (G == 21) rowpar_factor(lane, N, RS, sweep_worker);      // (the one-block asm variant carries the dense layout's offsets)
+                if constexpr (COMPACT) rowpar_factor(lane, N, RS, sweep_worker);      // (the one-block asm variant carries the dense layout's offsets)
                 else rowpar_factor_fast(lane, N, RS, sweep_worker);
 #endif
                 __syncthreads();

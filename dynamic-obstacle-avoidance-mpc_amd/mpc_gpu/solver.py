@@ -4,6 +4,7 @@ Mirrors what the reference keeps inside its `AcadosOcpSolver` object (iterate X,
 solve path of src/simulation/robot_ocp_problem.py:186-198, batched over independent MPC instances.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -28,9 +29,11 @@ def _ptr(a):
 
 
 class BatchedMpc:
-    # lanes per horizon stage / wavefronts per SIMD applied to every new handle (0 = automatic); test / tuning hooks
-    default_lanes_per_stage = 0
-    default_waves_per_simd = 0
+    # lanes per horizon stage / wavefronts per SIMD / lanes per instance applied to every new handle (0 = automatic); test / tuning hooks,
+    # also settable from the environment for profiling runs of unmodified programs (MPC_LANES_PER_STAGE, MPC_WAVES_PER_SIMD, MPC_LANES_PER_INSTANCE)
+    default_lanes_per_stage = int(os.environ.get("MPC_LANES_PER_STAGE", "0"))
+    default_waves_per_simd = int(os.environ.get("MPC_WAVES_PER_SIMD", "0"))
+    default_lanes_per_instance = int(os.environ.get("MPC_LANES_PER_INSTANCE", "0"))
 
     def __init__(self, N=20, n_obst=3, Tf=2.0, max_batch=1, device=0, **cfg_overrides):
         self.cfg = _lib.default_config(N, n_obst, Tf, **cfg_overrides)
@@ -44,6 +47,8 @@ class BatchedMpc:
             _lib.check(_lib.lib().mpc_set_lanes_per_stage(self._h, int(BatchedMpc.default_lanes_per_stage)))
         if BatchedMpc.default_waves_per_simd:
             _lib.check(_lib.lib().mpc_set_waves_per_simd(self._h, int(BatchedMpc.default_waves_per_simd)))
+        if BatchedMpc.default_lanes_per_instance:
+            _lib.check(_lib.lib().mpc_set_lanes_per_instance(self._h, int(BatchedMpc.default_lanes_per_instance)))
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -225,6 +230,12 @@ class BatchedMpc:
 
     def lanes_per_stage(self, batch):
         return _lib.lib().mpc_get_lanes_per_stage(self._h, batch)
+
+    def kernel_name(self, batch, lookahead=True):
+        """the solve kernel instantiation a batch of this size runs, as a profiler prints it (without the namespace)"""
+        buf = C.create_string_buffer(96)
+        _lib.check(_lib.lib().mpc_get_kernel_name(self._h, batch, 1 if lookahead else 0, buf, 96))
+        return buf.value.decode()
 
     def set_waves_per_simd(self, waves):
         """stage-split mapping: 0 automatic, 1 one wavefront per SIMD (512 registers), 2 two (256 registers, compact LDS blocks)"""

@@ -206,6 +206,11 @@ int mpc_get_lanes_per_stage(mpc_handle *h, int batch);
  * per wavefront at N = 20, eight wavefronts per CU) for deeper batches, where a second resident wavefront fills the LDS and
  * dependent-issue stalls of the first.  1 / 2: forced.  The one-lane-per-stage mapping always runs one wavefront per SIMD (449 registers).
  * Same arithmetic specification either way.  No reference counterpart (tuning / test hook). */
+/* name of the solve kernel instantiation a batch of this size runs (as rocprofv3 prints it, without the namespace), for measurement
+ * records: "rti_split_kernel<n_obst, lanes per stage, two wavefronts per SIMD>" or "rti_solve_kernel<n_obst, lanes per instance, sweeps>"
+ * (sweeps: 0 systolic, 1 matrix cores, 2 row-parallel on dense LDS blocks, 3 row-parallel on compact LDS blocks).  lookahead: whether the
+ * obstacle look-ahead runs inside the kernel (mpc_closed_loop_step_dev) -- it enters the LDS budget that selects the block layout. */
+int mpc_get_kernel_name(mpc_handle *h, int batch, int lookahead, char *buf, int len);
 int mpc_set_waves_per_simd(mpc_handle *h, int waves);
 int mpc_get_waves_per_simd(mpc_handle *h, int batch);
 

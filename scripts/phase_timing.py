@@ -1,29 +1,41 @@
-"""Diagnostic: build a -DMPC_PHASE_TIMING variant of the library and print the cycle share of each phase of the solve kernel."""
-import sys, os, subprocess, ctypes as C
+"""Diagnostic: build a -DMPC_PHASE_TIMING variant of the library and print the cycle share of each phase of the solve kernel.
+usage (GPU box): python scripts/phase_timing.py [batch] [lanes_per_stage] [lanes_per_instance] [waves_per_simd] [-DEXTRA ...]
+(lanes_per_stage 0 = automatic / 1 = one lane per stage / 2, 3 = split; lanes_per_instance 0, 16, 21, 32, 64)"""
+import sys, os, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "dynamic-obstacle-avoidance-mpc_amd")
 sys.path[:0] = [ROOT, PKG]
-import numpy as np, torch
 so = os.path.join(ROOT, "gpurun_out", "libmpcgpu_timing.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-                       "-DMPC_PHASE_TIMING"] + [a for a in sys.argv[2:] if a.startswith("-D")] + ["-o", so, os.path.join(PKG, "csrc", "mpc_api.hip")])
+if not os.path.exists(so) or "--rebuild" in sys.argv:
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+                           "-DMPC_PHASE_TIMING"] + [a for a in sys.argv[1:] if a.startswith("-D")] + ["-o", so, os.path.join(PKG, "csrc", "mpc_api.hip")])
+os.environ["MPC_GPU_LIB"] = so
+import numpy as np, torch
 from mpc_gpu import _lib
-_lib.LIB_PATH = so
 import mpc_gpu, bench
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-x0, goal, obst, _ = bench.make_workload("c2" if B <= 4096 else "c3", B, 20, 3)
+from mpc_gpu.sharding import shard_slice
+nums = [int(a) for a in sys.argv[1:] if a.lstrip("-").isdigit()]
+B, lps, lpi, waves = (nums + [1024, 0, 0, 0])[:4] if len(nums) < 4 else nums[:4]
 dev = torch.device("cuda:0"); torch.cuda.set_device(0); torch.cuda.set_stream(torch.cuda.Stream(device=dev))
-loop = bench.Loop(mpc_gpu, 20, 3, B, x0, goal, obst, dev)
+x0, goal, obst, desc, _, G = bench.make_workload("c3", 1, 0, shard_slice)
+x0, goal, obst = x0[:B], goal[:B], obst[:B]
+loop = bench.Loop(mpc_gpu, torch, 20, 3, x0, goal, obst, dev)
+if lps: loop.m.set_lanes_per_stage(lps)
+if lpi: loop.m.set_lanes_per_instance(lpi)
+if waves: loop.m.set_waves_per_simd(waves)
 _lib.check(_lib.lib().mpc_debug_trace(loop.m._h, 1, B, None))
-for _ in range(10): loop.step()
+loop.reset()
+for _ in range(30): loop.control_step()
 torch.cuda.synchronize()
 tr = np.zeros((B, 50, 4)); _lib.check(_lib.lib().mpc_debug_trace(loop.m._h, 1, B, tr.ctypes.data))
 t = tr.reshape(B, -1)[:, :16]
+split = loop.m.lanes_per_stage(B) > 1
+print(f"B={B} lanes/stage {loop.m.lanes_per_stage(B)} lanes/instance {loop.m.lanes_per_instance(B)} waves/SIMD {loop.m.waves_per_simd(B)}")
 names = ["mu/conv check", "predictor assemble", "factor sweep", "rollout (affine)", "affine step + sigma", "corrector rhs", "corrector sweep", "rollout", "combined step + update", "(row-parallel: stage operands -> LDS)"]
 tot = t[:, :10].sum(1).mean(); it = loop.iters.double().mean().item()
-print(f"B={B} mean IPM iters {it:.2f}  total cycles/solve (IPM loop) {tot:.0f}  per iteration {tot/it:.0f}")
-for k, n in zip(range(10, 15), ["loads + look-ahead", "iterate loads", "linearise + W staging", "row state init", "tail (step, plant, stores)"]):
-    print(f"  outside the IPM loop: {n:28s} {t[:,k].mean():10.0f} cycles")
-print(f"  (of the affine rollout: the sweep itself        {t[:,15].mean():10.0f} cycles, per iter {t[:,15].mean()/it:8.0f})")
+print(f"mean IPM iters (last step) {it:.2f}  total cycles/solve (IPM loop) {tot:.0f}  per iteration {tot/it:.0f}")
+if split:
+    for k, n in zip(range(10, 15), ["loads + look-ahead", "iterate loads", "linearise + W staging", "row state init", "tail (step, plant, stores)"]):
+        print(f"  outside the IPM loop: {n:28s} {t[:,k].mean():10.0f} cycles")
 for k, n in enumerate(names[:10]): print(f"  {n:24s} {t[:,k].mean():10.0f} cycles  {100*t[:,k].mean()/tot:5.1f}%   per iter {t[:,k].mean()/it:8.0f}")

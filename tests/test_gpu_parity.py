@@ -150,9 +150,18 @@ def test_permutation_invariance_large_batch(env):
     x0, goal, obst = random_batch(B, no, seed=21)
     perm = np.random.default_rng(0).permutation(B)
     with mpc_gpu.BatchedMpc(N, no, 2.0, max_batch=B) as s:
+        lanes = s.lanes_per_instance(B)
         s.reset_guess(x0); g1 = s.solve(x0, obst, goal); X1, U1 = s.get_traj(B)
         s.reset_guess(x0[perm]); g2 = s.solve(x0[perm], obst[perm], goal[perm]); X2, U2 = s.get_traj(B)
-    assert (X1[perm] == X2).all() and (U1[perm] == U2).all() and (g1["status"][perm] == g2["status"]).all()
+    if lanes != 21:
+        assert (X1[perm] == X2).all() and (U1[perm] == U2).all() and (g1["status"][perm] == g2["status"]).all()
+    else:
+        # three instances per wavefront: the wavefront sums of an instance are formed in an order that depends on which third of the
+        # wavefront it occupies (the instances do not coincide with DPP rows), so a permuted batch agrees to rounding, not bit for bit
+        same = g1["status"][perm] == g2["status"]
+        assert same.mean() > 0.999
+        d = np.abs(X1[perm] - X2).reshape(B, -1).max(1)[same & (g2["status"] == 0)]
+        assert np.median(d) < 1e-12 and np.quantile(d, 0.999) < 1e-6 and d.max() < 1e-3
     # spot-check 64 of them against the oracle
     cfg = orc.config(N, no, 2.0, qp_tol=1e-8)
     idx = perm[:64]
@@ -320,9 +329,10 @@ def test_horizon_extremes_and_packing_boundaries(env, N):
 
 
 @pytest.mark.gpu
-def test_longest_horizon_with_ten_obstacles_uses_more_than_64k_lds(env):
-    """N = 62 with 10 obstacles and the on-device look-ahead needs ~66 KB of dynamic LDS per workgroup (row-parallel operands
-    + look-ahead staging): the launch must be granted it, and the result must still match the oracle"""
+def test_longest_horizon_with_ten_obstacles_takes_the_compact_stage_blocks(env):
+    """N = 62 with 10 obstacles: the dense stage blocks plus the look-ahead staging would need ~66 KB of dynamic LDS per workgroup; the
+    dispatcher takes the compact blocks instead (41 KB, look-ahead staged inside them, rti_solve_kernel<10, 64, 3>).  The result must match
+    the oracle"""
     mpc_gpu, orc = env
     N, no, B = 62, 10, 6
     x0, goal, obst = random_batch(B, no, seed=977)
@@ -392,12 +402,13 @@ def test_automatic_lane_mapping(env):
         from mpc_gpu import _lib
         with mpc_gpu.BatchedMpc(20, 3, 2.0, max_batch=70000) as s:
             assert s.lanes_per_stage(1) == 3 and s.lanes_per_stage(1024) == 3 and s.lanes_per_instance(1024) == 64
-            assert s.lanes_per_stage(65536) == 3 and s.waves_per_simd(4096) == 1 and s.waves_per_simd(4097) == 2 and s.waves_per_simd(65536) == 2
+            assert s.lanes_per_stage(12288) == 3 and s.waves_per_simd(4096) == 1 and s.waves_per_simd(4097) == 2 and s.waves_per_simd(12288) == 2
+            assert s.lanes_per_stage(12289) == 1 and s.lanes_per_instance(12289) == 21 and s.lanes_per_instance(65536) == 21     # three per wavefront
             s.set_waves_per_simd(1)
-            assert s.waves_per_simd(65536) == 1
+            assert s.waves_per_simd(8192) == 1
             assert _lib.lib().mpc_set_waves_per_simd(s._h, 3) == _lib.MPC_ERR_ARG
             s.set_lanes_per_instance(64)
-            assert s.lanes_per_stage(8) == 1 and s.waves_per_simd(65536) == 1
+            assert s.lanes_per_stage(8) == 1 and s.waves_per_simd(65536) == 1 and s.lanes_per_instance(65536) == 64
         with mpc_gpu.BatchedMpc(20, 10, 2.0, max_batch=70000) as s:
             assert s.lanes_per_stage(65536) == 3 and s.waves_per_simd(65536) == 1           # 10 obstacles: never the 256-register build
         with mpc_gpu.BatchedMpc(10, 3, 1.0, max_batch=70000) as s:
@@ -435,3 +446,46 @@ def test_two_wavefronts_per_simd_variant_is_bitwise_the_one_wavefront_variant(en
         assert np.array_equal(Xa, Xb) and np.array_equal(Ua, Ub)
         for key in ("u0", "cost", "status", "iters"):
             assert np.array_equal(ga[key], gb[key]), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,no,B", [(20, 3, 500), (20, 5, 100), (10, 3, 200), (17, 10, 40), (2, 3, 31)])
+def test_three_instances_per_wavefront(env, N, no, B):
+    """G = 21 (lanes [0,21), [21,42), [42,63) of a wavefront hold three instances; compact LDS stage blocks; the sweeps of the three
+    instances run in DPP rows 0..2) against two / four instances per wavefront and against the oracle: statuses equal, iteration counts
+    equal but for a rounding case, iterates equal to rounding (the wavefront reductions add in a different order); batch not a multiple of 3;
+    look-ahead in the kernel and explicit P; three closed-loop steps"""
+    mpc_gpu, orc = env
+    x0, goal, obst = random_batch(B, no, seed=1300 + N + no)
+    cfg = orc.config(N, no, 0.1 * N)
+    P = oracle_P(orc, cfg, obst); Xg, Ug = oracle_guess(orc, cfg, x0)
+    res = {}
+    for G in (21, 32 if N + 2 > 16 else 16):
+        with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
+            s.set_lanes_per_stage(1); s.set_lanes_per_instance(G)
+            assert s.lanes_per_instance(B) == G
+            s.reset_guess(x0); outs = []
+            for k in range(3):
+                g = s.solve(x0, obst if k != 1 else P, goal); X, U = s.get_traj(B); s.shift(B)
+                outs.append((g, X, U))
+            res[G] = outs
+    other = [k for k in res if k != 21][0]
+    for (ga, Xa, Ua), (gb, Xb, Ub) in zip(res[21], res[other]):
+        assert (ga["status"] == gb["status"]).mean() >= 0.99
+        ok = (ga["status"] == 0) & (gb["status"] == 0)
+        assert (ga["iters"][ok] == gb["iters"][ok]).mean() >= 0.98
+        d = np.abs(Xa - Xb).reshape(B, -1).max(1)[ok]
+        assert np.median(d) < 1e-10 and np.quantile(d, 0.95) < 1e-6 and d.max() < 1e-3
+    o = orc.rti_solve_batch(cfg, x0, P, goal, Xg, Ug)
+    g, X, U = res[21][0]
+    assert (g["status"] == o["status"]).all()
+    ok = o["status"] == 0
+    d = np.abs(X - o["X"]).reshape(B, -1).max(1)[ok]
+    assert np.quantile(d, 0.9) < 1e-8 and d.max() < 1e-3
+    for b in np.nonzero(ok)[0][d > 1e-6]:       # judged by the QP (helpers.qp_merit), as everywhere
+        fg, eqg, bg = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xg[b], Ug[b], X[b], U[b])
+        fo, _, _ = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xg[b], Ug[b], o["X"][b], o["U"][b])
+        assert eqg <= 1e-7 and bg <= 1e-7 and fg <= fo + 1e-7 * max(1.0, abs(fo)), (b, fg, fo)
+    with mpc_gpu.BatchedMpc(21, 3, 2.1, max_batch=4) as s:
+        from mpc_gpu import _lib
+        assert _lib.lib().mpc_set_lanes_per_instance(s._h, 21) == _lib.MPC_ERR_ARG      # 22 stages do not fit 21 lanes
