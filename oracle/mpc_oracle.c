@@ -1,7 +1,7 @@
 /*
  * mpc_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).  See mpc_oracle.h.
  *
- * PARITY UNPINNED for solve outputs (acados/HPIPM are absent; see header).
+ * Pinned per seed by the closed-loop tables the reference recorded (acados/HPIPM themselves are absent; see the header).
  *
  * Deliberately written as a dense, generic, residual-form ("delta form") primal-dual interior
  * point method with explicit costates and explicit KKT residuals, i.e. NOT the way the HIP

@@ -1,7 +1,7 @@
 """ctypes binding of the CPU ORACLE (oracle/liborc.so) -- test infrastructure, NOT product code.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
-PARITY UNPINNED for solve outputs (see oracle/mpc_oracle.h).
+Pinned per seed by the closed-loop tables the reference recorded (see oracle/mpc_oracle.h, tests/test_oracle_golden.py).
 """
 import ctypes as C
 import os

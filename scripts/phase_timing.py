@@ -1,5 +1,6 @@
 """Diagnostic: build a -DMPC_PHASE_TIMING variant of the library and print the cycle share of each phase of the solve kernel.
-usage (GPU box): python scripts/phase_timing.py [batch] [lanes_per_stage] [lanes_per_instance] [waves_per_simd] [-DEXTRA ...]
+usage (GPU box): python scripts/phase_timing.py [batch] [lanes_per_stage] [lanes_per_instance] [waves_per_simd] [N] [n_obst] [--rebuild] [-DEXTRA ...]
+(N, n_obst: 20 3 = the C3 workload, 50 10 = the C5 workload)
 (lanes_per_stage 0 = automatic / 1 = one lane per stage / 2, 3 = split; lanes_per_instance 0, 16, 21, 32, 64)"""
 import sys, os, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,11 +17,11 @@ from mpc_gpu import _lib
 import mpc_gpu, bench
 from mpc_gpu.sharding import shard_slice
 nums = [int(a) for a in sys.argv[1:] if a.lstrip("-").isdigit()]
-B, lps, lpi, waves = (nums + [1024, 0, 0, 0])[:4] if len(nums) < 4 else nums[:4]
+B, lps, lpi, waves, N, no = (nums + [1024, 0, 0, 0, 20, 3][len(nums):])[:6]
 dev = torch.device("cuda:0"); torch.cuda.set_device(0); torch.cuda.set_stream(torch.cuda.Stream(device=dev))
-x0, goal, obst, desc, _, G = bench.make_workload("c3", 1, 0, shard_slice)
+x0, goal, obst, desc, _, G = bench.make_workload("c3" if (N, no) == (20, 3) else "c5", 1, 0, shard_slice)
 x0, goal, obst = x0[:B], goal[:B], obst[:B]
-loop = bench.Loop(mpc_gpu, torch, 20, 3, x0, goal, obst, dev)
+loop = bench.Loop(mpc_gpu, torch, N, no, x0, goal, obst, dev)
 if lps: loop.m.set_lanes_per_stage(lps)
 if lpi: loop.m.set_lanes_per_instance(lpi)
 if waves: loop.m.set_waves_per_simd(waves)

@@ -4,7 +4,7 @@
 # One --kernel-trace --stats pass, then one PMC pass per counter group (FETCH_SIZE and WRITE_SIZE do not fit one pass; PMC
 # passes carry no tracing options).  The program after `--` is python3 itself.
 set -u
-TAG=${1:-r01_final}; shift || true
+TAG=${1:-r02}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"

@@ -9,7 +9,7 @@ on the GPU box, so nothing at test time reads it -- tests consume the committed 
 What can be pinned: the scenario generator (utils/obstacle_generator.py:8-28), the obstacle
 motion model and look-ahead (utils/visualization.py:20-79), the constants (models/world_specification.py) and
 summary statistics of the recorded closed-loop tables (src/simulation/test_data/*.csv).  The MPC solve itself
-(acados/HPIPM) is not importable: parity of the solve is UNPINNED.
+(acados/HPIPM) is not importable; it is pinned through the recorded tables, replayed per seed (tests/test_oracle_golden.py, test_gpu_replay.py).
 """
 import glob
 import importlib
