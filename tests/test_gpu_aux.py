@@ -113,7 +113,7 @@ def test_reference_step_loop_on_the_shims(env):
 
 def test_fused_closed_loop_step_equals_kernel_sequence(env):
     """mpc_closed_loop_step_dev (one launch) == predict + solve + plant + obstacle step + shift (five launches), bit for bit,
-    over 12 control steps with obstacle noise, for 1 and 2 instances per wavefront"""
+    over 12 control steps with obstacle noise, for every lane mapping (1, 2, 3 instances per wavefront; stage split with 1 and 2 wavefronts per SIMD)"""
     import torch
     mpc_gpu, orc = env
     from mpc_gpu import _lib
@@ -123,10 +123,16 @@ def test_fused_closed_loop_step_equals_kernel_sequence(env):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     z = lambda *s, dt=torch.float64: torch.zeros(*s, dtype=dt, device=dev)
     noise = torch.from_numpy(np.random.default_rng(0).normal(size=(12, B, no, 2))).to(dev)
-    for lanes in (64, 32, 0):       # 0: automatic = rows of a stage split over 3 lanes (batch 67)
+    # lanes per instance 64 / 32 / 21 (one, two, three instances per wavefront), 0: automatic = rows of a stage split over 3 lanes (batch 67),
+    # -2: the split mapping with two wavefronts per SIMD
+    for lanes in (64, 32, 21, 0, -2):
         # torch ops (copy_) and the library's kernels must share ONE queue: an explicit, non-default torch stream
         with mpc_gpu.BatchedMpc(N, no, 2.0, max_batch=B) as s, torch.cuda.stream(torch.cuda.Stream(device=dev)):
-            _lib.check(_lib.lib().mpc_set_lanes_per_instance(s._h, lanes))
+            if lanes > 0:
+                s.set_lanes_per_stage(1)
+            _lib.check(_lib.lib().mpc_set_lanes_per_instance(s._h, max(lanes, 0)))
+            if lanes == -2:
+                s.set_lanes_per_stage(3); s.set_waves_per_simd(2)
             st = torch.cuda.current_stream().cuda_stream
             assert st != 0
             # reference sequence

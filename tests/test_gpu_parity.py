@@ -489,3 +489,40 @@ def test_three_instances_per_wavefront(env, N, no, B):
     with mpc_gpu.BatchedMpc(21, 3, 2.1, max_batch=4) as s:
         from mpc_gpu import _lib
         assert _lib.lib().mpc_set_lanes_per_instance(s._h, 21) == _lib.MPC_ERR_ARG      # 22 stages do not fit 21 lanes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [65536, 32768])
+def test_full_size_batches_c3_and_c4_share(env, B):
+    """BASELINE configs[2] (65536 on one GPU) and one GPU's share of configs[3] (32768 of 262144) at FULL size, whatever kernel the
+    dispatcher gives them: two closed-loop steps; instances are independent (a permuted batch gives the permuted result -- bit for bit, or
+    to rounding where three instances share a wavefront); 256 instances sampled from the whole range agree with the oracle"""
+    mpc_gpu, orc = env
+    N, no = 20, 3
+    x0, goal, obst = random_batch(B, no, seed=1234)
+    perm = np.random.default_rng(1).permutation(B)
+    with mpc_gpu.BatchedMpc(N, no, 2.0, max_batch=B) as s:
+        kernel = s.kernel_name(B, lookahead=False)
+        s.reset_guess(x0); g1 = s.solve(x0, obst, goal); s.shift(B); Xs, Us = s.get_traj(B); h1 = s.solve(x0, obst, goal); X1, U1 = s.get_traj(B)
+        s.reset_guess(x0[perm]); s.solve(x0[perm], obst[perm], goal[perm]); s.shift(B); h2 = s.solve(x0[perm], obst[perm], goal[perm]); X2, U2 = s.get_traj(B)
+    same = h1["status"][perm] == h2["status"]
+    if "21" in kernel.split(",")[1]:
+        assert same.mean() > 0.999
+        d = np.abs(X1[perm] - X2).reshape(B, -1).max(1)[same & (h2["status"] == 0)]
+        assert np.median(d) < 1e-11 and np.quantile(d, 0.999) < 1e-5
+    else:
+        assert same.all() and np.array_equal(X1[perm], X2) and np.array_equal(U1[perm], U2)
+    assert (g1["status"] != 4).mean() > 0.99 and 5.0 < g1["iters"].mean() < 12.0
+    idx = np.linspace(0, B - 1, 256).astype(int)
+    cfg = orc.config(N, no, 2.0, qp_tol=1e-8)
+    P = oracle_P(orc, cfg, obst[idx])
+    o = orc.rti_solve_batch(cfg, x0[idx], P, goal[idx], Xs[idx], Us[idx])          # second step, from the GPU's own shifted iterate
+    assert (o["status"] == h1["status"][idx]).all()
+    ok = o["status"] == 0
+    d = np.abs(o["X"] - X1[idx]).reshape(256, -1).max(1)[ok]
+    assert np.quantile(d, 0.98) < 1e-8 and d.max() < 1e-3
+    for k in np.nonzero(ok)[0][d > TOL_X]:
+        b = idx[k]
+        fg, eqg, bg = qp_merit(orc, cfg, x0[b], P[k], goal[b], Xs[b], Us[b], X1[b], U1[b])
+        fo, _, _ = qp_merit(orc, cfg, x0[b], P[k], goal[b], Xs[b], Us[b], o["X"][k], o["U"][k])
+        assert eqg <= 1e-7 and bg <= 1e-7 and fg <= fo + 1e-7 * max(1.0, abs(fo)), (b, fg, fo)
