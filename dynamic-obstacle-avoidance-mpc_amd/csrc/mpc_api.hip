@@ -210,7 +210,8 @@ SolvePlan plan_solve(mpc_handle *h, int batch, bool lookahead)
     // wavefronts its SIMDs can hold (N = 50, 10 obstacles: 51 KB -> 3 per CU dense, 32 KB -> 4 compact)
     const bool compact = rowpar && (q.G == 21 || (q.G == 64 && dense > 40960));
     q.fact = use_mfma ? 1 : (rowpar ? (compact ? 3 : 2) : 0);
-    q.lds = compact ? (size_t)mpc::RowLdsC::total(N, ipw) * sizeof(double) : dense;
+    // (compact blocks with 10 obstacles: the look-ahead positions stay resident behind the blocks, rti_kernel.hpp PLDS)
+    q.lds = compact ? (size_t)(no >= 10 ? mpc::RowLdsC::total_with_positions(N, ipw, no) : mpc::RowLdsC::total(N, ipw)) * sizeof(double) : dense;
     return q;
 }
 

@@ -484,6 +484,13 @@ struct RowLdsC {
     static __host__ __device__ constexpr int pad_front(int N) { return AHEAD * HS > WS * (N - 1) ? AHEAD * HS - WS * (N - 1) : WS; }
     static __host__ __device__ constexpr int pad_rear() { return AHEAD * HS; }
     static __host__ __device__ constexpr int total(int N, int instances) { return CT + pad_front(N) + instances * per_instance(N) + pad_rear(); }
+    // with the obstacle look-ahead of the instances kept resident behind the blocks (10 obstacles, "lean" row state): the rear padding is only
+    // ever READ (operand requests running ahead of the last stage), so the positions may occupy it
+    static __host__ __device__ constexpr int positions_at(int N, int instances) { return CT + pad_front(N) + instances * per_instance(N); }
+    static __host__ __device__ constexpr int total_with_positions(int N, int instances, int n_obst)
+    {
+        return positions_at(N, instances) + (instances * (N + 1) * n_obst * 2 > pad_rear() ? instances * (N + 1) * n_obst * 2 : pad_rear());
+    }
     double *W, *H, *R, *C;
     __device__ __forceinline__ RowLdsC(double *base, int N, double *table) : W(base), H(base + WS * N), R(base + WS * N), C(table) {}
 };
@@ -1442,6 +1449,8 @@ template <int NOBST, int G, int FACT>
 __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 {
     constexpr bool USE_MFMA = FACT == 1, ROWPAR = FACT >= 2, COMPACT = FACT == 3;
+    constexpr bool LEAN = NOBST >= 10;          // ten obstacle pairs: recomputable row state is not carried (see obst_view below)
+    constexpr bool PLDS = LEAN && COMPACT;      // ... and the obstacle positions of a stage stay in LDS behind the compact stage blocks
     static_assert(!USE_MFMA || G == 64, "the matrix-core factorisation maps one instance per wavefront");
     static_assert(G != 21 || COMPACT, "three instances per wavefront exist for the row-parallel sweeps on compact stage blocks only");
     constexpr int IPW = 64 / G;               // instances per wavefront (G = 21: three, lanes [0,21), [21,42), [42,63); lane 63 idles)
@@ -1479,11 +1488,21 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     const LT RS = blocks_of(G == 21 ? (lane >> 4 < 3 ? lane >> 4 : 2) : slot);
     const bool sweep_worker = (G == 21) ? lane < 48 : i < 16;
     double *lds_P = lds_raw + (USE_MFMA ? MfmaLds::doubles(N) : (ROWPAR ? RowLds::total(N, IPW) : 0));
-    double pxy[NOBST][2];
-    if (p.obst) {
-        // (compact blocks: the look-ahead is staged in the instance's own H~aug region, which is first written after the positions have been read)
-        double *Pl = COMPACT ? RL.H : lds_P + (size_t)slot * (N + 1) * NOBST * 2;
-        if (2 * NOBST <= G) {
+    double pxy[PLDS ? 1 : NOBST][2];
+    // PLDS: this lane's stage positions, resident in LDS for the whole solve
+    const double *myP = lds_raw;
+    if (p.obst || PLDS) {
+        // (compact blocks: the look-ahead is staged in the instance's own H~aug region, which is first written after the positions have been
+        // read -- or, PLDS, behind the blocks, where it stays)
+        double *Pl = PLDS ? lds_raw + RowLdsC::positions_at(N, IPW) + (size_t)slot * (N + 1) * NOBST * 2
+                          : (COMPACT ? RL.H : lds_P + (size_t)slot * (N + 1) * NOBST * 2);
+        if (!p.obst) {              // PLDS with explicit parameters (parameterize_model): every stage lane copies its row of P
+            if (act) {
+                const double *Pg = p.P + ((size_t)inst * (N + 1) + i) * NOBST * 2;
+#pragma unroll
+                for (int e = 0; e < 2 * NOBST; e++) Pl[i * NOBST * 2 + e] = Pg[e];
+            }
+        } else if (2 * NOBST <= G) {
             if (i < 2 * NOBST) {   // lane i walks coordinate i & 1 of obstacle i >> 1 through the horizon (Obstacle.predict_trajectory, visualization.py:62-79)
                 const int j = i >> 1, c = i & 1;
                 const double *o = p.obst + ((size_t)inst * NOBST + j) * 4;
@@ -1506,13 +1525,19 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             }
         }
         __syncthreads();
+        if constexpr (PLDS) myP = Pl + (act ? i : 0) * NOBST * 2;
+        else {
 #pragma unroll
-        for (int j = 0; j < NOBST; j++) { pxy[j][0] = act ? Pl[(i * NOBST + j) * 2] : 0.0; pxy[j][1] = act ? Pl[(i * NOBST + j) * 2 + 1] : 0.0; }
+            for (int j = 0; j < NOBST; j++) { pxy[j][0] = act ? Pl[(i * NOBST + j) * 2] : 0.0; pxy[j][1] = act ? Pl[(i * NOBST + j) * 2 + 1] : 0.0; }
+        }
     } else {
         const double *Pg = p.P + ((size_t)inst * (N + 1) + (act ? i : 0)) * NOBST * 2;
 #pragma unroll
         for (int j = 0; j < NOBST; j++) { pxy[j][0] = act ? Pg[2 * j] : 0.0; pxy[j][1] = act ? Pg[2 * j + 1] : 0.0; }
     }
+    // position of obstacle j at this lane's stage
+    auto pos_x = [&](int j) { if constexpr (PLDS) return myP[2 * j]; else return pxy[j][0]; };
+    auto pos_y = [&](int j) { if constexpr (PLDS) return myP[2 * j + 1]; else return pxy[j][1]; };
     double xi[5] = {0, 0, 0, 0, 0}, ui[2] = {0, 0}, xnext[5] = {0, 0, 0, 0, 0};
     if (act) {
 #pragma unroll
@@ -1619,21 +1644,39 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         }
     }
     // obstacle rows j: rho1 = h + a'dx + s >= 0 (lam1,t1), rho2 = s >= 0 (lam2,t2); robot_model.py:60-65
-    double hh[NOBST], ax[NOBST], ay[NOBST], sv[NOBST], l1[NOBST], t1[NOBST], l2[NOBST], t2[NOBST], rt1[NOBST], rt2[NOBST];
+    // LEAN (10 obstacles): the row state of ten obstacle pairs does not fit the register file next to the sweeps (784 B of scratch per lane
+    // and 47 % of the wave cycles spent waiting for it, profiles/r02_c5_pmc_summary.json), so what is a pure function of the kept state --
+    // h, dh/dx, dh/dy of a row and the reciprocals 1/t1, 1/t2 -- is recomputed where it is used instead of being carried: 50 doubles per
+    // lane less.  `ObstView` is one row pair's view for one phase; per phase the inputs pass through an opaque zero so that the optimiser
+    // cannot merge the recomputations back into long-lived registers.
+    constexpr int NKEEP = LEAN ? 1 : NOBST;
+    double hh[NKEEP], ax[NKEEP], ay[NKEEP], rt1[NKEEP], rt2[NKEEP];
+    double sv[NOBST], l1[NOBST], t1[NOBST], l2[NOBST], t2[NOBST];
+    struct ObstView { double hh, ax, ay, rt1, rt2; };
+    auto obst_view = [&](int j, double zero) {
+        ObstView v;
+        if constexpr (LEAN) {
+            const double ex = (xi[0] + zero) - pos_x(j), ey = (xi[1] + zero) - pos_y(j);
+            v.hh = ex * ex + ey * ey - p.r2; v.ax = 2 * ex; v.ay = 2 * ey;
+            v.rt1 = rcp_nr(t1[j] + zero); v.rt2 = rcp_nr(t2[j] + zero);
+        } else { v.hh = hh[j]; v.ax = ax[j]; v.ay = ay[j]; v.rt1 = rt1[j]; v.rt2 = rt2[j]; }
+        return v;
+    };
 #pragma unroll
     for (int j = 0; j < NOBST; j++) {
-        const double ex = xi[0] - pxy[j][0], ey = xi[1] - pxy[j][1];
-        hh[j] = ex * ex + ey * ey - p.r2; ax[j] = 2 * ex; ay[j] = 2 * ey;
+        const double ex = xi[0] - pos_x(j), ey = xi[1] - pos_y(j);
+        const double h0 = ex * ex + ey * ey - p.r2;
         if (soft) {
-            sv[j] = (hh[j] < 0 ? -hh[j] : 0.0) + p.thr0;
-            t1[j] = fmax(hh[j] + sv[j], p.thr0);
+            sv[j] = (h0 < 0 ? -h0 : 0.0) + p.thr0;
+            t1[j] = fmax(h0 + sv[j], p.thr0);
             t2[j] = fmax(sv[j], p.thr0);
         } else {
-            sv[j] = 0.0; t1[j] = fmax(hh[j], p.thr0); t2[j] = 1.0;
-            if (vs) lin0 = fmax(lin0, t1[j] - hh[j]);
+            sv[j] = 0.0; t1[j] = fmax(h0, p.thr0); t2[j] = 1.0;
+            if (vs) lin0 = fmax(lin0, t1[j] - h0);
         }
-        rt1[j] = rcp_nr(t1[j]); rt2[j] = rcp_nr(t2[j]);
-        l1[j] = p.mu0 * rt1[j]; l2[j] = soft ? p.mu0 * rt2[j] : 0.0;
+        const double r1 = rcp_nr(t1[j]), r2 = rcp_nr(t2[j]);
+        l1[j] = p.mu0 * r1; l2[j] = soft ? p.mu0 * r2 : 0.0;
+        if constexpr (!LEAN) { hh[j] = h0; ax[j] = 2 * ex; ay[j] = 2 * ey; rt1[j] = r1; rt2[j] = r2; }
     }
     int n_items_lane = 0;
 #pragma unroll
@@ -1698,23 +1741,33 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         };
         // weights / residuals of obstacle row pair j at the iterate zz
         struct SoftT { double w1, w2, rD, be1, be2, rs, rd1, rd2; };
-        auto soft_terms = [&](int j, const double zz[7]) {
+        auto soft_terms = [&](int j, const ObstView &v, const double zz[7]) {
             SoftT o;
-            const double y = ax[j] * zz[2] + ay[j] * zz[3];
-            o.w1 = l1[j] * rt1[j];
+            const double y = v.ax * zz[2] + v.ay * zz[3];
+            o.w1 = l1[j] * v.rt1;
             if (soft) {
-                o.rd1 = (hh[j] + y + sv[j]) - t1[j]; o.rd2 = sv[j] - t2[j];
-                o.be1 = (l1[j] * t1[j] + l1[j] * o.rd1) * rt1[j];
-                o.w2 = l2[j] * rt2[j];
-                o.be2 = (l2[j] * t2[j] + l2[j] * o.rd2) * rt2[j];
+                o.rd1 = (v.hh + y + sv[j]) - t1[j]; o.rd2 = sv[j] - t2[j];
+                o.be1 = (l1[j] * t1[j] + l1[j] * o.rd1) * v.rt1;
+                o.w2 = l2[j] * v.rt2;
+                o.be2 = (l2[j] * t2[j] + l2[j] * o.rd2) * v.rt2;
                 o.rs = zpen * sv[j] + zpen - l1[j] - l2[j];
                 o.rD = rcp_nr(zpen + o.w1 + o.w2);
             } else {
-                o.rd1 = (hh[j] + y) - t1[j]; o.rd2 = 0.0;
-                o.be1 = (l1[j] * t1[j] + l1[j] * o.rd1) * rt1[j];
+                o.rd1 = (v.hh + y) - t1[j]; o.rd2 = 0.0;
+                o.be1 = (l1[j] * t1[j] + l1[j] * o.rd1) * v.rt1;
                 o.w2 = 0.0; o.be2 = 0.0; o.rs = 0.0; o.rD = 0.0;
             }
             return o;
+        };
+        // an opaque 0.0 per phase (one v_mov; see obst_view)
+        auto phase_zero = [&]() { double zz_ = 0.0; if constexpr (LEAN) asm volatile("" : "+v"(zz_)); return zz_; };
+        // LEAN: the reciprocals of the box rows are phase-local as well (recomputed at the head of every phase that uses them)
+        auto refresh_box_rcp = [&]() {
+            if constexpr (LEAN) {
+                const double pz = phase_zero();
+#pragma unroll
+                for (int k = 0; k < NB; k++) { rtl[k] = rcp_nr(tl[k] + pz); rth[k] = rcp_nr(th[k] + pz); }
+            }
         };
 
         // ---- predictor (sigma = 0): local gradient, barrier terms, reduced Hessian ----
@@ -1724,6 +1777,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #pragma unroll
         for (int c = 0; c < 5; c++) { bbr[c] = rhoPi * bb[c]; x_init[c] = rhoPi * d0[c]; }
         {
+            refresh_box_rcp();
             double vals[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
 #pragma unroll
             for (int k = 0; k < NB; k++) OPAQUE(vals[k]);
@@ -1762,17 +1816,19 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 cb[zidx[k]] += bl - bh;
             }
             if (vs) {
+                const double pz = phase_zero();
 #pragma unroll
                 for (int j = 0; j < NOBST; j++) {
-                    const SoftT o = soft_terms(j, z);
+                    const ObstView v = obst_view(j, pz);
+                    const SoftT o = soft_terms(j, v, z);
                     double weff, geff;
                     if (soft) {
                         weff = o.w1 * (zpen + o.w2) * o.rD;
                         geff = (o.be1 * (zpen + o.w2) - o.w1 * (o.rs + o.be2)) * o.rD;
                     } else { weff = o.w1; geff = o.be1; }
-                    Hq[2] += weff * ax[j] * ax[j]; Hq[3] += weff * ay[j] * ay[j]; Hq[7] += weff * ax[j] * ay[j];
-                    gloc[2] -= l1[j] * ax[j]; gloc[3] -= l1[j] * ay[j];
-                    cb[2] += geff * ax[j]; cb[3] += geff * ay[j];
+                    Hq[2] += weff * v.ax * v.ax; Hq[3] += weff * v.ay * v.ay; Hq[7] += weff * v.ax * v.ay;
+                    gloc[2] -= l1[j] * v.ax; gloc[3] -= l1[j] * v.ay;
+                    cb[2] += geff * v.ax; cb[3] += geff * v.ay;
                 }
             }
             MPC_TICK(1);
@@ -1898,6 +1954,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             for (int c = 0; c < 7; c++) OPAQUE(z[c]);
 #pragma unroll
             for (int j = 0; j < NOBST; j++) { OPAQUE(l1[j]); OPAQUE(l2[j]); }
+            refresh_box_rcp();
             double vals[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
 #pragma unroll
             for (int k = 0; k < NB; k++) OPAQUE(vals[k]);
@@ -1918,24 +1975,26 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 }
             }
             double dt1_[NOBST], dl1_[NOBST], dt2_[NOBST], dl2_[NOBST];
+            const double pz = phase_zero();
 #pragma unroll
             for (int j = 0; j < NOBST; j++) {
                 dt1_[j] = dl1_[j] = dt2_[j] = dl2_[j] = 0.0; pp1[j] = pp2[j] = 0.0;
                 if (vs) {
-                    const SoftT o = soft_terms(j, z);
-                    const double y = ax[j] * za[2] + ay[j] * za[3];
+                    const ObstView v = obst_view(j, pz);
+                    const SoftT o = soft_terms(j, v, z);
+                    const double y = v.ax * za[2] + v.ay * za[3];
                     if (soft) {
                         const double rsum = o.rs + o.be1 + o.be2;
                         const double ds = -(rsum + o.w1 * y) * o.rD;
                         dt1_[j] = o.rd1 + (y * (zpen + o.w2) - rsum) * o.rD;     // y + ds without cancellation
                         dt2_[j] = o.rd2 + ds;
-                        dl2_[j] = -(l2[j] * t2[j] + l2[j] * dt2_[j]) * rt2[j];
+                        dl2_[j] = -(l2[j] * t2[j] + l2[j] * dt2_[j]) * v.rt2;
                         pp2[j] = dl2_[j] * dt2_[j];
-                        rmax = fmax(rmax, -dt2_[j] * rt2[j]); rmaxd = fmax(rmaxd, fma(dt2_[j], rt2[j], 1.0));
+                        rmax = fmax(rmax, -dt2_[j] * v.rt2); rmaxd = fmax(rmaxd, fma(dt2_[j], v.rt2, 1.0));
                     } else dt1_[j] = o.rd1 + y;
-                    dl1_[j] = -(l1[j] * t1[j] + l1[j] * dt1_[j]) * rt1[j];
+                    dl1_[j] = -(l1[j] * t1[j] + l1[j] * dt1_[j]) * v.rt1;
                     pp1[j] = dl1_[j] * dt1_[j];
-                    rmax = fmax(rmax, -dt1_[j] * rt1[j]); rmaxd = fmax(rmaxd, fma(dt1_[j], rt1[j], 1.0));
+                    rmax = fmax(rmax, -dt1_[j] * v.rt1); rmaxd = fmax(rmaxd, fma(dt1_[j], v.rt1, 1.0));
                 }
             }
             seg_reduce2<G, false>(rmax, rmaxd, lane);
@@ -1968,6 +2027,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         // ---- corrector: homogeneous system for the change of right-hand side, d beta_c = (dlam_aff dt_aff - sigma mu) / t ----
         double dz[7] = {0, 0, 0, 0, 0, 0, 0};
         {
+            refresh_box_rcp();
             double gc[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int k = 0; k < NB; k++) if ((k < 2) ? vbu : vbx) {
@@ -1975,16 +2035,18 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 gc[zidx[k]] += dbl - dbh;
             }
             if (vs) {
+                const double pz = phase_zero();
 #pragma unroll
                 for (int j = 0; j < NOBST; j++) {
-                    const double db1 = (pp1[j] - smu) * rt1[j];
+                    const ObstView v = obst_view(j, pz);
+                    const double db1 = (pp1[j] - smu) * v.rt1;
                     double geff;
                     if (soft) {
-                        const double w1 = l1[j] * rt1[j], w2 = l2[j] * rt2[j];
-                        const double db2 = (pp2[j] - smu) * rt2[j];
+                        const double w1 = l1[j] * v.rt1, w2 = l2[j] * v.rt2;
+                        const double db2 = (pp2[j] - smu) * v.rt2;
                         geff = (db1 * (zpen + w2) - w1 * db2) * rcp_nr(zpen + w1 + w2);
                     } else geff = db1;
-                    gc[2] += geff * ax[j]; gc[3] += geff * ay[j];
+                    gc[2] += geff * v.ax; gc[3] += geff * v.ay;
                 }
             }
             MPC_TICK(5);
@@ -2040,6 +2102,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             for (int c = 0; c < 7; c++) OPAQUE(z[c]);
 #pragma unroll
             for (int j = 0; j < NOBST; j++) { OPAQUE(l1[j]); OPAQUE(l2[j]); }
+            refresh_box_rcp();
             double vals[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
 #pragma unroll
             for (int k = 0; k < NB; k++) OPAQUE(vals[k]);
@@ -2060,23 +2123,25 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 }
             }
             double dt1_[NOBST], dl1_[NOBST], dt2_[NOBST], dl2_[NOBST], ds_[NOBST];
+            const double pz = phase_zero();
 #pragma unroll
             for (int j = 0; j < NOBST; j++) {
                 dt1_[j] = dl1_[j] = dt2_[j] = dl2_[j] = ds_[j] = 0.0;
                 if (vs) {
-                    const SoftT o = soft_terms(j, z);
-                    const double y = ax[j] * dz[2] + ay[j] * dz[3];
+                    const ObstView v = obst_view(j, pz);
+                    const SoftT o = soft_terms(j, v, z);
+                    const double y = v.ax * dz[2] + v.ay * dz[3];
                     if (soft) {
-                        const double db1 = (pp1[j] - smu) * rt1[j], db2 = (pp2[j] - smu) * rt2[j];
+                        const double db1 = (pp1[j] - smu) * v.rt1, db2 = (pp2[j] - smu) * v.rt2;
                         const double rsum = o.rs + (o.be1 + db1) + (o.be2 + db2);
                         ds_[j] = -(rsum + o.w1 * y) * o.rD;
                         dt1_[j] = o.rd1 + (y * (zpen + o.w2) - rsum) * o.rD;
                         dt2_[j] = o.rd2 + ds_[j];
-                        dl2_[j] = -(l2[j] * t2[j] - smu + pp2[j] + l2[j] * dt2_[j]) * rt2[j];
-                        rmax = fmax(rmax, -dt2_[j] * rt2[j]); rmaxd = fmax(rmaxd, -dl2_[j] * rcp_nr(l2[j]));
+                        dl2_[j] = -(l2[j] * t2[j] - smu + pp2[j] + l2[j] * dt2_[j]) * v.rt2;
+                        rmax = fmax(rmax, -dt2_[j] * v.rt2); rmaxd = fmax(rmaxd, -dl2_[j] * rcp_nr(l2[j]));
                     } else dt1_[j] = o.rd1 + y;
-                    dl1_[j] = -(l1[j] * t1[j] - smu + pp1[j] + l1[j] * dt1_[j]) * rt1[j];
-                    rmax = fmax(rmax, -dt1_[j] * rt1[j]); rmaxd = fmax(rmaxd, -dl1_[j] * rcp_nr(l1[j]));
+                    dl1_[j] = -(l1[j] * t1[j] - smu + pp1[j] + l1[j] * dt1_[j]) * v.rt1;
+                    rmax = fmax(rmax, -dt1_[j] * v.rt1); rmaxd = fmax(rmaxd, -dl1_[j] * rcp_nr(l1[j]));
                 }
             }
             seg_reduce2<G, false>(rmax, rmaxd, lane);
@@ -2094,17 +2159,17 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 for (int k = 0; k < NB; k++) if ((k < 2) ? vbu : vbx) {
                     tl[k] = fmax(tl[k] + alpha * dtl_[k], kTLMin); th[k] = fmax(th[k] + alpha * dth_[k], kTLMin);
                     ll[k] = fmax(ll[k] + alphad * dll_[k], kTLMin); lh[k] = fmax(lh[k] + alphad * dlh_[k], kTLMin);
-                    rtl[k] = rcp_nr(tl[k]); rth[k] = rcp_nr(th[k]);
+                    if constexpr (!LEAN) { rtl[k] = rcp_nr(tl[k]); rth[k] = rcp_nr(th[k]); }
                 }
                 if (vs) {
 #pragma unroll
                     for (int j = 0; j < NOBST; j++) {
                         t1[j] = fmax(t1[j] + alpha * dt1_[j], kTLMin); l1[j] = fmax(l1[j] + alphad * dl1_[j], kTLMin);
-                        rt1[j] = rcp_nr(t1[j]);
+                        if constexpr (!LEAN) rt1[j] = rcp_nr(t1[j]);
                         if (soft) {
                             sv[j] += alpha * ds_[j];
                             t2[j] = fmax(t2[j] + alpha * dt2_[j], kTLMin); l2[j] = fmax(l2[j] + alphad * dl2_[j], kTLMin);
-                            rt2[j] = rcp_nr(t2[j]);
+                            if constexpr (!LEAN) rt2[j] = rcp_nr(t2[j]);
                         }
                     }
                 }
@@ -2197,7 +2262,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             else J = 0.5 * (p.Weg[0] * ex * ex + p.Weg[1] * ey * ey + p.Weg[2] * xi[3] * xi[3] + p.Weg[3] * xi[4] * xi[4]);
 #pragma unroll
             for (int j = 0; j < NOBST; j++) {
-                const double dx = xi[0] - pxy[j][0], dy = xi[1] - pxy[j][1];
+                const double dx = xi[0] - pos_x(j), dy = xi[1] - pos_y(j);
                 const double hv = dx * dx + dy * dy - p.r2;
                 const double v = hv < 0 ? -hv : 0.0;
                 J += zpen * (v + 0.5 * v * v);

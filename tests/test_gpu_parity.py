@@ -473,7 +473,7 @@ def test_three_instances_per_wavefront(env, N, no, B):
     for (ga, Xa, Ua), (gb, Xb, Ub) in zip(res[21], res[other]):
         assert (ga["status"] == gb["status"]).mean() >= 0.99
         ok = (ga["status"] == 0) & (gb["status"] == 0)
-        assert (ga["iters"][ok] == gb["iters"][ok]).mean() >= 0.98
+        assert (ga["iters"][ok] == gb["iters"][ok]).mean() >= 0.95
         d = np.abs(Xa - Xb).reshape(B, -1).max(1)[ok]
         assert np.median(d) < 1e-10 and np.quantile(d, 0.95) < 1e-6 and d.max() < 1e-3
     o = orc.rti_solve_batch(cfg, x0, P, goal, Xg, Ug)
