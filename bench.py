@@ -468,7 +468,12 @@ def main():
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))   # one explicit queue for torch ops AND the library's kernels
 
     import __graft_entry__ as g
-    g.build()
+    if world > 1:           # one rank (re)builds if anything is stale; the others wait and then only load
+        if rank == 0:
+            g.build()
+        dist.barrier()
+    else:
+        g.build()
     import mpc_gpu
     from mpc_gpu.sharding import gather_costs, shard_slice
 

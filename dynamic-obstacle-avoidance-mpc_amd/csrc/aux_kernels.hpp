@@ -74,6 +74,48 @@ __global__ void scenario_kernel(int count, int n_obst, int scenario, unsigned se
     for (int j = 0; j < n_obst; j++) o[j * 4 + 3] = uniform(-v_max, v_max);
 }
 
+// INSTANCE SCHEDULING.  Where several instances share a wavefront (one lane per stage: 2, 3 or 4 of them) the wavefront runs until its
+// slowest instance has converged, and interior-point iteration counts are heavy-tailed: on the randomized C3 workload the mean is 6.6 but the
+// mean of the per-wavefront maximum is 8.2 with two and 9.4 with three instances per wavefront.  Iteration counts of consecutive control
+// steps of one instance are strongly correlated, so dealing the instances to wavefronts IN THE ORDER OF THEIR PREVIOUS COUNT brings the
+// per-wavefront maximum down to 7.1 / 7.4 (scripts/iters_order_probe.py).  This kernel builds that order: a stable counting sort of the
+// instances by their last iteration count, descending (the longest-running wavefronts are dispatched first), by ONE workgroup --
+// thread t counts the keys of the instances e = t (mod T) in LDS column t of a [64 bins][T] table, the table is scanned in (bin, thread)
+// order, and every thread scatters its instances in the order it counted them: deterministic, O(batch), ~20 us at 65536.
+// order[] is a permutation of 0..batch-1; the solve kernel's slot s processes instance order[s].  Results are those of the natural
+// order (bit for bit with 2 or 4 instances per wavefront; to the rounding of the wavefront sums with 3).
+constexpr int kSchedThreads = 512, kSchedBins = 64;
+__global__ __launch_bounds__(kSchedThreads) void schedule_kernel(int batch, const int32_t *__restrict__ iters, int32_t *__restrict__ order)
+{
+    extern __shared__ unsigned sched_lds[];              // [kSchedBins][kSchedThreads] counts -> offsets, then [kSchedThreads] partial sums
+    unsigned *cnt = sched_lds, *part = sched_lds + kSchedBins * kSchedThreads;
+    const int t = threadIdx.x;
+    for (int f = t; f < kSchedBins * kSchedThreads; f += kSchedThreads) cnt[f] = 0u;
+    __syncthreads();
+    auto key_of = [&](int e) { const int it = iters[e]; return (kSchedBins - 1) - (it < 0 ? 0 : (it > kSchedBins - 1 ? kSchedBins - 1 : it)); };   // descending counts
+    for (int e = t; e < batch; e += kSchedThreads) cnt[key_of(e) * kSchedThreads + t] += 1u;
+    __syncthreads();
+    // exclusive scan of the flattened table: thread t owns the kSchedBins consecutive entries [t * kSchedBins, (t + 1) * kSchedBins)
+    unsigned sum = 0u;
+    for (int f = 0; f < kSchedBins; f++) sum += cnt[t * kSchedBins + f];
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < kSchedThreads; d <<= 1) {         // inclusive Hillis-Steele scan of the 512 partial sums
+        const unsigned v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    unsigned run = part[t] - sum;                        // exclusive prefix of this thread's first entry
+    for (int f = 0; f < kSchedBins; f++) { const unsigned c = cnt[t * kSchedBins + f]; cnt[t * kSchedBins + f] = run; run += c; }
+    __syncthreads();
+    for (int e = t; e < batch; e += kSchedThreads) {
+        const int k = key_of(e) * kSchedThreads + t;
+        order[cnt[k]] = e;
+        cnt[k] += 1u;
+    }
+}
+
 // Warm-start shift, robot_ocp_problem.py:253-258: X[j] <- X[j+1] (j < N), U[j] <- U[j+1] (j < N-1), U[N-1] <- 0.
 // One wavefront per instance; every lane reads its successor stage before anyone writes.
 __global__ __launch_bounds__(64) void shift_kernel(int batch, int N, double *__restrict__ X, double *__restrict__ U)

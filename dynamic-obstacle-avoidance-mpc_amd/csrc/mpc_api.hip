@@ -48,6 +48,9 @@ struct mpc_handle {
     int launch_count;
     double *d_trace;                  // optional debug trace buffer (mpc_debug_trace)
     int32_t *d_iters_acc, *d_status_acc;   // optional accumulators (mpc_set_accumulators)
+    int scheduling;                   // instance scheduling for the mappings that pack several instances into a wavefront (mpc_set_instance_scheduling)
+    int32_t *d_order, *d_iters_sched; // ... the order for the next launch, and the iteration counts it is built from when the caller asks for none
+    int order_batch;                  // batch size d_order is a permutation of (0 = none yet)
     double *d_alpha_own;              // handle-owned copy of a host slack schedule (mpc_set_slack_schedule)
     const double *d_alpha;            // slack schedule in effect: d_alpha_own, a caller's device array, or null (the reference's formula)
     std::vector<hipEvent_t> ev_start, ev_stop;
@@ -232,10 +235,9 @@ int launch_one_lane_g(mpc_handle *h, const mpc::KParams &p, hipStream_t s, dim3 
     return fail(MPC_ERR_ARG, "no kernel variant for this lane mapping (three instances per wavefront need the row-parallel sweeps)");
 }
 
-// picks the lane mapping and launches; no event handling here
-int dispatch_solve(mpc_handle *h, const mpc::KParams &p, hipStream_t s)
+// launches the variant the plan names; no event handling here
+int dispatch_solve(mpc_handle *h, const mpc::KParams &p, hipStream_t s, const SolvePlan &q)
 {
-    const SolvePlan q = plan_solve(h, p.batch, p.obst != nullptr);
     int rc = MPC_OK;
     if (q.lps > 1) {
         switch (h->cfg.n_obst * 10 + q.lps) {
@@ -281,9 +283,22 @@ int create_resources(mpc_handle *h)
     HIPCHK(hipMalloc(&h->d_xb, B * 5 * sizeof(double)));
     HIPCHK(hipMalloc(&h->d_status, B * sizeof(int32_t)));
     HIPCHK(hipMalloc(&h->d_iters, B * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&h->d_order, B * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&h->d_iters_sched, B * sizeof(int32_t)));
+    HIPCHK(hipMemsetAsync(h->d_iters_sched, 0, B * sizeof(int32_t), h->stream));
     HIPCHK(hipMemsetAsync(h->dX, 0, B * (N + 1) * 5 * sizeof(double), h->stream));
     HIPCHK(hipMemsetAsync(h->dU, 0, B * N * 2 * sizeof(double), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return MPC_OK;
+}
+
+int launch_schedule(mpc_handle *h, int batch, const int32_t *d_iters, hipStream_t s)
+{
+    static int granted[kMaxDevices] = {};
+    const size_t lds = (size_t)(mpc::kSchedBins * mpc::kSchedThreads + mpc::kSchedThreads) * sizeof(unsigned);
+    int rc = grant_lds(&mpc::schedule_kernel, granted, h->device, lds); if (rc) return rc;
+    hipLaunchKernelGGL(mpc::schedule_kernel, dim3(1), dim3(mpc::kSchedThreads), lds, s, batch, d_iters, h->d_order);
+    HIPCHK(hipGetLastError());
     return MPC_OK;
 }
 
@@ -291,15 +306,27 @@ int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
 {
     p.iters_acc = h->d_iters_acc; p.status_acc = h->d_status_acc;
     p.alpha = h->d_alpha;
+    const SolvePlan q = plan_solve(h, p.batch, p.obst != nullptr);
+    // Instance scheduling (aux_kernels.hpp::schedule_kernel): the mappings that pack several instances into a wavefront deal them out in
+    // the order of their iteration counts in this handle's previous launch of the same batch size; the order for the NEXT launch is
+    // rebuilt behind this one, on the same stream.  A batch of at most one wavefront per SIMD has nothing to gain from it.
+    const bool sched = h->scheduling && q.lps == 1 && q.G < 64 && p.batch > h->simd_count;
+    p.order = (sched && h->order_batch == p.batch) ? h->d_order : nullptr;
+    if (sched && !p.iters) p.iters = h->d_iters_sched;
     // profiling: a start / stop event pair from the pool (created by mpc_profile_enable, never here) around every k-th launch; the pair
     // counts only when both records and the launch between them succeeded
     const bool timed = h->profiling && (h->launch_count++ % h->profiling) == 0 && h->ev_used < (int)h->ev_start.size();
     if (timed) HIPCHK(hipEventRecord(h->ev_start[h->ev_used], s));
-    int rc = dispatch_solve(h, p, s);
+    int rc = dispatch_solve(h, p, s, q);
     if (rc) return rc;
     if (timed) {
         HIPCHK(hipEventRecord(h->ev_stop[h->ev_used], s));
         h->ev_used++;
+    }
+    if (sched) {
+        h->order_batch = 0;
+        rc = launch_schedule(h, p.batch, p.iters, s); if (rc) return rc;
+        h->order_batch = p.batch;
     }
     return MPC_OK;
 }
@@ -353,7 +380,7 @@ int mpc_create(const mpc_config *cfg, int device, int max_batch, mpc_handle **ou
     HIPCHK(hipSetDevice(device));
     mpc_handle *h = new mpc_handle();     // value-initialised: every pointer null, so mpc_destroy can release a half-built handle
     h->cfg = *cfg; h->device = device; h->max_batch = max_batch;
-    h->row_parallel = 1;
+    h->row_parallel = 1; h->scheduling = 1;
     int rc = create_resources(h);
     if (rc) { mpc_destroy(h); return rc; }     // (mpc_destroy leaves g_err alone when nothing fails inside it)
     *out = h;
@@ -366,7 +393,7 @@ int mpc_destroy(mpc_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *bufs[] = {h->dX, h->dU, h->d_x0, h->d_P, h->d_goal, h->d_obst, h->d_u0, h->d_cost, h->d_xa, h->d_ua, h->d_xb, h->d_status, h->d_iters,
-                    h->d_trace, h->d_alpha_own};
+                    h->d_trace, h->d_alpha_own, h->d_order, h->d_iters_sched};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (auto e : h->ev_start) (void)hipEventDestroy(e);
     for (auto e : h->ev_stop) (void)hipEventDestroy(e);
@@ -757,6 +784,25 @@ int mpc_get_lanes_per_stage(mpc_handle *h, int batch)
 {
     if (!h) return fail(MPC_ERR_ARG, "null handle");
     return pick_split(h, batch);
+}
+
+int mpc_set_instance_scheduling(mpc_handle *h, int on)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    h->scheduling = on ? 1 : 0;
+    h->order_batch = 0;
+    return MPC_OK;
+}
+
+int mpc_get_instance_order(mpc_handle *h, int batch, int32_t *order)
+{
+    int rc = check_batch(h, batch); if (rc) return rc;
+    if (!order) return fail(MPC_ERR_ARG, "null pointer");
+    if (h->order_batch != batch) return 0;          // no order in effect for this batch size: natural order
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(order, h->d_order, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 1;
 }
 
 int mpc_get_kernel_name(mpc_handle *h, int batch, int lookahead, char *buf, int len)

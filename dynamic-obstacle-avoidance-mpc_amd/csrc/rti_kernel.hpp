@@ -69,6 +69,7 @@ struct KParams {
     const double *alpha;      // optional [B][N+1]: explicit slack weights zl_i = Zl_i (mpc_set_slack_schedule); null = the schedule of robot_ocp_problem.py:145-148
     double *X, *U, *u0, *cost;
     int32_t *status, *iters;
+    const int32_t *order;     // optional instance order (aux_kernels.hpp::schedule_kernel): wavefront slot s of the one-lane kernels processes instance order[s]
     int32_t *iters_acc, *status_acc;   // optional running sums over launches: IPM iterations; (status == 4) + 65536 * (status == 2)
     // ---- fused closed-loop step (all optional; see mpc_closed_loop_step_dev) ----
     const double *obst;       // [B][n_obst][4]: if set, the look-ahead P is computed in the kernel and p.P is ignored
@@ -1459,7 +1460,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     const int slot = (G == 21) ? seg21_slot(lane) : lane / G;
     const int inst_raw = blockIdx.x * IPW + slot;
     const bool valid = inst_raw < p.batch;    // tail wavefront: surplus slots replay the last instance and store nothing
-    const int inst = valid ? inst_raw : p.batch - 1;
+    const int sidx = valid ? inst_raw : p.batch - 1;
+    const int inst = p.order ? p.order[sidx] : sidx;      // instance scheduling: which instance this slot works on
     const int N = p.N;
     const int i = lane - slot * G;            // this lane's stage
     const bool act = (i <= N);

@@ -72,6 +72,8 @@ SYMBOLS = {
     "mpc_set_lanes_per_stage": (C.c_int, [_vp, C.c_int]),
     "mpc_get_lanes_per_stage": (C.c_int, [_vp, C.c_int]),
     "mpc_get_kernel_name": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p, C.c_int]),
+    "mpc_set_instance_scheduling": (C.c_int, [_vp, C.c_int]),
+    "mpc_get_instance_order": (C.c_int, [_vp, C.c_int, _vp]),
     "mpc_set_waves_per_simd": (C.c_int, [_vp, C.c_int]),
     "mpc_get_waves_per_simd": (C.c_int, [_vp, C.c_int]),
     "mpc_set_matrix_cores": (C.c_int, [_vp, C.c_int]),

@@ -237,6 +237,18 @@ class BatchedMpc:
         _lib.check(_lib.lib().mpc_get_kernel_name(self._h, batch, 1 if lookahead else 0, buf, 96))
         return buf.value.decode()
 
+    def set_instance_scheduling(self, on=True):
+        """deal instances to wavefronts in the order of their previous iteration counts (mappings with several instances per wavefront)"""
+        _lib.check(_lib.lib().mpc_set_instance_scheduling(self._h, 1 if on else 0))
+
+    def instance_order(self, batch):
+        """the permutation in effect for the next launch of `batch` instances, or None for the natural order"""
+        order = np.empty(batch, np.int32)
+        rc = _lib.lib().mpc_get_instance_order(self._h, batch, _ptr(order))
+        if rc < 0:
+            _lib.check(rc)
+        return order if rc == 1 else None
+
     def set_waves_per_simd(self, waves):
         """stage-split mapping: 0 automatic, 1 one wavefront per SIMD (512 registers), 2 two (256 registers, compact LDS blocks)"""
         _lib.check(_lib.lib().mpc_set_waves_per_simd(self._h, int(waves)))

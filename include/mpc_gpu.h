@@ -206,6 +206,15 @@ int mpc_get_lanes_per_stage(mpc_handle *h, int batch);
  * per wavefront at N = 20, eight wavefronts per CU) for deeper batches, where a second resident wavefront fills the LDS and
  * dependent-issue stalls of the first.  1 / 2: forced.  The one-lane-per-stage mapping always runs one wavefront per SIMD (449 registers).
  * Same arithmetic specification either way.  No reference counterpart (tuning / test hook). */
+/* Instance scheduling (default on).  Where several instances share a wavefront (one lane per stage: 2, 3 or 4 of them) the wavefront runs
+ * until its slowest instance has converged; iteration counts are heavy-tailed (C3: mean 6.6, mean of the per-wavefront maximum 9.4 with
+ * three per wavefront) but strongly correlated between consecutive control steps of an instance.  The library therefore deals the instances
+ * to wavefronts in the order of their iteration counts in this handle's previous launch of the same batch size (a stable counting sort on
+ * the device behind every launch; 7.4 instead of 9.4).  Which instances share a wavefront has no effect on their results beyond the
+ * rounding of the wavefront sums with three instances per wavefront (bit-identical with two or four).  No reference counterpart.
+ * mpc_get_instance_order: the permutation in effect for the next launch of `batch` instances (returns 1) or 0 when it is the natural order. */
+int mpc_set_instance_scheduling(mpc_handle *h, int on);
+int mpc_get_instance_order(mpc_handle *h, int batch, int32_t *order);
 /* name of the solve kernel instantiation a batch of this size runs (as rocprofv3 prints it, without the namespace), for measurement
  * records: "rti_split_kernel<n_obst, lanes per stage, two wavefronts per SIMD>" or "rti_solve_kernel<n_obst, lanes per instance, sweeps>"
  * (sweeps: 0 systolic, 1 matrix cores, 2 row-parallel on dense LDS blocks, 3 row-parallel on compact LDS blocks).  lookahead: whether the

@@ -526,3 +526,46 @@ def test_full_size_batches_c3_and_c4_share(env, B):
         fg, eqg, bg = qp_merit(orc, cfg, x0[b], P[k], goal[b], Xs[b], Us[b], X1[b], U1[b])
         fo, _, _ = qp_merit(orc, cfg, x0[b], P[k], goal[b], Xs[b], Us[b], o["X"][k], o["U"][k])
         assert eqg <= 1e-7 and bg <= 1e-7 and fg <= fo + 1e-7 * max(1.0, abs(fo)), (b, fg, fo)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G", [32, 21, 16])
+def test_instance_scheduling(env, G):
+    """instances are dealt to wavefronts in the order of their previous iteration counts (schedule_kernel: stable counting sort on the device):
+    the order is a permutation, sorted by the last counts (descending), and the results are those of the natural order -- bit for bit with two
+    or four instances per wavefront, to rounding with three -- over four closed-loop steps; a batch of at most one wavefront per SIMD and a
+    changed batch size fall back to the natural order"""
+    mpc_gpu, orc = env
+    N, no, B = (20, 3, 5003) if G != 16 else (10, 3, 6001)
+    x0, goal, obst = random_batch(B, no, seed=2024 + G)
+    res = {}
+    for on in (1, 0):
+        with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
+            s.set_lanes_per_stage(1); s.set_lanes_per_instance(G); s.set_instance_scheduling(bool(on))
+            assert s.instance_order(B) is None
+            s.reset_guess(x0); outs = []
+            xk = x0.copy()
+            for k in range(4):
+                g = s.solve(xk, obst, goal); X, U = s.get_traj(B)
+                order = s.instance_order(B)
+                if on:
+                    assert order is not None and np.array_equal(np.sort(order), np.arange(B))          # a permutation
+                    assert (np.diff(np.minimum(g["iters"][order], 63)) <= 0).all()                        # by the last counts, descending
+                    assert len(set(g["iters"].tolist())) > 4
+                else:
+                    assert order is None
+                outs.append((g, X, U))
+                xk = s.plant_step(xk, g["u0"]); s.shift(B)
+            if on:
+                assert s.instance_order(B - 1) is None                  # another batch size: no order yet
+                g = s.solve(xk[:900], obst[:900], goal[:900])            # at most one wavefront per SIMD: never scheduled
+                assert s.instance_order(900) is None
+            res[on] = outs
+    for (ga, Xa, Ua), (gb, Xb, Ub) in zip(res[1], res[0]):
+        if G != 21:
+            assert np.array_equal(Xa, Xb) and np.array_equal(Ua, Ub) and np.array_equal(ga["iters"], gb["iters"]) and np.array_equal(ga["cost"], gb["cost"])
+        else:
+            same = ga["status"] == gb["status"]
+            assert same.mean() > 0.999
+            d = np.abs(Xa - Xb).reshape(B, -1).max(1)[same & (gb["status"] == 0)]
+            assert np.median(d) < 1e-11 and np.quantile(d, 0.999) < 1e-5
