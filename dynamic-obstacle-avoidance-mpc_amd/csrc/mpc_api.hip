@@ -111,33 +111,37 @@ int pick_lanes(mpc_handle *h, int batch)
     // batches of up to one instance per SIMD (1024 on MI355X), beyond that packing instances per wavefront wins
     if (batch <= 1024 && h->use_mfma) G = 64;
     if (h->lanes_override == 21) return 21;       // three instances per wavefront (N <= 20, row-parallel sweeps)
-    // automatic: 17 <= N + 2 <= 22 (two instances per wavefront otherwise) with 3 obstacles, batches of more than 12 instances per SIMD
-    if (!h->lanes_override && !h->use_mfma && h->row_parallel && h->cfg.n_obst == 3 && need > 16 && h->cfg.N <= 20 && batch > 12 * h->simd_count) return 21;
+    // automatic: 17 <= N + 2 <= 22 (two instances per wavefront otherwise) with 3 or 5 obstacles, whenever pick_split leaves such a batch
+    // to this mapping (more than 8 resp. 12 instances per SIMD)
+    if (!h->lanes_override && !h->use_mfma && h->row_parallel && h->cfg.n_obst != 10 && need > 16 && h->cfg.N <= 20 && batch > 8 * h->simd_count) return 21;
     if (h->lanes_override >= G || (h->lanes_override && h->lanes_override >= need)) G = h->lanes_override;
     return G;
 }
 
-// Which lane mapping runs a batch (measured on MI355X, randomized C3-style workloads, scripts/w2_probe.py -> profiles/r02_w2_probe_*.json;
-// M solves/s at a batch of 65536, split 1 wavefront/SIMD | split 2 wavefronts/SIMD | one lane per stage):
-//     N = 20,  3 obstacles: 10.5 | 13.3 | 12.6        N = 20,  5 obstacles: 8.8 | 9.0 | 8.7        N = 20, 10 obstacles: 6.2 | 4.4 | 3.0
-//     N = 31,  3 obstacles:  5.0 |  6.2 |  5.7        N = 10,  3 obstacles: 16.0 | 19.9 | 26.4      N = 10,  5 obstacles: 13.4 | 12.4 | 14.0
-//   and, N = 20 with 3 obstacles, THREE instances per wavefront on compact LDS blocks (one lane per stage, G = 21): 14.8 (10.9 at 16384 against
-//   10.6 for the two-wavefront split variant, 8.0 against 8.5 at 8192)
-// * the stage-split mapping (rows of a stage over 3 lanes for N <= 20, 2 for N <= 31, one instance per wavefront; rti_split_kernel.hpp)
-//   wins wherever the horizon fits it, at every batch size, with one exception: 3 obstacles and N + 2 <= 16, where the one-lane mapping packs
-//   FOUR instances into a wavefront and overtakes beyond ~8 instances per SIMD;
-// * with 5 or 10 obstacles the one-lane mapping's row state no longer fits the register file (44 - 790 bytes of scratch per lane), which the
-//   split mapping avoids -- 2.1x at 10 obstacles;
-// * two wavefronts per SIMD (256 registers, compact LDS blocks) pay for 3 obstacles once the batch is more than ~4 instances per SIMD deep
-//   (+26 % over one wavefront at 65536); with more obstacles the 256-register build spills 500 - 1150 bytes per lane and loses.
+// Which lane mapping runs a batch (measured on MI355X, randomized C3-style workloads, closed loop, instance scheduling on;
+// scripts/w2_probe.py -> profiles/r02_w2_probe_*.json; 10^6 solves/s: split 1 wavefront/SIMD | split 2 wavefronts/SIMD | one lane per stage
+// with 2 (N = 20) or 4 (N = 10) instances per wavefront | with 3 instances per wavefront):
+//                          batch 4096                  8192                       16384                      65536
+//   N = 20,  3 obstacles:  7.0 | 6.1 | 5.5 | 5.4      9.7 | 10.1 |  9.8 |  9.7    10.6 | 12.6 | 16.0 | 16.0   11.3 | 14.0 | 20.7 | 20.7
+//   N = 20,  5 obstacles:  6.1 | 4.7 | 4.3 | 4.2      8.0 |  7.2 |  7.4 |  7.7     8.7 |  8.7 |  9.4 | 11.3    9.2 |  9.5 | 10.7 | 14.2
+//   N = 20, 10 obstacles:  4.7 | 2.7 | 2.4 | 2.6      5.7 |  3.7 |  3.1 |  3.9     6.1 |  4.2 |  3.5 |  4.6    6.5 |  4.6 |  3.8 |  5.3
+//   N = 31,  3 obstacles:  4.2 | 3.4 | 4.0 |  -       4.9 |  5.2 |  5.2 |  -       5.1 |  6.0 |  5.7 |  -      5.4 |  6.6 |  6.1 |  -
+//   N = 10,  3 obstacles:  9.9 | 8.4 | 6.9 | 6.6     14.5 | 13.8 | 12.5 | 11.8    15.9 | 19.0 | 22.6 | 21.1   16.9 | 21.0 | 37.0 | 28.7
+//   N = 10,  5 obstacles:  8.5 | 6.0 | 5.2 | 4.8     12.1 |  9.4 |  9.6 |  9.1    13.2 | 12.0 | 15.2 | 14.8   14.0 | 13.0 | 19.6 | 19.6
+// * the stage-split mapping (rows of a stage over 3 lanes for N <= 20, 2 for N <= 31, one instance per wavefront; rti_split_kernel.hpp) wins
+//   up to ~8 instances per SIMD everywhere, and at every batch size with 10 obstacles (the one-lane row state spills) and for 20 < N <= 31;
+// * beyond that the one-lane mappings that pack 3 (17 <= N + 2 <= 22) or 4 (N + 2 <= 16) instances into a wavefront win for 3 and 5
+//   obstacles -- since instance scheduling (launch_solve) their wavefronts hold instances that stop together;
+// * two wavefronts per SIMD (256 registers, compact LDS blocks) pay for 3 obstacles between ~4 and ~8 instances per SIMD and for
+//   20 < N <= 31 beyond; with more obstacles the 256-register build spills 500 - 1150 bytes per lane and loses.
 int pick_split(mpc_handle *h, int batch)
 {
     if (h->use_mfma || !h->row_parallel || h->lanes_override) return 1;
-    const int N = h->cfg.N;
+    const int N = h->cfg.N, no = h->cfg.n_obst;
     const int fit = N <= 20 ? 3 : (N <= 31 ? 2 : 1);
     if (h->split_override) return h->split_override <= fit ? h->split_override : fit;
-    if (h->cfg.n_obst == 3 && N + 2 <= 16 && batch > 8 * h->simd_count) return 1;      // four instances per wavefront
-    if (h->cfg.n_obst == 3 && N <= 20 && batch > 12 * h->simd_count) return 1;          // three instances per wavefront (G = 21)
+    if (no != 10 && N + 2 <= 16 && batch > 12 * h->simd_count) return 1;                      // four instances per wavefront (G = 16)
+    if (no != 10 && N + 2 > 16 && N <= 20 && batch > (no == 3 ? 8 : 12) * h->simd_count) return 1;   // three instances per wavefront (G = 21)
     return fit;
 }
 
@@ -307,10 +311,11 @@ int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
     p.iters_acc = h->d_iters_acc; p.status_acc = h->d_status_acc;
     p.alpha = h->d_alpha;
     const SolvePlan q = plan_solve(h, p.batch, p.obst != nullptr);
-    // Instance scheduling (aux_kernels.hpp::schedule_kernel): the mappings that pack several instances into a wavefront deal them out in
-    // the order of their iteration counts in this handle's previous launch of the same batch size; the order for the NEXT launch is
-    // rebuilt behind this one, on the same stream.  A batch of at most one wavefront per SIMD has nothing to gain from it.
-    const bool sched = h->scheduling && q.lps == 1 && q.G < 64 && p.batch > h->simd_count;
+    // Instance scheduling (aux_kernels.hpp::schedule_kernel): wavefront slots are dealt the instances in the order of their iteration counts
+    // in this handle's previous launch of the same batch size, longest first -- instances that share a wavefront then stop together, and
+    // the rare 50-iteration instance starts in the first round of wavefronts instead of stretching the last one; the order for the NEXT
+    // launch is rebuilt behind this one, on the same stream.  A batch of at most one wavefront per SIMD has nothing to gain from it.
+    const bool sched = h->scheduling && p.batch > h->simd_count;
     p.order = (sched && h->order_batch == p.batch) ? h->d_order : nullptr;
     if (sched && !p.iters) p.iters = h->d_iters_sched;
     // profiling: a start / stop event pair from the pool (created by mpc_profile_enable, never here) around every k-th launch; the pair

@@ -62,7 +62,7 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
     constexpr int NBL = SL::NBL, NSL = SL::NSL;
     constexpr int kKK = 45;                   // free words 45, 46 of a stage block (RowVec uses 0..44, dead-store words start at RowLds::TAIL)
     const int lane = threadIdx.x;
-    const int inst = blockIdx.x;              // grid = batch: one instance per wavefront
+    const int inst = p.order ? p.order[blockIdx.x] : (int)blockIdx.x;     // grid = batch: one instance per wavefront; instance scheduling: longest-running first
     const int N = p.N;
     const int i = lane / LPS;                 // this lane's stage
     const int h = lane - i * LPS;             // ... and its part of the stage's rows

@@ -402,17 +402,22 @@ def test_automatic_lane_mapping(env):
         from mpc_gpu import _lib
         with mpc_gpu.BatchedMpc(20, 3, 2.0, max_batch=70000) as s:
             assert s.lanes_per_stage(1) == 3 and s.lanes_per_stage(1024) == 3 and s.lanes_per_instance(1024) == 64
-            assert s.lanes_per_stage(12288) == 3 and s.waves_per_simd(4096) == 1 and s.waves_per_simd(4097) == 2 and s.waves_per_simd(12288) == 2
-            assert s.lanes_per_stage(12289) == 1 and s.lanes_per_instance(12289) == 21 and s.lanes_per_instance(65536) == 21     # three per wavefront
+            assert s.lanes_per_stage(8192) == 3 and s.waves_per_simd(4096) == 1 and s.waves_per_simd(4097) == 2 and s.waves_per_simd(8192) == 2
+            assert s.lanes_per_stage(8193) == 1 and s.lanes_per_instance(8193) == 21 and s.lanes_per_instance(65536) == 21     # three per wavefront
+            assert s.kernel_name(65536) == "rti_solve_kernel<3, 21, 3>" and s.kernel_name(1024) == "rti_split_kernel<3, 3, false>"
             s.set_waves_per_simd(1)
             assert s.waves_per_simd(8192) == 1
             assert _lib.lib().mpc_set_waves_per_simd(s._h, 3) == _lib.MPC_ERR_ARG
             s.set_lanes_per_instance(64)
             assert s.lanes_per_stage(8) == 1 and s.waves_per_simd(65536) == 1 and s.lanes_per_instance(65536) == 64
+        with mpc_gpu.BatchedMpc(20, 5, 2.0, max_batch=70000) as s:
+            assert s.lanes_per_stage(12288) == 3 and s.waves_per_simd(12288) == 1 and s.lanes_per_instance(12289) == 21
         with mpc_gpu.BatchedMpc(20, 10, 2.0, max_batch=70000) as s:
             assert s.lanes_per_stage(65536) == 3 and s.waves_per_simd(65536) == 1           # 10 obstacles: never the 256-register build
         with mpc_gpu.BatchedMpc(10, 3, 1.0, max_batch=70000) as s:
-            assert s.lanes_per_stage(8192) == 3 and s.lanes_per_stage(8193) == 1 and s.lanes_per_instance(65536) == 16
+            assert s.lanes_per_stage(12288) == 3 and s.lanes_per_stage(12289) == 1 and s.lanes_per_instance(65536) == 16
+        with mpc_gpu.BatchedMpc(50, 10, 5.0, max_batch=8) as s:
+            assert s.kernel_name(8) == "rti_solve_kernel<10, 64, 3>"                        # long horizon: compact LDS stage blocks
         with mpc_gpu.BatchedMpc(31, 3, 3.1, max_batch=8) as s:
             assert s.lanes_per_stage(8) == 2
         with mpc_gpu.BatchedMpc(32, 3, 3.2, max_batch=8) as s:
@@ -529,11 +534,11 @@ def test_full_size_batches_c3_and_c4_share(env, B):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("G", [32, 21, 16])
+@pytest.mark.parametrize("G", [32, 21, 16, 0])
 def test_instance_scheduling(env, G):
     """instances are dealt to wavefronts in the order of their previous iteration counts (schedule_kernel: stable counting sort on the device):
-    the order is a permutation, sorted by the last counts (descending), and the results are those of the natural order -- bit for bit with two
-    or four instances per wavefront, to rounding with three -- over four closed-loop steps; a batch of at most one wavefront per SIMD and a
+    the order is a permutation, sorted by the last counts (descending), and the results are those of the natural order -- bit for bit with one,
+    two or four instances per wavefront, to rounding with three -- over four closed-loop steps; a batch of at most one wavefront per SIMD and a
     changed batch size fall back to the natural order"""
     mpc_gpu, orc = env
     N, no, B = (20, 3, 5003) if G != 16 else (10, 3, 6001)
@@ -541,7 +546,11 @@ def test_instance_scheduling(env, G):
     res = {}
     for on in (1, 0):
         with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
-            s.set_lanes_per_stage(1); s.set_lanes_per_instance(G); s.set_instance_scheduling(bool(on))
+            if G:
+                s.set_lanes_per_stage(1); s.set_lanes_per_instance(G)
+            else:
+                s.set_lanes_per_stage(3)                                # G = 0: the stage-split mapping (one instance per wavefront: longest first)
+            s.set_instance_scheduling(bool(on))
             assert s.instance_order(B) is None
             s.reset_guess(x0); outs = []
             xk = x0.copy()
