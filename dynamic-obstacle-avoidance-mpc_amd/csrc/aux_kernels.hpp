@@ -78,41 +78,82 @@ __global__ void scenario_kernel(int count, int n_obst, int scenario, unsigned se
 // slowest instance has converged, and interior-point iteration counts are heavy-tailed: on the randomized C3 workload the mean is 6.6 but the
 // mean of the per-wavefront maximum is 8.2 with two and 9.4 with three instances per wavefront.  Iteration counts of consecutive control
 // steps of one instance are strongly correlated, so dealing the instances to wavefronts IN THE ORDER OF THEIR PREVIOUS COUNT brings the
-// per-wavefront maximum down to 7.1 / 7.4 (scripts/iters_order_probe.py).  This kernel builds that order: a stable counting sort of the
-// instances by their last iteration count, descending (the longest-running wavefronts are dispatched first), by ONE workgroup --
-// thread t counts the keys of the instances e = t (mod T) in LDS column t of a [64 bins][T] table, the table is scanned in (bin, thread)
-// order, and every thread scatters its instances in the order it counted them: deterministic, O(batch), ~20 us at 65536.
+// per-wavefront maximum down to 7.1 / 7.4 (scripts/iters_order_probe.py).  These kernels build that order: a stable counting sort of the
+// instances by their last iteration count, descending (the longest-running wavefronts are dispatched first): deterministic, O(batch),
+// ~10 us at 65536.
 // order[] is a permutation of 0..batch-1; the solve kernel's slot s processes instance order[s].  Results are those of the natural
 // order (bit for bit with 2 or 4 instances per wavefront; to the rounding of the wavefront sums with 3).
-constexpr int kSchedThreads = 512, kSchedBins = 64;
-__global__ __launch_bounds__(kSchedThreads) void schedule_kernel(int batch, const int32_t *__restrict__ iters, int32_t *__restrict__ order)
+// Two launches: schedule_count_kernel (one histogram per block of kSchedChunk consecutive instances) and schedule_scatter_kernel (every block
+// derives its global base per bin from all histograms, ranks its own instances stably and writes their slots).
+constexpr int kSchedThreads = 256, kSchedBins = 32, kSchedPer = 4, kSchedChunk = kSchedThreads * kSchedPer;   // counts >= 31 share the first bin
+__device__ __forceinline__ int sched_key(int it) { return (kSchedBins - 1) - (it < 0 ? 0 : (it > kSchedBins - 1 ? kSchedBins - 1 : it)); }   // descending counts
+
+__global__ __launch_bounds__(kSchedThreads) void schedule_count_kernel(int batch, int nblk, const int32_t *__restrict__ iters, unsigned *__restrict__ ghist)
 {
-    extern __shared__ unsigned sched_lds[];              // [kSchedBins][kSchedThreads] counts -> offsets, then [kSchedThreads] partial sums
-    unsigned *cnt = sched_lds, *part = sched_lds + kSchedBins * kSchedThreads;
-    const int t = threadIdx.x;
+    __shared__ unsigned hist[kSchedBins];
+    const int t = threadIdx.x, b = blockIdx.x;
+    if (t < kSchedBins) hist[t] = 0u;
+    __syncthreads();
+    const int e0 = b * kSchedChunk + t * kSchedPer;
+#pragma unroll
+    for (int u = 0; u < kSchedPer; u++)
+        if (e0 + u < batch) __hip_atomic_fetch_add(&hist[sched_key(iters[e0 + u])], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    if (t < kSchedBins) ghist[t * nblk + b] = hist[t];          // bin-major: the scatter pass reads a bin's blocks consecutively
+}
+
+__global__ __launch_bounds__(kSchedThreads) void schedule_scatter_kernel(int batch, int nblk, const int32_t *__restrict__ iters,
+                                                                         const unsigned *__restrict__ ghist, int32_t *__restrict__ order)
+{
+    __shared__ unsigned cnt[kSchedBins * kSchedThreads];      // [bin][thread]: counts, then exclusive offsets in (bin, thread) order
+    __shared__ unsigned part[kSchedThreads], tot[kSchedBins], pre[kSchedBins], base[kSchedBins], row0[kSchedBins];
+    const int t = threadIdx.x, b = blockIdx.x;
     for (int f = t; f < kSchedBins * kSchedThreads; f += kSchedThreads) cnt[f] = 0u;
+    if (t < kSchedBins) { tot[t] = 0u; pre[t] = 0u; }
     __syncthreads();
-    auto key_of = [&](int e) { const int it = iters[e]; return (kSchedBins - 1) - (it < 0 ? 0 : (it > kSchedBins - 1 ? kSchedBins - 1 : it)); };   // descending counts
-    for (int e = t; e < batch; e += kSchedThreads) cnt[key_of(e) * kSchedThreads + t] += 1u;
+    // (a) where this block's instances of every bin start: everything in earlier bins, plus the same bin in earlier blocks
+    for (int f = t; f < kSchedBins * nblk; f += kSchedThreads) {
+        const int bin = f / nblk, blk = f - bin * nblk;
+        const unsigned v = ghist[f];
+        if (v) {
+            __hip_atomic_fetch_add(&tot[bin], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (blk < b) __hip_atomic_fetch_add(&pre[bin], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    // (b) this block's own instances: thread t owns kSchedPer consecutive ones, counted in column t
+    const int e0 = b * kSchedChunk + t * kSchedPer;
+    int key[kSchedPer];
+#pragma unroll
+    for (int u = 0; u < kSchedPer; u++) {
+        key[u] = (e0 + u < batch) ? sched_key(iters[e0 + u]) : -1;
+        if (key[u] >= 0) cnt[key[u] * kSchedThreads + t] += 1u;
+    }
     __syncthreads();
-    // exclusive scan of the flattened table: thread t owns the kSchedBins consecutive entries [t * kSchedBins, (t + 1) * kSchedBins)
+    if (t == 0) { unsigned run = 0u; for (int k = 0; k < kSchedBins; k++) { base[k] = run + pre[k]; run += tot[k]; } }
+    // exclusive scan of cnt in (bin, thread) order: thread t owns the kSchedBins consecutive entries [t * kSchedBins, (t + 1) * kSchedBins)
     unsigned sum = 0u;
     for (int f = 0; f < kSchedBins; f++) sum += cnt[t * kSchedBins + f];
     part[t] = sum;
     __syncthreads();
-    for (int d = 1; d < kSchedThreads; d <<= 1) {         // inclusive Hillis-Steele scan of the 512 partial sums
+    for (int d = 1; d < kSchedThreads; d <<= 1) {
         const unsigned v = t >= d ? part[t - d] : 0u;
         __syncthreads();
         part[t] += v;
         __syncthreads();
     }
-    unsigned run = part[t] - sum;                        // exclusive prefix of this thread's first entry
+    unsigned run = part[t] - sum;
     for (int f = 0; f < kSchedBins; f++) { const unsigned c = cnt[t * kSchedBins + f]; cnt[t * kSchedBins + f] = run; run += c; }
     __syncthreads();
-    for (int e = t; e < batch; e += kSchedThreads) {
-        const int k = key_of(e) * kSchedThreads + t;
-        order[cnt[k]] = e;
-        cnt[k] += 1u;
+    if (t < kSchedBins) row0[t] = cnt[t * kSchedThreads];     // offset of the bin's first instance inside this block
+    __syncthreads();
+    // (c) slots: bins in descending-count order, inside a bin ascending instance index (blocks, threads, a thread's own instances in order)
+#pragma unroll
+    for (int u = 0; u < kSchedPer; u++) {
+        if (key[u] >= 0) {
+            const int k = key[u] * kSchedThreads + t;
+            order[base[key[u]] + (cnt[k] - row0[key[u]])] = e0 + u;
+            cnt[k] += 1u;
+        }
     }
 }
 

@@ -50,6 +50,7 @@ struct mpc_handle {
     int32_t *d_iters_acc, *d_status_acc;   // optional accumulators (mpc_set_accumulators)
     int scheduling;                   // instance scheduling for the mappings that pack several instances into a wavefront (mpc_set_instance_scheduling)
     int32_t *d_order, *d_iters_sched; // ... the order for the next launch, and the iteration counts it is built from when the caller asks for none
+    unsigned *d_sched_hist;           // ... per-block histograms of the counting sort [bins][blocks]
     int order_batch;                  // batch size d_order is a permutation of (0 = none yet)
     double *d_alpha_own;              // handle-owned copy of a host slack schedule (mpc_set_slack_schedule)
     const double *d_alpha;            // slack schedule in effect: d_alpha_own, a caller's device array, or null (the reference's formula)
@@ -289,6 +290,7 @@ int create_resources(mpc_handle *h)
     HIPCHK(hipMalloc(&h->d_iters, B * sizeof(int32_t)));
     HIPCHK(hipMalloc(&h->d_order, B * sizeof(int32_t)));
     HIPCHK(hipMalloc(&h->d_iters_sched, B * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&h->d_sched_hist, (size_t)mpc::kSchedBins * ((B + mpc::kSchedChunk - 1) / mpc::kSchedChunk) * sizeof(unsigned)));
     HIPCHK(hipMemsetAsync(h->d_iters_sched, 0, B * sizeof(int32_t), h->stream));
     HIPCHK(hipMemsetAsync(h->dX, 0, B * (N + 1) * 5 * sizeof(double), h->stream));
     HIPCHK(hipMemsetAsync(h->dU, 0, B * N * 2 * sizeof(double), h->stream));
@@ -298,10 +300,9 @@ int create_resources(mpc_handle *h)
 
 int launch_schedule(mpc_handle *h, int batch, const int32_t *d_iters, hipStream_t s)
 {
-    static int granted[kMaxDevices] = {};
-    const size_t lds = (size_t)(mpc::kSchedBins * mpc::kSchedThreads + mpc::kSchedThreads) * sizeof(unsigned);
-    int rc = grant_lds(&mpc::schedule_kernel, granted, h->device, lds); if (rc) return rc;
-    hipLaunchKernelGGL(mpc::schedule_kernel, dim3(1), dim3(mpc::kSchedThreads), lds, s, batch, d_iters, h->d_order);
+    const int nblk = (batch + mpc::kSchedChunk - 1) / mpc::kSchedChunk;
+    hipLaunchKernelGGL(mpc::schedule_count_kernel, dim3(nblk), dim3(mpc::kSchedThreads), 0, s, batch, nblk, d_iters, h->d_sched_hist);
+    hipLaunchKernelGGL(mpc::schedule_scatter_kernel, dim3(nblk), dim3(mpc::kSchedThreads), 0, s, batch, nblk, d_iters, h->d_sched_hist, h->d_order);
     HIPCHK(hipGetLastError());
     return MPC_OK;
 }
@@ -398,7 +399,7 @@ int mpc_destroy(mpc_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *bufs[] = {h->dX, h->dU, h->d_x0, h->d_P, h->d_goal, h->d_obst, h->d_u0, h->d_cost, h->d_xa, h->d_ua, h->d_xb, h->d_status, h->d_iters,
-                    h->d_trace, h->d_alpha_own, h->d_order, h->d_iters_sched};
+                    h->d_trace, h->d_alpha_own, h->d_order, h->d_iters_sched, h->d_sched_hist};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (auto e : h->ev_start) (void)hipEventDestroy(e);
     for (auto e : h->ev_stop) (void)hipEventDestroy(e);

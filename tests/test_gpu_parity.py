@@ -559,7 +559,7 @@ def test_instance_scheduling(env, G):
                 order = s.instance_order(B)
                 if on:
                     assert order is not None and np.array_equal(np.sort(order), np.arange(B))          # a permutation
-                    assert (np.diff(np.minimum(g["iters"][order], 63)) <= 0).all()                        # by the last counts, descending
+                    assert (np.diff(np.minimum(g["iters"][order], 31)) <= 0).all()                        # by the last counts, descending
                     assert len(set(g["iters"].tolist())) > 4
                 else:
                     assert order is None
