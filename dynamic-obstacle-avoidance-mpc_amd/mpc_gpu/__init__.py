@@ -10,8 +10,8 @@ from .api import solve, get_solver
 from .world import Obstacle, generate_random_moving_obstacles, obstacle_states
 from .acados_shim import AcadosOcpSolverShim, AcadosSimSolverShim
 from .closed_loop import RobotOcpProblem
-from .episodes import run_episodes, write_experiment
+from .episodes import run_episodes, visualisation_inputs, write_experiment
 
 __all__ = ["MpcConfig", "MpcError", "build", "default_config", "BatchedMpc", "solve", "get_solver", "Obstacle",
            "generate_random_moving_obstacles", "obstacle_states", "AcadosOcpSolverShim", "AcadosSimSolverShim",
-           "RobotOcpProblem", "run_episodes", "write_experiment"]
+           "RobotOcpProblem", "run_episodes", "visualisation_inputs", "write_experiment"]

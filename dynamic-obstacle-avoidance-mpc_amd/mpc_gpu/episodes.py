@@ -84,6 +84,29 @@ def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, i
     return dict(table=table, x_last=xl, steps_run=k, solves=int(steps.sum().item()) + int((fl_h & 1).sum()), **extra)
 
 
+def visualisation_inputs(rec, instance, steps=None):
+    """What the reference hands to its `VisDynamicRobotEnv` (robot_ocp_problem.py:270-276, visualization.py:135-151) for ONE instance of a
+    recorded batch (`rec` = run_episodes(..., record=True)):
+        trajectory   (2, T)          -> vis.set_trajectory(simX[:, :2].T)
+        pred         (T, N + 1, 2)   -> vis.set_pred_trajectories(pred): row 0 zeros (init_experiment, :48-49), row k the horizon solved at step k
+        obstacles    [n_obst x (2, T)] -> vis.set_obst_trajectory([o.get_trajectory().T ...])
+    with T = steps + 1 (default: the instance's own episode length).  The recorded iterate is the SHIFTED one (stage j of the solve sits at
+    X[j - 1], stage N is kept, :253-258) and stage 0 of a solve is the plant state it started from, so the solved horizon is re-assembled here."""
+    simX, obst, pred = rec["simX"], rec["obst_traj"], rec["pred"]
+    if steps is None:
+        steps = int(rec["table"][instance, 4]) + int(rec["table"][instance, 1])      # control steps run: i, plus the one that reached the goal
+    steps = min(steps, pred.shape[0])
+    T = steps + 1
+    N = pred.shape[2] - 1
+    horizon = np.zeros((T, N + 1, 2))
+    for k in range(steps):
+        horizon[k + 1, 0] = simX[k, instance, :2]
+        horizon[k + 1, 1:N] = pred[k, instance, 0:N - 1, :2]
+        horizon[k + 1, N] = pred[k, instance, N, :2]
+    return dict(trajectory=simX[:T, instance, :2].T.copy(), pred=horizon,
+                obstacles=[obst[:T, instance, j, :2].T.copy() for j in range(obst.shape[2])])
+
+
 def write_experiment(table, spec, out_dir, stamp=None):
     """experiments.py:28-43 file format: `<stamp>_experiment_data.csv` (';' separated) + `<stamp>_experiment_spec.json`."""
     os.makedirs(out_dir, exist_ok=True)

@@ -216,3 +216,26 @@ def test_episode_recording_for_visualisation(env):
     # noise-free obstacles move with constant velocity between wall contacts
     d = r["obst_traj"][1, :, :, :2] - r["obst_traj"][0, :, :, :2]
     assert np.abs(d - 0.1 * r["obst_traj"][0, :, :, 2:]).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_visualisation_inputs_match_the_shim_loop(env):
+    """visualisation_inputs(): the arrays the reference's VisDynamicRobotEnv takes (robot_ocp_problem.py:270-276), re-assembled from a recorded
+    batch, against the same quantities kept by the shim-driven single-scenario loop (show_pred=True): trajectory, solved horizons, obstacle tracks"""
+    mpc_gpu, _ = env
+    x0 = np.array([-6.0, -6.0, np.pi / 4, 0, 0]); goal = np.array([6.0, 6.0])
+    obst = np.array([[0.5, 0.5, 0.4, -0.3], [-3.0, 2.0, 0.5, 0.5], [3.0, -2.0, -0.6, 0.2]])
+    rec = mpc_gpu.run_episodes(x0[None], goal[None], obst[None], N=20, Tf=2.0, max_iter=120, random_move=False, record=True)
+    vis = mpc_gpu.visualisation_inputs(rec, 0)
+    np.random.seed(0)
+    prob = mpc_gpu.RobotOcpProblem(x0.copy(), goal, scenario="EDGE", N=20, Tf=2.0, n_obst=3, init_guess_when_error=True, show_pred=True)
+    for o, st in zip(prob.obstacles, obst):
+        o.x, o.y, o.vx, o.vy = st
+        o.traj = [[o.x, o.y]]
+    prob.step(120)
+    T = vis["trajectory"].shape[1]
+    assert T == len(prob.simX) and vis["pred"].shape == (T, 21, 2) and len(vis["obstacles"]) == 3
+    assert np.abs(vis["trajectory"] - prob.simX[:, :2].T).max() < 1e-9
+    assert (vis["pred"][0] == 0).all() and np.abs(vis["pred"][1:] - prob.pred).max() < 1e-9
+    for j, o in enumerate(prob.obstacles):
+        assert np.abs(vis["obstacles"][j] - o.get_trajectory().T).max() < 1e-12
