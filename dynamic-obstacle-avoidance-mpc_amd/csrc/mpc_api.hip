@@ -101,9 +101,9 @@ int check_batch(mpc_handle *h, int batch)
 
 hipStream_t pick(mpc_handle *h, void *stream) { return stream ? (hipStream_t)stream : h->stream; }
 
-// Lanes per instance: the smallest of {16, 32, 64} with N + 1 < G (an idle lane must separate instances that share a
-// wavefront), unless overridden.  Packing 64/G instances into one wavefront multiplies throughput for large batches
-// and costs a single small batch nothing (the instruction stream has the same length either way).
+// Lanes per instance of the one-lane-per-stage mapping: the smallest of {16, 32, 64} with N + 1 < G (an idle lane separates instances that
+// share a wavefront), or 21 -- three instances per wavefront on compact LDS blocks -- for 16 <= N <= 20 once pick_split hands a large batch
+// to this mapping; unless overridden.  Packing instances into one wavefront multiplies throughput for large batches.
 int pick_lanes(mpc_handle *h, int batch)
 {
     const int need = h->cfg.N + 2;

@@ -74,6 +74,7 @@ def test_short_horizon_table_and_iteration_cap(mapping):
 def test_the_other_lm_semantics_reproduces_nothing(built):
     """levenberg_marquardt NOT scaled by the stage interval (what SURVEY 8(c) first guessed): no recorded row comes back"""
     import mpc_gpu
+    mpc_gpu.BatchedMpc.default_lanes_per_stage = 0
     tb, rows, scen = replay(mpc_gpu, "20221031_215846", lm_scaled=0)
     assert row_match(tb, rows, 1e-3).sum() == 0
     assert (tb[STABLE[scen], 4] == rows[STABLE[scen], 4]).sum() <= 3
@@ -87,6 +88,7 @@ def test_recorded_rows_at_scale(built, copies):
     bit for bit where an instance has a wavefront to itself, to rounding where three share one."""
     import mpc_gpu
     from mpc_gpu.world import reference_streams
+    mpc_gpu.BatchedMpc.default_lanes_per_stage = 0          # the dispatcher's own choice (a module-scoped fixture of another test may still hold 1)
     t = TABLES["20221031_215846"]; rows = np.array(t["rows"])
     obst, noise = reference_streams("RANDOM", range(100), 5, 400)
     B = 100 * copies
