@@ -35,6 +35,11 @@ int main(void)
     if (mpc_predict(NULL, 1, buf, buf) != MPC_ERR_ARG) bad++;
     if (mpc_profile_enable(NULL, 1) != MPC_ERR_ARG) bad++;
     if (mpc_set_lanes_per_stage(NULL, 0) != MPC_ERR_ARG) bad++;
+    if (mpc_set_waves_per_simd(NULL, 2) != MPC_ERR_ARG) bad++;
+    if (mpc_set_instance_scheduling(NULL, 1) != MPC_ERR_ARG) bad++;
+    if (mpc_get_instance_order(NULL, 1, ibuf) != MPC_ERR_ARG) bad++;
+    char name[8];
+    if (mpc_get_kernel_name(NULL, 1, 1, name, 8) != MPC_ERR_ARG) bad++;
     if (mpc_destroy(NULL) != MPC_OK) bad++;
     printf("abi sanitizer driver: %d problems (devices: %d)\n", bad, ndev);
     return bad ? 1 : 0;
