@@ -16,6 +16,15 @@ for k in range(100):
     loop.control_step(); torch.cuda.synchronize()
     hist.append(loop.iters.cpu().numpy().copy())
 hist = np.array(hist)
+# alternative predictors of an instance's next iteration count (three per wavefront)
+for name, pred in (("previous", lambda k: hist[k - 1].astype(float)), ("max of last two", lambda k: np.maximum(hist[k - 1], hist[k - 2]).astype(float)),
+                   ("sum of last two", lambda k: (hist[k - 1] + hist[k - 2]).astype(float)), ("0.7 prev + 0.3 prevprev", lambda k: 0.7 * hist[k - 1] + 0.3 * hist[k - 2]),
+                   ("mean of last four", lambda k: hist[k - 4:k].mean(0))):
+    vals = []
+    for k in range(4, 100):
+        it = hist[k].astype(float); n = (len(it) // 3) * 3
+        vals.append(it[np.argsort(-pred(k), kind="stable")][:n].reshape(-1, 3).max(1).mean())
+    print("predictor", name, float(np.mean(vals)))
 out = []
 for per in (2, 3):
     nat, srt, ideal = [], [], []
