@@ -1579,6 +1579,10 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     if (i == 0) {
 #pragma unroll
         for (int c = 0; c < 5; c++) { d0[c] = x0v[c] - xi[c]; lin0 = fmax(lin0, fabs(d0[c])); }
+        if constexpr (PLDS) {       // LEAN on compact blocks: the initial-condition residual is only ever used by the lane of stage 0 -- it waits in the
+#pragma unroll                      // front padding of the stage blocks (5 words per instance) instead of in five registers of every lane
+            for (int c = 0; c < 5; c++) lds_raw[RowLdsC::CT + slot * 5 + c] = d0[c];
+        }
     }
     if (USE_MFMA) {
         // zero the operand tiles once, then every stage lane writes its W~_t = [A b B; 0 1 0] (cols: x0..x4, 1, ua, ual)
@@ -1626,6 +1630,18 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #pragma unroll
             for (int c = 0; c < 8; c++) w[k * 8 + c] = Wrow[k][c];
     }
+    // PLDS: the non-trivial entries of A, B are not carried through the interior point either -- rows 0, 1 of the stage's W~ block in LDS hold them
+    // (words 2..4, 6, 7 and 10..12, 14, 15) for the whole solve
+    auto stage_lin = [&]() {
+        if constexpr (PLDS) {
+            StageLin L;
+            const double *w = RL.W + LT::WS * (has_u ? i : 0);
+            L.a02 = has_u ? w[2] : 0.0; L.a03 = has_u ? w[3] : 0.0; L.a04 = has_u ? w[4] : 0.0; L.b00 = has_u ? w[6] : 0.0; L.b01 = has_u ? w[7] : 0.0;
+            L.a12 = has_u ? w[10] : 0.0; L.a13 = has_u ? w[11] : 0.0; L.a14 = has_u ? w[12] : 0.0; L.b10 = has_u ? w[14] : 0.0; L.b11 = has_u ? w[15] : 0.0;
+            L.dt = dt; L.h2 = h2;
+            return L;
+        } else return S;
+    };
     // ---- inequality rows of this stage, in registers ----
     // box variables k: 0 ua, 1 ual, 2 x, 3 y, 4 v, 5 om  -> z index {0,1,2,3,5,6} (also the slot in Hq below)
     constexpr int NB = 6;
@@ -1777,7 +1793,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         double za[7] = {0, 0, 0, 0, 0, 0, 0};
         double bbr[5], x_init[5];
 #pragma unroll
-        for (int c = 0; c < 5; c++) { bbr[c] = rhoPi * bb[c]; x_init[c] = rhoPi * d0[c]; }
+        for (int c = 0; c < 5; c++) { bbr[c] = rhoPi * bb[c]; x_init[c] = PLDS ? 0.0 : rhoPi * d0[c]; }
         {
             refresh_box_rcp();
             double vals[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
@@ -1909,8 +1925,9 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 // (no barrier: every lane overwrites only the block it has just read, and a wavefront's LDS operations complete in order)
                 if (has_u) {    // closed-loop matrix Acl = A + B K of this stage, row-major, for the row-parallel vector recursions
                     double *acl = RL.H + LT::HS * i + RowVec::ACL;
-                    const double Ar[2][5] = {{1.0, 0.0, S.a02, S.a03, S.a04}, {0.0, 1.0, S.a12, S.a13, S.a14}};
-                    const double Br[2][2] = {{S.b00, S.b01}, {S.b10, S.b11}};
+                    const StageLin SL = stage_lin();
+                    const double Ar[2][5] = {{1.0, 0.0, SL.a02, SL.a03, SL.a04}, {0.0, 1.0, SL.a12, SL.a13, SL.a14}};
+                    const double Br[2][2] = {{SL.b00, SL.b01}, {SL.b10, SL.b11}};
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
                         acl[0 * RowVec::RS + c] = Ar[0][c] + Br[0][0] * F.K0[c] + Br[0][1] * F.K1[c];
@@ -1927,12 +1944,13 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         if (ROWPAR) {
             if (has_u) {        // c_t = r_b + B k
                 double *cc = RL.H + LT::HS * i + RowVec::ACL + 5;      // c[r] closes row r
-                cc[0 * RowVec::RS] = bbr[0] + S.b00 * F.k0 + S.b01 * F.k1; cc[1 * RowVec::RS] = bbr[1] + S.b10 * F.k0 + S.b11 * F.k1;
+                const StageLin SL = stage_lin();
+                cc[0 * RowVec::RS] = bbr[0] + SL.b00 * F.k0 + SL.b01 * F.k1; cc[1 * RowVec::RS] = bbr[1] + SL.b10 * F.k0 + SL.b11 * F.k1;
                 cc[2 * RowVec::RS] = bbr[2] + h2 * F.k1; cc[3 * RowVec::RS] = bbr[3] + dt * F.k0; cc[4 * RowVec::RS] = bbr[4] + dt * F.k1;
             }
             if (i == 0) {
 #pragma unroll
-                for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = x_init[c];
+                for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = PLDS ? rhoPi * lds_raw[RowLdsC::CT + slot * 5 + c] : x_init[c];
             }
             __syncthreads();
             rowpar_vector_fast<true>(lane, N, RS, sweep_worker);
@@ -2064,7 +2082,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 if (has_u) {    // feed-forward of the corrector right-hand side: k = -Muu^-1 (gc_u + B' p_{t+1})
                     const double *pp = RL.H + LT::HS * (i + 1) + RowVec::P;
                     const double pv[5] = {pp[0], pp[1], pp[2], pp[3], pp[4]};
-                    const double m0 = gc[0] + S.dua(pv), m1 = gc[1] + S.dual(pv);
+                    const StageLin SL = stage_lin();
+                    const double m0 = gc[0] + SL.dua(pv), m1 = gc[1] + SL.dual(pv);
                     F.k1 = fma(F.l, m0, -m1) * F.i11;
                     F.k0 = fma(-F.l, F.k1, -(m0 * F.i00));
                 }
@@ -2075,7 +2094,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         if (ROWPAR) {
             if (has_u) {        // homogeneous dynamics: c_t = B k
                 double *cc = RL.H + LT::HS * i + RowVec::ACL + 5;
-                cc[0 * RowVec::RS] = S.b00 * F.k0 + S.b01 * F.k1; cc[1 * RowVec::RS] = S.b10 * F.k0 + S.b11 * F.k1;
+                const StageLin SL = stage_lin();
+                cc[0 * RowVec::RS] = SL.b00 * F.k0 + SL.b01 * F.k1; cc[1 * RowVec::RS] = SL.b10 * F.k0 + SL.b11 * F.k1;
                 cc[2 * RowVec::RS] = h2 * F.k1; cc[3 * RowVec::RS] = dt * F.k0; cc[4 * RowVec::RS] = dt * F.k1;
             }
             if (i == 0) {
@@ -2185,6 +2205,12 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     if (p.trace && i == 0 && valid) { for (int k = 0; k < 10; k++) p.trace[((size_t)inst * p.iter_max) * 4 + k] = (double)tacc_[k]; }
 #endif
 
+    if constexpr (LEAN) {       // the plant state is read again here instead of being carried through the interior point (5 doubles per lane less)
+        const double *xg = p.x0 + (size_t)inst * 5;
+        asm volatile("" : "+v"(xg));
+#pragma unroll
+        for (int c = 0; c < 5; c++) x0v[c] = xg[c];
+    }
     // ---- full step on the iterate; status 4 leaves it unchanged ----
     const bool store = valid && !ep_done;
     if (status != 4) {
