@@ -1452,6 +1452,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     constexpr bool USE_MFMA = FACT == 1, ROWPAR = FACT >= 2, COMPACT = FACT == 3;
     constexpr bool LEAN = NOBST >= 10;          // ten obstacle pairs: recomputable row state is not carried (see obst_view below)
     constexpr bool PLDS = LEAN && COMPACT;      // ... and the obstacle positions of a stage stay in LDS behind the compact stage blocks
+    constexpr bool SLDS = PLDS;                 // ... as do the A / B entries (re-read from the W~ block) and the initial residual (front padding); on the
+                                                // 3-obstacle kernels, which do not spill, the same move costs 2 % (measured at C3) and is not made
     static_assert(!USE_MFMA || G == 64, "the matrix-core factorisation maps one instance per wavefront");
     static_assert(G != 21 || COMPACT, "three instances per wavefront exist for the row-parallel sweeps on compact stage blocks only");
     constexpr int IPW = 64 / G;               // instances per wavefront (G = 21: three, lanes [0,21), [21,42), [42,63); lane 63 idles)
@@ -1579,7 +1581,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     if (i == 0) {
 #pragma unroll
         for (int c = 0; c < 5; c++) { d0[c] = x0v[c] - xi[c]; lin0 = fmax(lin0, fabs(d0[c])); }
-        if constexpr (PLDS) {       // LEAN on compact blocks: the initial-condition residual is only ever used by the lane of stage 0 -- it waits in the
+        if constexpr (SLDS) {       // LEAN on compact blocks: the initial-condition residual is only ever used by the lane of stage 0 -- it waits in the
 #pragma unroll                      // front padding of the stage blocks (5 words per instance) instead of in five registers of every lane
             for (int c = 0; c < 5; c++) lds_raw[RowLdsC::CT + slot * 5 + c] = d0[c];
         }
@@ -1633,7 +1635,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     // PLDS: the non-trivial entries of A, B are not carried through the interior point either -- rows 0, 1 of the stage's W~ block in LDS hold them
     // (words 2..4, 6, 7 and 10..12, 14, 15) for the whole solve
     auto stage_lin = [&]() {
-        if constexpr (PLDS) {
+        if constexpr (SLDS) {
             StageLin L;
             const double *w = RL.W + LT::WS * (has_u ? i : 0);
             L.a02 = has_u ? w[2] : 0.0; L.a03 = has_u ? w[3] : 0.0; L.a04 = has_u ? w[4] : 0.0; L.b00 = has_u ? w[6] : 0.0; L.b01 = has_u ? w[7] : 0.0;
@@ -1793,7 +1795,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         double za[7] = {0, 0, 0, 0, 0, 0, 0};
         double bbr[5], x_init[5];
 #pragma unroll
-        for (int c = 0; c < 5; c++) { bbr[c] = rhoPi * bb[c]; x_init[c] = PLDS ? 0.0 : rhoPi * d0[c]; }
+        for (int c = 0; c < 5; c++) { bbr[c] = rhoPi * bb[c]; x_init[c] = SLDS ? 0.0 : rhoPi * d0[c]; }
         {
             refresh_box_rcp();
             double vals[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
@@ -1950,7 +1952,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             }
             if (i == 0) {
 #pragma unroll
-                for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = PLDS ? rhoPi * lds_raw[RowLdsC::CT + slot * 5 + c] : x_init[c];
+                for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = SLDS ? rhoPi * lds_raw[RowLdsC::CT + slot * 5 + c] : x_init[c];
             }
             __syncthreads();
             rowpar_vector_fast<true>(lane, N, RS, sweep_worker);
