@@ -1024,6 +1024,357 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const LT L, bool 
         "3:\n" \
         "s_waitcnt lgkmcnt(0)\n"
 
+// THE SAME ONE-BLOCK SWEEP ON THE COMPACT STAGE BLOCKS (RowLdsC; text derived mechanically from MPC_FACTOR_ASM: same instructions, same registers, same
+// wait counts -- the W~ and H~aug operands arrive through the same number of requests).  What differs: the offsets (21 + 57 words per stage), rows 2..4 of W~
+// through two per-lane pointers (%5 upper / %6 lower stage of a pair; lane 5 walks the b_t words of the stage blocks with the per-lane stride %11, the other
+// lanes stay on the wavefront's constant table), rows 6, 7 of H~aug through the per-lane pointer %7 (rti_kernel.hpp, RowLdsC).
+#define MPC_FACTOR_ASM_C \
+        "ds_read2_b64 v[116:119], %9 offset0:0 offset1:8\n" \
+        "ds_read2_b64 v[120:123], %9 offset0:16 offset1:24\n" \
+        "ds_read2_b64 v[124:127], %9 offset0:32 offset1:40\n" \
+        "ds_read2_b64 v[144:147], %0 offset0:21 offset1:29\n" \
+        "ds_read2_b64 v[148:151], %5 offset0:0 offset1:1\n" \
+        "ds_read_b64 v[152:153], %5 offset:16\n" \
+        "ds_read2_b64 v[100:103], %1 offset0:57 offset1:65\n" \
+        "ds_read2_b64 v[104:107], %1 offset0:73 offset1:81\n" \
+        "ds_read2_b64 v[108:111], %1 offset0:89 offset1:97\n" \
+        "ds_read2_b64 v[112:115], %7 offset0:57 offset1:58\n" \
+        "s_waitcnt lgkmcnt(0)\n" \
+        "s_nop 4\n" \
+        "s_cmp_eq_u32 %4, 0\n" \
+        "s_cbranch_scc1 2f\n" \
+        "1:\n" \
+        "s_waitcnt lgkmcnt(7)\n" \
+        "v_mul_f64 v[132:133], v[116:117], %8\n" \
+        "v_mul_f64 v[134:135], v[118:119], %8\n" \
+        "v_mul_f64 v[136:137], v[120:121], %8\n" \
+        "v_mul_f64 v[138:139], v[122:123], %8\n" \
+        "v_mul_f64 v[140:141], v[124:125], %8\n" \
+        "v_mul_f64 v[142:143], v[126:127], %8\n" \
+        "s_nop 1\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[144:145] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[116:117], v[144:145] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[116:117], v[144:145] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[116:117], v[144:145] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[116:117], v[144:145] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[116:117], v[144:145] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[146:147] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[118:119], v[146:147] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[118:119], v[146:147] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[118:119], v[146:147] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[118:119], v[146:147] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[118:119], v[146:147] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[148:149] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[118:119], v[148:149] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[120:121], v[148:149] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[120:121], v[148:149] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[120:121], v[148:149] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[120:121], v[148:149] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[118:119], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[120:121], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[122:123], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[122:123], v[150:151] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[122:123], v[150:151] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[118:119], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[120:121], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[122:123], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[124:125], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[124:125], v[152:153] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "ds_read2_b64 v[154:157], %0 offset0:0 offset1:8\n" \
+        "ds_read2_b64 v[158:161], %6 offset0:0 offset1:1\n" \
+        "ds_read_b64 v[162:163], %6 offset:16\n" \
+        "ds_read2_b64 v[116:119], %1 offset0:0 offset1:8\n" \
+        "ds_read2_b64 v[120:123], %1 offset0:16 offset1:24\n" \
+        "ds_read2_b64 v[124:127], %1 offset0:32 offset1:40\n" \
+        "ds_read2_b64 v[128:131], %7 offset0:0 offset1:1\n" \
+        "s_waitcnt lgkmcnt(10)\n" \
+        "s_nop 1\n" \
+        "v_fmac_f64_dpp v[112:113], v[144:145], v[132:133] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[114:115], v[144:145], v[132:133] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[112:113], v[146:147], v[134:135] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[114:115], v[146:147], v[134:135] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[114:115], v[148:149], v[136:137] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[112:113], v[150:151], v[138:139] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[114:115], v[152:153], v[140:141] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[100:101], v[144:145], v[132:133] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[104:105], v[144:145], v[132:133] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_dpp v[174:175], v[112:113] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_dpp v[176:177], v[112:113] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_dpp v[178:179], v[114:115] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[106:107], v[144:145], v[132:133] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_rcp_f64_e32 v[182:183], v[174:175]\n" \
+        "v_fmac_f64_dpp v[108:109], v[144:145], v[132:133] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[174:175], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[110:111], v[144:145], v[132:133] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[182:183], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[102:103], v[146:147], v[134:135] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[174:175], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[104:105], v[146:147], v[134:135] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[168:169], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[106:107], v[146:147], v[134:135] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_mul_f64 v[170:171], v[176:177], v[168:169]\n" \
+        "v_fmac_f64_dpp v[108:109], v[146:147], v[134:135] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[178:179], -v[170:171], v[176:177], v[178:179]\n" \
+        "v_fmac_f64_dpp v[110:111], v[146:147], v[134:135] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_rcp_f64_e32 v[182:183], v[178:179]\n" \
+        "v_fmac_f64_dpp v[104:105], v[148:149], v[136:137] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[178:179], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[108:109], v[148:149], v[136:137] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[182:183], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[110:111], v[148:149], v[136:137] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[178:179], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[106:107], v[150:151], v[138:139] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[172:173], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[110:111], v[150:151], v[138:139] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], v[170:171], v[112:113], -v[114:115]\n" \
+        "v_fmac_f64_dpp v[108:109], v[152:153], v[140:141] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_mul_f64 v[166:167], v[180:181], v[172:173]\n" \
+        "v_mul_f64 v[180:181], v[112:113], v[168:169]\n" \
+        "v_fmac_f64_dpp v[110:111], v[152:153], v[140:141] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[164:165], -v[170:171], v[166:167], -v[180:181]\n" \
+        "v_add_f64 v[110:111], v[110:111], v[142:143]\n" \
+        "ds_write2_b64 %2, v[164:165], v[166:167] offset0:57 offset1:65\n" \
+        "ds_write2_b64 %3, v[168:169], v[170:171] offset0:57 offset1:58\n" \
+        "ds_write_b64 %3, v[172:173] offset:520\n" \
+        "s_nop 1\n" \
+        "v_fmac_f64_dpp v[100:101], v[112:113], v[164:165] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[102:103], v[112:113], v[164:165] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[104:105], v[112:113], v[164:165] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[106:107], v[112:113], v[164:165] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[108:109], v[112:113], v[164:165] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[110:111], v[112:113], v[164:165] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[100:101], v[114:115], v[166:167] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[102:103], v[114:115], v[166:167] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[104:105], v[114:115], v[166:167] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[106:107], v[114:115], v[166:167] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[108:109], v[114:115], v[166:167] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[110:111], v[114:115], v[166:167] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "s_waitcnt lgkmcnt(7)\n" \
+        "v_mul_f64 v[132:133], v[100:101], %8\n" \
+        "v_mul_f64 v[134:135], v[102:103], %8\n" \
+        "v_mul_f64 v[136:137], v[104:105], %8\n" \
+        "v_mul_f64 v[138:139], v[106:107], %8\n" \
+        "v_mul_f64 v[140:141], v[108:109], %8\n" \
+        "v_mul_f64 v[142:143], v[110:111], %8\n" \
+        "s_nop 1\n" \
+        "v_fmac_f64_dpp v[132:133], v[100:101], v[154:155] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[100:101], v[154:155] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[100:101], v[154:155] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[100:101], v[154:155] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[100:101], v[154:155] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[100:101], v[154:155] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[100:101], v[156:157] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[102:103], v[156:157] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[102:103], v[156:157] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[102:103], v[156:157] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[102:103], v[156:157] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[102:103], v[156:157] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[100:101], v[158:159] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[102:103], v[158:159] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[104:105], v[158:159] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[104:105], v[158:159] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[104:105], v[158:159] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[104:105], v[158:159] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[100:101], v[160:161] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[102:103], v[160:161] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[104:105], v[160:161] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[106:107], v[160:161] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[106:107], v[160:161] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[106:107], v[160:161] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[100:101], v[162:163] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[102:103], v[162:163] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[104:105], v[162:163] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[106:107], v[162:163] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[108:109], v[162:163] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[108:109], v[162:163] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_add_u32_e32 %0, 0xfffffeb0, %0\n" \
+        "v_add_u32_e32 %1, 0xfffffc70, %1\n" \
+        "v_add_u32_e32 %5, %11, %5\n" \
+        "v_add_u32_e32 %6, %11, %6\n" \
+        "v_add_u32_e32 %7, 0xfffffc70, %7\n" \
+        "ds_read2_b64 v[144:147], %0 offset0:21 offset1:29\n" \
+        "ds_read2_b64 v[148:151], %5 offset0:0 offset1:1\n" \
+        "ds_read_b64 v[152:153], %5 offset:16\n" \
+        "ds_read2_b64 v[100:103], %1 offset0:57 offset1:65\n" \
+        "ds_read2_b64 v[104:107], %1 offset0:73 offset1:81\n" \
+        "ds_read2_b64 v[108:111], %1 offset0:89 offset1:97\n" \
+        "ds_read2_b64 v[112:115], %7 offset0:57 offset1:58\n" \
+        "s_waitcnt lgkmcnt(10)\n" \
+        "s_nop 1\n" \
+        "v_fmac_f64_dpp v[128:129], v[154:155], v[132:133] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[130:131], v[154:155], v[132:133] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[128:129], v[156:157], v[134:135] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[130:131], v[156:157], v[134:135] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[130:131], v[158:159], v[136:137] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[128:129], v[160:161], v[138:139] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[130:131], v[162:163], v[140:141] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[116:117], v[154:155], v[132:133] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[120:121], v[154:155], v[132:133] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_dpp v[174:175], v[128:129] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_dpp v[176:177], v[128:129] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_dpp v[178:179], v[130:131] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[122:123], v[154:155], v[132:133] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_rcp_f64_e32 v[182:183], v[174:175]\n" \
+        "v_fmac_f64_dpp v[124:125], v[154:155], v[132:133] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[174:175], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[126:127], v[154:155], v[132:133] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[182:183], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[118:119], v[156:157], v[134:135] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[174:175], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[120:121], v[156:157], v[134:135] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[168:169], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[122:123], v[156:157], v[134:135] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_mul_f64 v[170:171], v[176:177], v[168:169]\n" \
+        "v_fmac_f64_dpp v[124:125], v[156:157], v[134:135] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[178:179], -v[170:171], v[176:177], v[178:179]\n" \
+        "v_fmac_f64_dpp v[126:127], v[156:157], v[134:135] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_rcp_f64_e32 v[182:183], v[178:179]\n" \
+        "v_fmac_f64_dpp v[120:121], v[158:159], v[136:137] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[178:179], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[124:125], v[158:159], v[136:137] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[182:183], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[126:127], v[158:159], v[136:137] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[178:179], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[122:123], v[160:161], v[138:139] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[172:173], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[126:127], v[160:161], v[138:139] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], v[170:171], v[128:129], -v[130:131]\n" \
+        "v_fmac_f64_dpp v[124:125], v[162:163], v[140:141] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_mul_f64 v[166:167], v[180:181], v[172:173]\n" \
+        "v_mul_f64 v[180:181], v[128:129], v[168:169]\n" \
+        "v_fmac_f64_dpp v[126:127], v[162:163], v[140:141] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[164:165], -v[170:171], v[166:167], -v[180:181]\n" \
+        "v_add_f64 v[126:127], v[126:127], v[142:143]\n" \
+        "ds_write2_b64 %2, v[164:165], v[166:167] offset0:0 offset1:8\n" \
+        "ds_write2_b64 %3, v[168:169], v[170:171] offset0:0 offset1:1\n" \
+        "ds_write_b64 %3, v[172:173] offset:64\n" \
+        "v_add_u32_e32 %2, 0xfffffc70, %2\n" \
+        "v_add_u32_e32 %3, 0xfffffc70, %3\n" \
+        "s_nop 1\n" \
+        "v_fmac_f64_dpp v[116:117], v[128:129], v[164:165] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[118:119], v[128:129], v[164:165] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[120:121], v[128:129], v[164:165] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[122:123], v[128:129], v[164:165] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[124:125], v[128:129], v[164:165] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[126:127], v[128:129], v[164:165] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[116:117], v[130:131], v[166:167] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[118:119], v[130:131], v[166:167] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[120:121], v[130:131], v[166:167] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[122:123], v[130:131], v[166:167] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[124:125], v[130:131], v[166:167] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[126:127], v[130:131], v[166:167] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "s_sub_u32 %4, %4, 1\n" \
+        "s_cmp_lg_u32 %4, 0\n" \
+        "s_cbranch_scc1 1b\n" \
+        "2:\n" \
+        "s_cmp_eq_u32 %10, 0\n" \
+        "s_cbranch_scc1 3f\n" \
+        "s_waitcnt lgkmcnt(7)\n" \
+        "v_mul_f64 v[132:133], v[116:117], %8\n" \
+        "v_mul_f64 v[134:135], v[118:119], %8\n" \
+        "v_mul_f64 v[136:137], v[120:121], %8\n" \
+        "v_mul_f64 v[138:139], v[122:123], %8\n" \
+        "v_mul_f64 v[140:141], v[124:125], %8\n" \
+        "v_mul_f64 v[142:143], v[126:127], %8\n" \
+        "s_nop 1\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[144:145] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[116:117], v[144:145] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[116:117], v[144:145] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[116:117], v[144:145] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[116:117], v[144:145] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[116:117], v[144:145] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[146:147] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[118:119], v[146:147] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[118:119], v[146:147] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[118:119], v[146:147] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[118:119], v[146:147] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[118:119], v[146:147] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[148:149] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[118:119], v[148:149] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[120:121], v[148:149] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[120:121], v[148:149] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[120:121], v[148:149] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[120:121], v[148:149] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[118:119], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[120:121], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[122:123], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[122:123], v[150:151] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[122:123], v[150:151] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[132:133], v[116:117], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[134:135], v[118:119], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[136:137], v[120:121], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[138:139], v[122:123], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[140:141], v[124:125], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[142:143], v[124:125], v[152:153] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "s_waitcnt lgkmcnt(3)\n" \
+        "s_nop 1\n" \
+        "v_fmac_f64_dpp v[112:113], v[144:145], v[132:133] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[114:115], v[144:145], v[132:133] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[112:113], v[146:147], v[134:135] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[114:115], v[146:147], v[134:135] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[114:115], v[148:149], v[136:137] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[112:113], v[150:151], v[138:139] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[114:115], v[152:153], v[140:141] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[100:101], v[144:145], v[132:133] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[104:105], v[144:145], v[132:133] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_dpp v[174:175], v[112:113] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_dpp v[176:177], v[112:113] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_mov_b64_dpp v[178:179], v[114:115] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[106:107], v[144:145], v[132:133] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_rcp_f64_e32 v[182:183], v[174:175]\n" \
+        "v_fmac_f64_dpp v[108:109], v[144:145], v[132:133] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[174:175], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[110:111], v[144:145], v[132:133] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[182:183], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[102:103], v[146:147], v[134:135] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[174:175], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[104:105], v[146:147], v[134:135] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[168:169], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[106:107], v[146:147], v[134:135] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_mul_f64 v[170:171], v[176:177], v[168:169]\n" \
+        "v_fmac_f64_dpp v[108:109], v[146:147], v[134:135] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[178:179], -v[170:171], v[176:177], v[178:179]\n" \
+        "v_fmac_f64_dpp v[110:111], v[146:147], v[134:135] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_rcp_f64_e32 v[182:183], v[178:179]\n" \
+        "v_fmac_f64_dpp v[104:105], v[148:149], v[136:137] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[178:179], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[108:109], v[148:149], v[136:137] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[182:183], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[110:111], v[148:149], v[136:137] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], -v[178:179], v[182:183], 1.0\n" \
+        "v_fmac_f64_dpp v[106:107], v[150:151], v[138:139] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[172:173], v[180:181], v[182:183], v[182:183]\n" \
+        "v_fmac_f64_dpp v[110:111], v[150:151], v[138:139] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[180:181], v[170:171], v[112:113], -v[114:115]\n" \
+        "v_fmac_f64_dpp v[108:109], v[152:153], v[140:141] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_mul_f64 v[166:167], v[180:181], v[172:173]\n" \
+        "v_mul_f64 v[180:181], v[112:113], v[168:169]\n" \
+        "v_fmac_f64_dpp v[110:111], v[152:153], v[140:141] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fma_f64 v[164:165], -v[170:171], v[166:167], -v[180:181]\n" \
+        "v_add_f64 v[110:111], v[110:111], v[142:143]\n" \
+        "ds_write2_b64 %2, v[164:165], v[166:167] offset0:57 offset1:65\n" \
+        "ds_write2_b64 %3, v[168:169], v[170:171] offset0:57 offset1:58\n" \
+        "ds_write_b64 %3, v[172:173] offset:520\n" \
+        "s_nop 1\n" \
+        "v_fmac_f64_dpp v[100:101], v[112:113], v[164:165] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[102:103], v[112:113], v[164:165] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[104:105], v[112:113], v[164:165] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[106:107], v[112:113], v[164:165] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[108:109], v[112:113], v[164:165] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[110:111], v[112:113], v[164:165] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[100:101], v[114:115], v[166:167] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[102:103], v[114:115], v[166:167] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[104:105], v[114:115], v[166:167] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[106:107], v[114:115], v[166:167] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[108:109], v[114:115], v[166:167] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
+        "v_fmac_f64_dpp v[110:111], v[114:115], v[166:167] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
+        "3:\n" \
+        "s_waitcnt lgkmcnt(0)\n"
+
+
 #define MPC_FACTOR_ASM_CLOBBERS "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "scc", "vcc", "memory"
 
 __device__ __forceinline__ void rowpar_factor_fast(int lane, int N, const RowLds L, bool worker_row)
@@ -1039,6 +1390,27 @@ __device__ __forceinline__ void rowpar_factor_fast(int lane, int N, const RowLds
     int passes = N >> 1;
     const int odd = N & 1;
     asm volatile(MPC_FACTOR_ASM : "+v"(wp), "+v"(hp), "+v"(kp), "+v"(fp), "+s"(passes) : "v"(d5), "v"(hN), "s"(odd) : MPC_FACTOR_ASM_CLOBBERS);
+}
+
+__device__ __forceinline__ void rowpar_factor_fast_c(int lane, int N, const RowLdsC L, bool worker_row)
+{
+    constexpr int WS = RowLdsC::WS, HS = RowLdsC::HS;
+    const int j = lane & 7, l15 = lane & 15;
+    const bool store = worker_row && l15 < 6, store0 = worker_row && l15 == 0;
+    const double d5 = (j == 5) ? 1.0 : 0.0;
+    // base pointers: the LOWER stage of the first pair (stage N - 2; the upper one sits one block above, as an immediate offset)
+    uint32_t wp = lds_address(L.W + j + WS * (N - 2)), hp = lds_address(L.H + j + HS * (N - 2));
+    uint32_t kp = lds_address(L.R + (store ? j : RowLdsC::DEADK) + HS * (N - 2)), fp = lds_address(L.R + (store0 ? 6 : RowLdsC::DEADF) + HS * (N - 2));
+    const uint32_t hN = lds_address(L.H + j + HS * N);
+    // rows 2..4 of W~: lane 5 reads b_t[2..4] of the stage block, the other lanes the constant table (stride 0)
+    uint32_t bpu = lds_address(j == 5 ? L.W + 16 + WS * (N - 1) : L.C + 3 * j), bpl = lds_address(j == 5 ? L.W + 16 + WS * (N - 2) : L.C + 3 * j);
+    const uint32_t bstride = j == 5 ? (uint32_t)(-2 * WS * 8) : 0u;
+    // rows 6, 7 of H~aug: (zero, zero) | (H[5][6], H[5][7]) | (H66, zero) | (zero, H77)
+    uint32_t h6p = lds_address(L.H + (j < 5 ? 49 : (j == 5 ? 46 : (j == 6 ? 48 : 50))) + HS * (N - 2));
+    int passes = N >> 1;
+    const int odd = N & 1;
+    asm volatile(MPC_FACTOR_ASM_C : "+v"(wp), "+v"(hp), "+v"(kp), "+v"(fp), "+s"(passes), "+v"(bpu), "+v"(bpl), "+v"(h6p)
+                 : "v"(d5), "v"(hN), "s"(odd), "v"(bstride) : MPC_FACTOR_ASM_CLOBBERS);
 }
 
 // ROW-PARALLEL VECTOR RECURSIONS.  With the closed-loop matrix Acl_t = A_t + B_t K_t (5 x 5, computed by the lane that owns
@@ -1911,8 +2283,13 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #ifdef MPC_FACTOR_PLAIN
                 rowpar_factor(lane, N, RS, sweep_worker);
 #else
-                if constexpr (COMPACT) rowpar_factor(lane, N, RS, sweep_worker);      // (the one-block asm variant carries the dense layout's offsets)
-                else rowpar_factor_fast(lane, N, RS, sweep_worker);
+                if constexpr (COMPACT) {
+#ifdef MPC_COMPACT_PLAIN
+                    rowpar_factor(lane, N, RS, sweep_worker);
+#else
+                    rowpar_factor_fast_c(lane, N, RS, sweep_worker);
+#endif
+                } else rowpar_factor_fast(lane, N, RS, sweep_worker);
 #endif
                 __syncthreads();
                 F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;
