@@ -681,29 +681,68 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const LT L, bool 
 // (s_waitcnt lgkmcnt(7) before a T block: the 4 accumulator requests and 3 stores younger than its W~ operands; lgkmcnt(10) before an M
 // block: 3 stores and the 7 requests of the next stage).  Two stages per loop pass (register sets a / b), the operands of a stage are
 // requested right after the T block of the stage before; an odd horizon ends with a single stage.  Fixed registers v100..v183.
-#define MPC_FACTOR_ASM \
-        "ds_read2_b64 v[116:119], %6 offset0:0 offset1:8\n" \
-        "ds_read2_b64 v[120:123], %6 offset0:16 offset1:24\n" \
-        "ds_read2_b64 v[124:127], %6 offset0:32 offset1:40\n" \
-        "ds_read2_b64 v[144:147], %0 offset0:41 offset1:49\n" \
-        "ds_read2_b64 v[148:151], %0 offset0:57 offset1:65\n" \
-        "ds_read_b64 v[152:153], %0 offset:584\n" \
-        "ds_read2_b64 v[100:103], %1 offset0:65 offset1:73\n" \
-        "ds_read2_b64 v[104:107], %1 offset0:81 offset1:89\n" \
-        "ds_read2_b64 v[108:111], %1 offset0:97 offset1:105\n" \
-        "ds_read2_b64 v[112:115], %1 offset0:113 offset1:121\n" \
+// per-layout pieces of the text below: MPC_FACTOR_ASM_T(FAD) = dense blocks (RowLds), MPC_FACTOR_ASM_T(FAC) = compact blocks (RowLdsC)
+#define FAD_D5 "%5"
+#define FAD_HN "%6"
+#define FAD_ODD "%7"
+#define FAD_W_U01 "%0 offset0:41 offset1:49"
+#define FAD_W_U23 "%0 offset0:57 offset1:65"
+#define FAD_W_U4 "%0 offset:584"
+#define FAD_W_L23 "%0 offset0:16 offset1:24"
+#define FAD_W_L4 "%0 offset:256"
+#define FAD_H_U01 "%1 offset0:65 offset1:73"
+#define FAD_H_U23 "%1 offset0:81 offset1:89"
+#define FAD_H_U45 "%1 offset0:97 offset1:105"
+#define FAD_H_U67 "%1 offset0:113 offset1:121"
+#define FAD_H_L67 "%1 offset0:48 offset1:56"
+#define FAD_K_U "offset0:65 offset1:73"
+#define FAD_F_U "offset0:65 offset1:66"
+#define FAD_F_U8 "offset:584"
+#define FAD_W_DEC "0xfffffd70"
+#define FAD_H_DEC "0xfffffbf0"
+#define FAD_MORE_DEC ""
+#define FAC_D5 "%8"
+#define FAC_HN "%9"
+#define FAC_ODD "%10"
+#define FAC_W_U01 "%0 offset0:21 offset1:29"
+#define FAC_W_U23 "%5 offset0:0 offset1:1"
+#define FAC_W_U4 "%5 offset:16"
+#define FAC_W_L23 "%6 offset0:0 offset1:1"
+#define FAC_W_L4 "%6 offset:16"
+#define FAC_H_U01 "%1 offset0:57 offset1:65"
+#define FAC_H_U23 "%1 offset0:73 offset1:81"
+#define FAC_H_U45 "%1 offset0:89 offset1:97"
+#define FAC_H_U67 "%7 offset0:57 offset1:58"
+#define FAC_H_L67 "%7 offset0:0 offset1:1"
+#define FAC_K_U "offset0:57 offset1:65"
+#define FAC_F_U "offset0:57 offset1:58"
+#define FAC_F_U8 "offset:520"
+#define FAC_W_DEC "0xfffffeb0"
+#define FAC_H_DEC "0xfffffc70"
+#define FAC_MORE_DEC "v_add_u32_e32 %5, %11, %5\nv_add_u32_e32 %6, %11, %6\nv_add_u32_e32 %7, 0xfffffc70, %7\n"
+#define MPC_FACTOR_ASM_T(V) \
+        "ds_read2_b64 v[116:119], " V##_HN " offset0:0 offset1:8\n" \
+        "ds_read2_b64 v[120:123], " V##_HN " offset0:16 offset1:24\n" \
+        "ds_read2_b64 v[124:127], " V##_HN " offset0:32 offset1:40\n" \
+        "ds_read2_b64 v[144:147], " V##_W_U01 "\n" \
+        "ds_read2_b64 v[148:151], " V##_W_U23 "\n" \
+        "ds_read_b64 v[152:153], " V##_W_U4 "\n" \
+        "ds_read2_b64 v[100:103], " V##_H_U01 "\n" \
+        "ds_read2_b64 v[104:107], " V##_H_U23 "\n" \
+        "ds_read2_b64 v[108:111], " V##_H_U45 "\n" \
+        "ds_read2_b64 v[112:115], " V##_H_U67 "\n" \
         "s_waitcnt lgkmcnt(0)\n" \
         "s_nop 4\n" \
         "s_cmp_eq_u32 %4, 0\n" \
         "s_cbranch_scc1 2f\n" \
         "1:\n" \
         "s_waitcnt lgkmcnt(7)\n" \
-        "v_mul_f64 v[132:133], v[116:117], %5\n" \
-        "v_mul_f64 v[134:135], v[118:119], %5\n" \
-        "v_mul_f64 v[136:137], v[120:121], %5\n" \
-        "v_mul_f64 v[138:139], v[122:123], %5\n" \
-        "v_mul_f64 v[140:141], v[124:125], %5\n" \
-        "v_mul_f64 v[142:143], v[126:127], %5\n" \
+        "v_mul_f64 v[132:133], v[116:117], " V##_D5 "\n" \
+        "v_mul_f64 v[134:135], v[118:119], " V##_D5 "\n" \
+        "v_mul_f64 v[136:137], v[120:121], " V##_D5 "\n" \
+        "v_mul_f64 v[138:139], v[122:123], " V##_D5 "\n" \
+        "v_mul_f64 v[140:141], v[124:125], " V##_D5 "\n" \
+        "v_mul_f64 v[142:143], v[126:127], " V##_D5 "\n" \
         "s_nop 1\n" \
         "v_fmac_f64_dpp v[132:133], v[116:117], v[144:145] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
         "v_fmac_f64_dpp v[134:135], v[116:117], v[144:145] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
@@ -736,12 +775,12 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const LT L, bool 
         "v_fmac_f64_dpp v[140:141], v[124:125], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
         "v_fmac_f64_dpp v[142:143], v[124:125], v[152:153] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
         "ds_read2_b64 v[154:157], %0 offset0:0 offset1:8\n" \
-        "ds_read2_b64 v[158:161], %0 offset0:16 offset1:24\n" \
-        "ds_read_b64 v[162:163], %0 offset:256\n" \
+        "ds_read2_b64 v[158:161], " V##_W_L23 "\n" \
+        "ds_read_b64 v[162:163], " V##_W_L4 "\n" \
         "ds_read2_b64 v[116:119], %1 offset0:0 offset1:8\n" \
         "ds_read2_b64 v[120:123], %1 offset0:16 offset1:24\n" \
         "ds_read2_b64 v[124:127], %1 offset0:32 offset1:40\n" \
-        "ds_read2_b64 v[128:131], %1 offset0:48 offset1:56\n" \
+        "ds_read2_b64 v[128:131], " V##_H_L67 "\n" \
         "s_waitcnt lgkmcnt(10)\n" \
         "s_nop 1\n" \
         "v_fmac_f64_dpp v[112:113], v[144:145], v[132:133] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
@@ -788,9 +827,9 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const LT L, bool 
         "v_fmac_f64_dpp v[110:111], v[152:153], v[140:141] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
         "v_fma_f64 v[164:165], -v[170:171], v[166:167], -v[180:181]\n" \
         "v_add_f64 v[110:111], v[110:111], v[142:143]\n" \
-        "ds_write2_b64 %2, v[164:165], v[166:167] offset0:65 offset1:73\n" \
-        "ds_write2_b64 %3, v[168:169], v[170:171] offset0:65 offset1:66\n" \
-        "ds_write_b64 %3, v[172:173] offset:584\n" \
+        "ds_write2_b64 %2, v[164:165], v[166:167] " V##_K_U "\n" \
+        "ds_write2_b64 %3, v[168:169], v[170:171] " V##_F_U "\n" \
+        "ds_write_b64 %3, v[172:173] " V##_F_U8 "\n" \
         "s_nop 1\n" \
         "v_fmac_f64_dpp v[100:101], v[112:113], v[164:165] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
         "v_fmac_f64_dpp v[102:103], v[112:113], v[164:165] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
@@ -805,12 +844,12 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const LT L, bool 
         "v_fmac_f64_dpp v[108:109], v[114:115], v[166:167] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
         "v_fmac_f64_dpp v[110:111], v[114:115], v[166:167] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
         "s_waitcnt lgkmcnt(7)\n" \
-        "v_mul_f64 v[132:133], v[100:101], %5\n" \
-        "v_mul_f64 v[134:135], v[102:103], %5\n" \
-        "v_mul_f64 v[136:137], v[104:105], %5\n" \
-        "v_mul_f64 v[138:139], v[106:107], %5\n" \
-        "v_mul_f64 v[140:141], v[108:109], %5\n" \
-        "v_mul_f64 v[142:143], v[110:111], %5\n" \
+        "v_mul_f64 v[132:133], v[100:101], " V##_D5 "\n" \
+        "v_mul_f64 v[134:135], v[102:103], " V##_D5 "\n" \
+        "v_mul_f64 v[136:137], v[104:105], " V##_D5 "\n" \
+        "v_mul_f64 v[138:139], v[106:107], " V##_D5 "\n" \
+        "v_mul_f64 v[140:141], v[108:109], " V##_D5 "\n" \
+        "v_mul_f64 v[142:143], v[110:111], " V##_D5 "\n" \
         "s_nop 1\n" \
         "v_fmac_f64_dpp v[132:133], v[100:101], v[154:155] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
         "v_fmac_f64_dpp v[134:135], v[100:101], v[154:155] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
@@ -842,15 +881,15 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const LT L, bool 
         "v_fmac_f64_dpp v[138:139], v[106:107], v[162:163] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
         "v_fmac_f64_dpp v[140:141], v[108:109], v[162:163] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
         "v_fmac_f64_dpp v[142:143], v[108:109], v[162:163] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_add_u32_e32 %0, 0xfffffd70, %0\n" \
-        "v_add_u32_e32 %1, 0xfffffbf0, %1\n" \
-        "ds_read2_b64 v[144:147], %0 offset0:41 offset1:49\n" \
-        "ds_read2_b64 v[148:151], %0 offset0:57 offset1:65\n" \
-        "ds_read_b64 v[152:153], %0 offset:584\n" \
-        "ds_read2_b64 v[100:103], %1 offset0:65 offset1:73\n" \
-        "ds_read2_b64 v[104:107], %1 offset0:81 offset1:89\n" \
-        "ds_read2_b64 v[108:111], %1 offset0:97 offset1:105\n" \
-        "ds_read2_b64 v[112:115], %1 offset0:113 offset1:121\n" \
+        "v_add_u32_e32 %0, " V##_W_DEC ", %0\n" \
+        "v_add_u32_e32 %1, " V##_H_DEC ", %1\n" V##_MORE_DEC \
+        "ds_read2_b64 v[144:147], " V##_W_U01 "\n" \
+        "ds_read2_b64 v[148:151], " V##_W_U23 "\n" \
+        "ds_read_b64 v[152:153], " V##_W_U4 "\n" \
+        "ds_read2_b64 v[100:103], " V##_H_U01 "\n" \
+        "ds_read2_b64 v[104:107], " V##_H_U23 "\n" \
+        "ds_read2_b64 v[108:111], " V##_H_U45 "\n" \
+        "ds_read2_b64 v[112:115], " V##_H_U67 "\n" \
         "s_waitcnt lgkmcnt(10)\n" \
         "s_nop 1\n" \
         "v_fmac_f64_dpp v[128:129], v[154:155], v[132:133] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
@@ -900,8 +939,8 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const LT L, bool 
         "ds_write2_b64 %2, v[164:165], v[166:167] offset0:0 offset1:8\n" \
         "ds_write2_b64 %3, v[168:169], v[170:171] offset0:0 offset1:1\n" \
         "ds_write_b64 %3, v[172:173] offset:64\n" \
-        "v_add_u32_e32 %2, 0xfffffbf0, %2\n" \
-        "v_add_u32_e32 %3, 0xfffffbf0, %3\n" \
+        "v_add_u32_e32 %2, " V##_H_DEC ", %2\n" \
+        "v_add_u32_e32 %3, " V##_H_DEC ", %3\n" \
         "s_nop 1\n" \
         "v_fmac_f64_dpp v[116:117], v[128:129], v[164:165] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
         "v_fmac_f64_dpp v[118:119], v[128:129], v[164:165] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
@@ -919,15 +958,15 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const LT L, bool 
         "s_cmp_lg_u32 %4, 0\n" \
         "s_cbranch_scc1 1b\n" \
         "2:\n" \
-        "s_cmp_eq_u32 %7, 0\n" \
+        "s_cmp_eq_u32 " V##_ODD ", 0\n" \
         "s_cbranch_scc1 3f\n" \
         "s_waitcnt lgkmcnt(7)\n" \
-        "v_mul_f64 v[132:133], v[116:117], %5\n" \
-        "v_mul_f64 v[134:135], v[118:119], %5\n" \
-        "v_mul_f64 v[136:137], v[120:121], %5\n" \
-        "v_mul_f64 v[138:139], v[122:123], %5\n" \
-        "v_mul_f64 v[140:141], v[124:125], %5\n" \
-        "v_mul_f64 v[142:143], v[126:127], %5\n" \
+        "v_mul_f64 v[132:133], v[116:117], " V##_D5 "\n" \
+        "v_mul_f64 v[134:135], v[118:119], " V##_D5 "\n" \
+        "v_mul_f64 v[136:137], v[120:121], " V##_D5 "\n" \
+        "v_mul_f64 v[138:139], v[122:123], " V##_D5 "\n" \
+        "v_mul_f64 v[140:141], v[124:125], " V##_D5 "\n" \
+        "v_mul_f64 v[142:143], v[126:127], " V##_D5 "\n" \
         "s_nop 1\n" \
         "v_fmac_f64_dpp v[132:133], v[116:117], v[144:145] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
         "v_fmac_f64_dpp v[134:135], v[116:117], v[144:145] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
@@ -1005,9 +1044,9 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const LT L, bool 
         "v_fmac_f64_dpp v[110:111], v[152:153], v[140:141] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
         "v_fma_f64 v[164:165], -v[170:171], v[166:167], -v[180:181]\n" \
         "v_add_f64 v[110:111], v[110:111], v[142:143]\n" \
-        "ds_write2_b64 %2, v[164:165], v[166:167] offset0:65 offset1:73\n" \
-        "ds_write2_b64 %3, v[168:169], v[170:171] offset0:65 offset1:66\n" \
-        "ds_write_b64 %3, v[172:173] offset:584\n" \
+        "ds_write2_b64 %2, v[164:165], v[166:167] " V##_K_U "\n" \
+        "ds_write2_b64 %3, v[168:169], v[170:171] " V##_F_U "\n" \
+        "ds_write_b64 %3, v[172:173] " V##_F_U8 "\n" \
         "s_nop 1\n" \
         "v_fmac_f64_dpp v[100:101], v[112:113], v[164:165] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
         "v_fmac_f64_dpp v[102:103], v[112:113], v[164:165] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
@@ -1024,357 +1063,12 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const LT L, bool 
         "3:\n" \
         "s_waitcnt lgkmcnt(0)\n"
 
-// THE SAME ONE-BLOCK SWEEP ON THE COMPACT STAGE BLOCKS (RowLdsC; text derived mechanically from MPC_FACTOR_ASM: same instructions, same registers, same
+// THE SAME ONE-BLOCK SWEEP ON THE COMPACT STAGE BLOCKS (RowLdsC; the FAC_ pieces of the text above: same instructions, same registers, same
 // wait counts -- the W~ and H~aug operands arrive through the same number of requests).  What differs: the offsets (21 + 57 words per stage), rows 2..4 of W~
 // through two per-lane pointers (%5 upper / %6 lower stage of a pair; lane 5 walks the b_t words of the stage blocks with the per-lane stride %11, the other
 // lanes stay on the wavefront's constant table), rows 6, 7 of H~aug through the per-lane pointer %7 (rti_kernel.hpp, RowLdsC).
-#define MPC_FACTOR_ASM_C \
-        "ds_read2_b64 v[116:119], %9 offset0:0 offset1:8\n" \
-        "ds_read2_b64 v[120:123], %9 offset0:16 offset1:24\n" \
-        "ds_read2_b64 v[124:127], %9 offset0:32 offset1:40\n" \
-        "ds_read2_b64 v[144:147], %0 offset0:21 offset1:29\n" \
-        "ds_read2_b64 v[148:151], %5 offset0:0 offset1:1\n" \
-        "ds_read_b64 v[152:153], %5 offset:16\n" \
-        "ds_read2_b64 v[100:103], %1 offset0:57 offset1:65\n" \
-        "ds_read2_b64 v[104:107], %1 offset0:73 offset1:81\n" \
-        "ds_read2_b64 v[108:111], %1 offset0:89 offset1:97\n" \
-        "ds_read2_b64 v[112:115], %7 offset0:57 offset1:58\n" \
-        "s_waitcnt lgkmcnt(0)\n" \
-        "s_nop 4\n" \
-        "s_cmp_eq_u32 %4, 0\n" \
-        "s_cbranch_scc1 2f\n" \
-        "1:\n" \
-        "s_waitcnt lgkmcnt(7)\n" \
-        "v_mul_f64 v[132:133], v[116:117], %8\n" \
-        "v_mul_f64 v[134:135], v[118:119], %8\n" \
-        "v_mul_f64 v[136:137], v[120:121], %8\n" \
-        "v_mul_f64 v[138:139], v[122:123], %8\n" \
-        "v_mul_f64 v[140:141], v[124:125], %8\n" \
-        "v_mul_f64 v[142:143], v[126:127], %8\n" \
-        "s_nop 1\n" \
-        "v_fmac_f64_dpp v[132:133], v[116:117], v[144:145] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[134:135], v[116:117], v[144:145] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[136:137], v[116:117], v[144:145] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[138:139], v[116:117], v[144:145] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[140:141], v[116:117], v[144:145] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[142:143], v[116:117], v[144:145] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[132:133], v[116:117], v[146:147] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[134:135], v[118:119], v[146:147] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[136:137], v[118:119], v[146:147] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[138:139], v[118:119], v[146:147] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[140:141], v[118:119], v[146:147] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[142:143], v[118:119], v[146:147] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[132:133], v[116:117], v[148:149] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[134:135], v[118:119], v[148:149] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[136:137], v[120:121], v[148:149] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[138:139], v[120:121], v[148:149] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[140:141], v[120:121], v[148:149] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[142:143], v[120:121], v[148:149] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[132:133], v[116:117], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[134:135], v[118:119], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[136:137], v[120:121], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[138:139], v[122:123], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[140:141], v[122:123], v[150:151] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[142:143], v[122:123], v[150:151] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[132:133], v[116:117], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[134:135], v[118:119], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[136:137], v[120:121], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[138:139], v[122:123], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[140:141], v[124:125], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[142:143], v[124:125], v[152:153] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "ds_read2_b64 v[154:157], %0 offset0:0 offset1:8\n" \
-        "ds_read2_b64 v[158:161], %6 offset0:0 offset1:1\n" \
-        "ds_read_b64 v[162:163], %6 offset:16\n" \
-        "ds_read2_b64 v[116:119], %1 offset0:0 offset1:8\n" \
-        "ds_read2_b64 v[120:123], %1 offset0:16 offset1:24\n" \
-        "ds_read2_b64 v[124:127], %1 offset0:32 offset1:40\n" \
-        "ds_read2_b64 v[128:131], %7 offset0:0 offset1:1\n" \
-        "s_waitcnt lgkmcnt(10)\n" \
-        "s_nop 1\n" \
-        "v_fmac_f64_dpp v[112:113], v[144:145], v[132:133] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[114:115], v[144:145], v[132:133] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[112:113], v[146:147], v[134:135] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[114:115], v[146:147], v[134:135] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[114:115], v[148:149], v[136:137] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[112:113], v[150:151], v[138:139] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[114:115], v[152:153], v[140:141] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[100:101], v[144:145], v[132:133] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[104:105], v[144:145], v[132:133] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_mov_b64_dpp v[174:175], v[112:113] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
-        "v_mov_b64_dpp v[176:177], v[112:113] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
-        "v_mov_b64_dpp v[178:179], v[114:115] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[106:107], v[144:145], v[132:133] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_rcp_f64_e32 v[182:183], v[174:175]\n" \
-        "v_fmac_f64_dpp v[108:109], v[144:145], v[132:133] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[180:181], -v[174:175], v[182:183], 1.0\n" \
-        "v_fmac_f64_dpp v[110:111], v[144:145], v[132:133] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[182:183], v[180:181], v[182:183], v[182:183]\n" \
-        "v_fmac_f64_dpp v[102:103], v[146:147], v[134:135] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[180:181], -v[174:175], v[182:183], 1.0\n" \
-        "v_fmac_f64_dpp v[104:105], v[146:147], v[134:135] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[168:169], v[180:181], v[182:183], v[182:183]\n" \
-        "v_fmac_f64_dpp v[106:107], v[146:147], v[134:135] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_mul_f64 v[170:171], v[176:177], v[168:169]\n" \
-        "v_fmac_f64_dpp v[108:109], v[146:147], v[134:135] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[178:179], -v[170:171], v[176:177], v[178:179]\n" \
-        "v_fmac_f64_dpp v[110:111], v[146:147], v[134:135] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_rcp_f64_e32 v[182:183], v[178:179]\n" \
-        "v_fmac_f64_dpp v[104:105], v[148:149], v[136:137] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[180:181], -v[178:179], v[182:183], 1.0\n" \
-        "v_fmac_f64_dpp v[108:109], v[148:149], v[136:137] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[182:183], v[180:181], v[182:183], v[182:183]\n" \
-        "v_fmac_f64_dpp v[110:111], v[148:149], v[136:137] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[180:181], -v[178:179], v[182:183], 1.0\n" \
-        "v_fmac_f64_dpp v[106:107], v[150:151], v[138:139] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[172:173], v[180:181], v[182:183], v[182:183]\n" \
-        "v_fmac_f64_dpp v[110:111], v[150:151], v[138:139] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[180:181], v[170:171], v[112:113], -v[114:115]\n" \
-        "v_fmac_f64_dpp v[108:109], v[152:153], v[140:141] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_mul_f64 v[166:167], v[180:181], v[172:173]\n" \
-        "v_mul_f64 v[180:181], v[112:113], v[168:169]\n" \
-        "v_fmac_f64_dpp v[110:111], v[152:153], v[140:141] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[164:165], -v[170:171], v[166:167], -v[180:181]\n" \
-        "v_add_f64 v[110:111], v[110:111], v[142:143]\n" \
-        "ds_write2_b64 %2, v[164:165], v[166:167] offset0:57 offset1:65\n" \
-        "ds_write2_b64 %3, v[168:169], v[170:171] offset0:57 offset1:58\n" \
-        "ds_write_b64 %3, v[172:173] offset:520\n" \
-        "s_nop 1\n" \
-        "v_fmac_f64_dpp v[100:101], v[112:113], v[164:165] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[102:103], v[112:113], v[164:165] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[104:105], v[112:113], v[164:165] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[106:107], v[112:113], v[164:165] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[108:109], v[112:113], v[164:165] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[110:111], v[112:113], v[164:165] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[100:101], v[114:115], v[166:167] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[102:103], v[114:115], v[166:167] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[104:105], v[114:115], v[166:167] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[106:107], v[114:115], v[166:167] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[108:109], v[114:115], v[166:167] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[110:111], v[114:115], v[166:167] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "s_waitcnt lgkmcnt(7)\n" \
-        "v_mul_f64 v[132:133], v[100:101], %8\n" \
-        "v_mul_f64 v[134:135], v[102:103], %8\n" \
-        "v_mul_f64 v[136:137], v[104:105], %8\n" \
-        "v_mul_f64 v[138:139], v[106:107], %8\n" \
-        "v_mul_f64 v[140:141], v[108:109], %8\n" \
-        "v_mul_f64 v[142:143], v[110:111], %8\n" \
-        "s_nop 1\n" \
-        "v_fmac_f64_dpp v[132:133], v[100:101], v[154:155] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[134:135], v[100:101], v[154:155] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[136:137], v[100:101], v[154:155] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[138:139], v[100:101], v[154:155] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[140:141], v[100:101], v[154:155] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[142:143], v[100:101], v[154:155] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[132:133], v[100:101], v[156:157] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[134:135], v[102:103], v[156:157] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[136:137], v[102:103], v[156:157] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[138:139], v[102:103], v[156:157] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[140:141], v[102:103], v[156:157] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[142:143], v[102:103], v[156:157] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[132:133], v[100:101], v[158:159] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[134:135], v[102:103], v[158:159] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[136:137], v[104:105], v[158:159] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[138:139], v[104:105], v[158:159] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[140:141], v[104:105], v[158:159] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[142:143], v[104:105], v[158:159] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[132:133], v[100:101], v[160:161] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[134:135], v[102:103], v[160:161] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[136:137], v[104:105], v[160:161] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[138:139], v[106:107], v[160:161] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[140:141], v[106:107], v[160:161] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[142:143], v[106:107], v[160:161] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[132:133], v[100:101], v[162:163] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[134:135], v[102:103], v[162:163] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[136:137], v[104:105], v[162:163] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[138:139], v[106:107], v[162:163] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[140:141], v[108:109], v[162:163] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[142:143], v[108:109], v[162:163] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_add_u32_e32 %0, 0xfffffeb0, %0\n" \
-        "v_add_u32_e32 %1, 0xfffffc70, %1\n" \
-        "v_add_u32_e32 %5, %11, %5\n" \
-        "v_add_u32_e32 %6, %11, %6\n" \
-        "v_add_u32_e32 %7, 0xfffffc70, %7\n" \
-        "ds_read2_b64 v[144:147], %0 offset0:21 offset1:29\n" \
-        "ds_read2_b64 v[148:151], %5 offset0:0 offset1:1\n" \
-        "ds_read_b64 v[152:153], %5 offset:16\n" \
-        "ds_read2_b64 v[100:103], %1 offset0:57 offset1:65\n" \
-        "ds_read2_b64 v[104:107], %1 offset0:73 offset1:81\n" \
-        "ds_read2_b64 v[108:111], %1 offset0:89 offset1:97\n" \
-        "ds_read2_b64 v[112:115], %7 offset0:57 offset1:58\n" \
-        "s_waitcnt lgkmcnt(10)\n" \
-        "s_nop 1\n" \
-        "v_fmac_f64_dpp v[128:129], v[154:155], v[132:133] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[130:131], v[154:155], v[132:133] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[128:129], v[156:157], v[134:135] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[130:131], v[156:157], v[134:135] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[130:131], v[158:159], v[136:137] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[128:129], v[160:161], v[138:139] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[130:131], v[162:163], v[140:141] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[116:117], v[154:155], v[132:133] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[120:121], v[154:155], v[132:133] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_mov_b64_dpp v[174:175], v[128:129] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
-        "v_mov_b64_dpp v[176:177], v[128:129] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
-        "v_mov_b64_dpp v[178:179], v[130:131] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[122:123], v[154:155], v[132:133] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_rcp_f64_e32 v[182:183], v[174:175]\n" \
-        "v_fmac_f64_dpp v[124:125], v[154:155], v[132:133] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[180:181], -v[174:175], v[182:183], 1.0\n" \
-        "v_fmac_f64_dpp v[126:127], v[154:155], v[132:133] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[182:183], v[180:181], v[182:183], v[182:183]\n" \
-        "v_fmac_f64_dpp v[118:119], v[156:157], v[134:135] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[180:181], -v[174:175], v[182:183], 1.0\n" \
-        "v_fmac_f64_dpp v[120:121], v[156:157], v[134:135] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[168:169], v[180:181], v[182:183], v[182:183]\n" \
-        "v_fmac_f64_dpp v[122:123], v[156:157], v[134:135] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_mul_f64 v[170:171], v[176:177], v[168:169]\n" \
-        "v_fmac_f64_dpp v[124:125], v[156:157], v[134:135] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[178:179], -v[170:171], v[176:177], v[178:179]\n" \
-        "v_fmac_f64_dpp v[126:127], v[156:157], v[134:135] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_rcp_f64_e32 v[182:183], v[178:179]\n" \
-        "v_fmac_f64_dpp v[120:121], v[158:159], v[136:137] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[180:181], -v[178:179], v[182:183], 1.0\n" \
-        "v_fmac_f64_dpp v[124:125], v[158:159], v[136:137] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[182:183], v[180:181], v[182:183], v[182:183]\n" \
-        "v_fmac_f64_dpp v[126:127], v[158:159], v[136:137] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[180:181], -v[178:179], v[182:183], 1.0\n" \
-        "v_fmac_f64_dpp v[122:123], v[160:161], v[138:139] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[172:173], v[180:181], v[182:183], v[182:183]\n" \
-        "v_fmac_f64_dpp v[126:127], v[160:161], v[138:139] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[180:181], v[170:171], v[128:129], -v[130:131]\n" \
-        "v_fmac_f64_dpp v[124:125], v[162:163], v[140:141] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_mul_f64 v[166:167], v[180:181], v[172:173]\n" \
-        "v_mul_f64 v[180:181], v[128:129], v[168:169]\n" \
-        "v_fmac_f64_dpp v[126:127], v[162:163], v[140:141] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[164:165], -v[170:171], v[166:167], -v[180:181]\n" \
-        "v_add_f64 v[126:127], v[126:127], v[142:143]\n" \
-        "ds_write2_b64 %2, v[164:165], v[166:167] offset0:0 offset1:8\n" \
-        "ds_write2_b64 %3, v[168:169], v[170:171] offset0:0 offset1:1\n" \
-        "ds_write_b64 %3, v[172:173] offset:64\n" \
-        "v_add_u32_e32 %2, 0xfffffc70, %2\n" \
-        "v_add_u32_e32 %3, 0xfffffc70, %3\n" \
-        "s_nop 1\n" \
-        "v_fmac_f64_dpp v[116:117], v[128:129], v[164:165] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[118:119], v[128:129], v[164:165] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[120:121], v[128:129], v[164:165] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[122:123], v[128:129], v[164:165] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[124:125], v[128:129], v[164:165] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[126:127], v[128:129], v[164:165] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[116:117], v[130:131], v[166:167] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[118:119], v[130:131], v[166:167] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[120:121], v[130:131], v[166:167] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[122:123], v[130:131], v[166:167] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[124:125], v[130:131], v[166:167] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[126:127], v[130:131], v[166:167] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "s_sub_u32 %4, %4, 1\n" \
-        "s_cmp_lg_u32 %4, 0\n" \
-        "s_cbranch_scc1 1b\n" \
-        "2:\n" \
-        "s_cmp_eq_u32 %10, 0\n" \
-        "s_cbranch_scc1 3f\n" \
-        "s_waitcnt lgkmcnt(7)\n" \
-        "v_mul_f64 v[132:133], v[116:117], %8\n" \
-        "v_mul_f64 v[134:135], v[118:119], %8\n" \
-        "v_mul_f64 v[136:137], v[120:121], %8\n" \
-        "v_mul_f64 v[138:139], v[122:123], %8\n" \
-        "v_mul_f64 v[140:141], v[124:125], %8\n" \
-        "v_mul_f64 v[142:143], v[126:127], %8\n" \
-        "s_nop 1\n" \
-        "v_fmac_f64_dpp v[132:133], v[116:117], v[144:145] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[134:135], v[116:117], v[144:145] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[136:137], v[116:117], v[144:145] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[138:139], v[116:117], v[144:145] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[140:141], v[116:117], v[144:145] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[142:143], v[116:117], v[144:145] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[132:133], v[116:117], v[146:147] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[134:135], v[118:119], v[146:147] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[136:137], v[118:119], v[146:147] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[138:139], v[118:119], v[146:147] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[140:141], v[118:119], v[146:147] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[142:143], v[118:119], v[146:147] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[132:133], v[116:117], v[148:149] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[134:135], v[118:119], v[148:149] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[136:137], v[120:121], v[148:149] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[138:139], v[120:121], v[148:149] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[140:141], v[120:121], v[148:149] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[142:143], v[120:121], v[148:149] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[132:133], v[116:117], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[134:135], v[118:119], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[136:137], v[120:121], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[138:139], v[122:123], v[150:151] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[140:141], v[122:123], v[150:151] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[142:143], v[122:123], v[150:151] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[132:133], v[116:117], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[134:135], v[118:119], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[136:137], v[120:121], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[138:139], v[122:123], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[140:141], v[124:125], v[152:153] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[142:143], v[124:125], v[152:153] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "s_waitcnt lgkmcnt(3)\n" \
-        "s_nop 1\n" \
-        "v_fmac_f64_dpp v[112:113], v[144:145], v[132:133] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[114:115], v[144:145], v[132:133] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[112:113], v[146:147], v[134:135] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[114:115], v[146:147], v[134:135] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[114:115], v[148:149], v[136:137] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[112:113], v[150:151], v[138:139] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[114:115], v[152:153], v[140:141] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[100:101], v[144:145], v[132:133] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[104:105], v[144:145], v[132:133] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_mov_b64_dpp v[174:175], v[112:113] row_newbcast:6 row_mask:0xf bank_mask:0xf\n" \
-        "v_mov_b64_dpp v[176:177], v[112:113] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
-        "v_mov_b64_dpp v[178:179], v[114:115] row_newbcast:7 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[106:107], v[144:145], v[132:133] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_rcp_f64_e32 v[182:183], v[174:175]\n" \
-        "v_fmac_f64_dpp v[108:109], v[144:145], v[132:133] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[180:181], -v[174:175], v[182:183], 1.0\n" \
-        "v_fmac_f64_dpp v[110:111], v[144:145], v[132:133] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[182:183], v[180:181], v[182:183], v[182:183]\n" \
-        "v_fmac_f64_dpp v[102:103], v[146:147], v[134:135] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[180:181], -v[174:175], v[182:183], 1.0\n" \
-        "v_fmac_f64_dpp v[104:105], v[146:147], v[134:135] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[168:169], v[180:181], v[182:183], v[182:183]\n" \
-        "v_fmac_f64_dpp v[106:107], v[146:147], v[134:135] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_mul_f64 v[170:171], v[176:177], v[168:169]\n" \
-        "v_fmac_f64_dpp v[108:109], v[146:147], v[134:135] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[178:179], -v[170:171], v[176:177], v[178:179]\n" \
-        "v_fmac_f64_dpp v[110:111], v[146:147], v[134:135] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_rcp_f64_e32 v[182:183], v[178:179]\n" \
-        "v_fmac_f64_dpp v[104:105], v[148:149], v[136:137] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[180:181], -v[178:179], v[182:183], 1.0\n" \
-        "v_fmac_f64_dpp v[108:109], v[148:149], v[136:137] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[182:183], v[180:181], v[182:183], v[182:183]\n" \
-        "v_fmac_f64_dpp v[110:111], v[148:149], v[136:137] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[180:181], -v[178:179], v[182:183], 1.0\n" \
-        "v_fmac_f64_dpp v[106:107], v[150:151], v[138:139] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[172:173], v[180:181], v[182:183], v[182:183]\n" \
-        "v_fmac_f64_dpp v[110:111], v[150:151], v[138:139] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[180:181], v[170:171], v[112:113], -v[114:115]\n" \
-        "v_fmac_f64_dpp v[108:109], v[152:153], v[140:141] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_mul_f64 v[166:167], v[180:181], v[172:173]\n" \
-        "v_mul_f64 v[180:181], v[112:113], v[168:169]\n" \
-        "v_fmac_f64_dpp v[110:111], v[152:153], v[140:141] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fma_f64 v[164:165], -v[170:171], v[166:167], -v[180:181]\n" \
-        "v_add_f64 v[110:111], v[110:111], v[142:143]\n" \
-        "ds_write2_b64 %2, v[164:165], v[166:167] offset0:57 offset1:65\n" \
-        "ds_write2_b64 %3, v[168:169], v[170:171] offset0:57 offset1:58\n" \
-        "ds_write_b64 %3, v[172:173] offset:520\n" \
-        "s_nop 1\n" \
-        "v_fmac_f64_dpp v[100:101], v[112:113], v[164:165] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[102:103], v[112:113], v[164:165] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[104:105], v[112:113], v[164:165] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[106:107], v[112:113], v[164:165] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[108:109], v[112:113], v[164:165] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[110:111], v[112:113], v[164:165] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[100:101], v[114:115], v[166:167] row_newbcast:0 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[102:103], v[114:115], v[166:167] row_newbcast:1 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[104:105], v[114:115], v[166:167] row_newbcast:2 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[106:107], v[114:115], v[166:167] row_newbcast:3 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[108:109], v[114:115], v[166:167] row_newbcast:4 row_mask:0xf bank_mask:0xf\n" \
-        "v_fmac_f64_dpp v[110:111], v[114:115], v[166:167] row_newbcast:5 row_mask:0xf bank_mask:0xf\n" \
-        "3:\n" \
-        "s_waitcnt lgkmcnt(0)\n"
-
-
+#define MPC_FACTOR_ASM MPC_FACTOR_ASM_T(FAD)
+#define MPC_FACTOR_ASM_C MPC_FACTOR_ASM_T(FAC)
 #define MPC_FACTOR_ASM_CLOBBERS "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "scc", "vcc", "memory"
 
 __device__ __forceinline__ void rowpar_factor_fast(int lane, int N, const RowLds L, bool worker_row)
