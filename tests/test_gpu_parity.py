@@ -329,17 +329,19 @@ def test_horizon_extremes_and_packing_boundaries(env, N):
 
 
 @pytest.mark.gpu
-def test_longest_horizon_with_ten_obstacles_takes_the_compact_stage_blocks(env):
+@pytest.mark.parametrize("N", [62, 49])
+def test_longest_horizon_with_ten_obstacles_takes_the_compact_stage_blocks(env, N):
     """N = 62 with 10 obstacles: the dense stage blocks plus the look-ahead staging would need ~66 KB of dynamic LDS per workgroup; the
     dispatcher takes the compact blocks instead (41 KB, look-ahead staged inside them, rti_solve_kernel<10, 64, 3>).  The result must match
-    the oracle"""
+    the oracle.  N = 49: an odd horizon on the compact blocks (the single-stage tail of the two-stages-per-pass asm sweep)"""
     mpc_gpu, orc = env
-    N, no, B = 62, 10, 6
+    no, B = 10, 6
     x0, goal, obst = random_batch(B, no, seed=977)
     cfg = orc.config(N, no, 0.1 * N)
     P = oracle_P(orc, cfg, obst); Xg, Ug = oracle_guess(orc, cfg, x0)
     o = orc.rti_solve_batch(cfg, x0, P, goal, Xg, Ug)
     with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
+        assert s.kernel_name(B) == "rti_solve_kernel<10, 64, 3>"
         s.reset_guess(x0); g = s.solve(x0, obst, goal); X, U = s.get_traj(B)     # obstacle states in: look-ahead staged in LDS
     assert (g["status"] == o["status"]).all()
     ok = o["status"] == 0
