@@ -1107,6 +1107,79 @@ __device__ __forceinline__ void rowpar_factor_fast_c(int lane, int N, const RowL
                  : "v"(d5), "v"(hN), "s"(odd), "v"(bstride) : MPC_FACTOR_ASM_CLOBBERS);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// THE FACTOR SWEEP ON THE MATRIX CORES, 4x4x4 BLOCKS (one instance per wavefront; dense stage blocks).  v_mfma_f64_4x4x4_4b multiplies four
+// independent 4 x 4 blocks per instruction: the 8 x 8 matrices of a stage are 2 x 2 blocks, block (I, J) in block slot q = 2 I + J.  Lane layouts
+// (scripts/bin_src/mfma4_test.hip, found by unit probes): A[q][i][k] in lane i + 4 q + 16 k, B[q][k][j] in lane j + 4 q + 16 k, C/D[q][i][j] in lane
+// j + 4 q + 16 i.  So a result register serves as a B operand as it is and as an A operand TRANSPOSED block by block, and a block slot is a
+// quad of a 16-lane DPP row: moving blocks between slots is a v_mov_b32_dpp row_shl / row_shr / row_ror by 4 or 8 lanes under a bank mask.
+// Per stage (same homogeneous formulation as rowpar_factor):
+//   T  = P~ W~            2 MFMAs   A: slot (I, J) <- P~(K, I) (as A: its transpose = P~(I, K), P~ symmetric);  B: W~(K, J) from LDS
+//   M~ = H~aug + W~' T    2 MFMAs   A: W~(K, I) from LDS (as A: transposed);  B: slot (I, J) <- T(K, J);  C: H~aug from LDS
+//   Muu -> L D L' on wave-uniform scalars (v_readlane), rows 6, 7 of M~ (DPP rows 2, 3 of block row 1) -> K~ after one v_permlane16_swap
+//   P~+ = M~ + M~[:, u] K~  1 MFMA  A: slot (I, J) <- M~(1, I) (transposed: columns 6, 7 of M~);  B: rows 2, 3 = K~ (slots replicated), rows 0, 1 zero
+// Rows / columns 6, 7 of P~ carry finite garbage: rows 6, 7 of the padded W~ are zero, so they never reach T's rows 0..5 or M~.
+// ------------------------------------------------------------------------------------------------------------------
+template <int CTRL, int BANKS>
+__device__ __forceinline__ double dpp_blocks(double old, double src)       // quads named by BANKS take src moved by CTRL, the others keep old
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xf, BANKS, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xf, BANKS, false);
+    return __hiloint2double(hi, lo);
+}
+// slot (I, J) <- block (0, I) of x: quads [0, 0, 1, 1];  block (1, I): quads [2, 2, 3, 3];  slot (I, J) <- block (K, J): [0, 1, 0, 1] / [2, 3, 2, 3]
+__device__ __forceinline__ double blocks_0011(double x) { return dpp_blocks<0x118, 0x8>(dpp_blocks<0x114, 0x6>(x, x), x); }     // row_shr:4 -> quads 1, 2; row_shr:8 -> quad 3
+__device__ __forceinline__ double blocks_2233(double x) { return dpp_blocks<0x108, 0x1>(dpp_blocks<0x104, 0x6>(x, x), x); }     // row_shl:4 -> quads 1, 2; row_shl:8 -> quad 0
+__device__ __forceinline__ double blocks_0101(double x) { return dpp_blocks<0x128, 0xc>(x, x); }                                // row_ror:8 -> quads 2, 3
+__device__ __forceinline__ double blocks_2323(double x) { return dpp_blocks<0x128, 0x3>(x, x); }                                // row_ror:8 -> quads 0, 1
+
+template <class LT>
+__device__ __forceinline__ void mfma4_factor(int lane, int N, const LT L)
+{
+    static_assert(!LT::COMPACT, "dense stage blocks");
+    constexpr int WS = LT::WS, HS = LT::HS;
+    const int dr = lane >> 4, I = (lane >> 3) & 1, J = (lane >> 2) & 1, jj = lane & 3;
+    const double *wb = L.W + dr * 8 + 4 * J + jj;              // W~(K, J)[dr][jj]: + 32 K
+    const double *wa = L.W + dr * 8 + 4 * I + jj;              // W~(K, I)[dr][jj]
+    const double *hd = L.H + (4 * I + dr) * 8 + 4 * J + jj;    // H~aug(I, J)[dr][jj]
+    const bool cst = dr >= 1;                                   // rows 5..7 of the padded W~: e_5', 0, 0
+    const double cwb = (dr == 1 && 4 * J + jj == 5) ? 1.0 : 0.0, cwa = (dr == 1 && 4 * I + jj == 5) ? 1.0 : 0.0;
+    const int c = 4 * J + jj;                                   // column of K~ this lane holds after the solve (DPP rows 2, 3, block row 1)
+    double *kp = L.R + ((I == 1 && c < 6 && dr >= 2) ? (dr == 2 ? c : 8 + c) : LT::DEADK);
+    double *fp = L.R + (lane == 0 ? 6 : (lane == 1 ? 7 : (lane == 2 ? 14 : LT::DEADF)));
+    double P = hd[HS * N];
+    double wb0 = wb[WS * (N - 1)], wb1 = wb[WS * (N - 1) + 32], wa0 = wa[WS * (N - 1)], wa1 = wa[WS * (N - 1) + 32], H = hd[HS * (N - 1)];
+    for (int t = N - 1; t >= 0; t--) {
+        const double b0 = wb0, b1 = cst ? cwb : wb1, a0 = wa0, a1 = cst ? cwa : wa1, Hc = H;
+        // operands of the stage in front (t - 1 = -1 reads the dead block in front of the instance's blocks)
+        wb0 = wb[WS * (t - 1)]; wb1 = wb[WS * (t - 1) + 32]; wa0 = wa[WS * (t - 1)]; wa1 = wa[WS * (t - 1) + 32]; H = hd[HS * (t - 1)];
+        double T = __builtin_amdgcn_mfma_f64_4x4x4f64(blocks_0011(P), b0, 0.0, 0, 0, 0);
+        T = __builtin_amdgcn_mfma_f64_4x4x4f64(blocks_2233(P), b1, T, 0, 0, 0);
+        double M = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, blocks_0101(T), Hc, 0, 0, 0);
+        M = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, blocks_2323(T), M, 0, 0, 0);
+        // Muu = M~[6..7][6..7]: block (1, 1), rows / columns 2, 3 -> lanes 46, 47, 63
+        const double m66 = lane_value(M, 46), m67 = lane_value(M, 47), m77 = lane_value(M, 63);
+        double i00 = __builtin_amdgcn_rcp(m66);
+        i00 = fma(fma(-m66, i00, 1.0), i00, i00); i00 = fma(fma(-m66, i00, 1.0), i00, i00);
+        const double l = m67 * i00;
+        const double d1 = fma(-l, m67, m77);
+        double i11 = __builtin_amdgcn_rcp(d1);
+        i11 = fma(fma(-d1, i11, 1.0), i11, i11); i11 = fma(fma(-d1, i11, 1.0), i11, i11);
+        // rows 6 (DPP row 2) and 7 (DPP row 3) of M~ side by side: v_permlane16_swap exchanges row 3 of its first with row 2 of its second operand
+        const auto slo = __builtin_amdgcn_permlane16_swap(__double2loint(M), __double2loint(M), false, false);
+        const auto shi = __builtin_amdgcn_permlane16_swap(__double2hiint(M), __double2hiint(M), false, false);
+        const double X = __hiloint2double(shi[0], slo[0]), Y = __hiloint2double(shi[1], slo[1]);      // X: row 3 <- row 2 (M~[6][.]);  Y: row 2 <- row 3 (M~[7][.])
+        const double g0 = dr == 3 ? X : M, g1 = dr == 3 ? M : Y;
+        const double K1 = fma(l, g0, -g1) * i11;
+        const double K0 = fma(-l, K1, -(g0 * i00));
+        const double Kr = dr == 2 ? K0 : K1;
+        const double Kb = blocks_2323(dr >= 2 ? Kr : 0.0);
+        P = __builtin_amdgcn_mfma_f64_4x4x4f64(blocks_2233(M), Kb, M, 0, 0, 0);
+        kp[HS * t] = Kr;
+        fp[HS * t] = lane == 0 ? i00 : (lane == 1 ? l : i11);
+    }
+}
+
 // ROW-PARALLEL VECTOR RECURSIONS.  With the closed-loop matrix Acl_t = A_t + B_t K_t (5 x 5, computed by the lane that owns
 // stage t, for all stages at once) in LDS, the forward rollout  dx_{t+1} = Acl_t dx_t + c_t  and the backward (adjoint)
 // recursion  p_t = c~_t + Acl_t' p_{t+1}  are 5 x 5 matrix-vector products per stage: lane r of the instance's first DPP row
@@ -1983,7 +2056,12 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #else
                     rowpar_factor_fast_c(lane, N, RS, sweep_worker);
 #endif
-                } else rowpar_factor_fast(lane, N, RS, sweep_worker);
+                } else {
+#ifdef MPC_MFMA4
+                    if constexpr (G == 64) mfma4_factor(lane, N, RS); else
+#endif
+                    rowpar_factor_fast(lane, N, RS, sweep_worker);
+                }
 #endif
                 __syncthreads();
                 F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;

@@ -436,6 +436,9 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
         MPC_TICK(9);
         // (the one-block asm variant rowpar_factor_fast saves 12 instructions per stage but claims 84 fixed registers: here, where the row
         // state lives in VGPRs next to the sweep, the extra AGPR round trips cost more than it gains -- measured 150.7 vs 148.0 us at C2)
+#ifdef MPC_MFMA4
+        if constexpr (!W2) mfma4_factor(lane, N, RL); else
+#endif
         rowpar_factor(lane, N, RL, lane < 16);
         __syncthreads();
         StageFac F;
