@@ -1843,12 +1843,24 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     n_items_lane += vs ? (soft ? 2 * NOBST : NOBST) : 0;
     const double n_items = seg_sum<G>((double)n_items_lane, lane);
     const double inv_items = n_items > 0 ? 1.0 / n_items : 0.0;
+    {   // Non-finite inputs (a diverged plant, a bad sensor frame, a poisoned warm start) must not pass as a converged solve: fmax() drops NaN, so
+        // the residual norm above would not show them.  One sum over everything this lane read decides; the instance then fails at once (status 4).
+        double fin = gl[0] + gl[1] + ui[0] + ui[1];
+#pragma unroll
+        for (int c = 0; c < 5; c++) fin += x0v[c] + xi[c] + xnext[c];
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < NOBST; j++) fin += pos_x(j) + pos_y(j);
+        }
+        if (!(fabs(fin) <= 1e300)) lin0 = INFINITY;
+    }
     lin0 = seg_max<G>(lin0, lane);
 
     double z[7] = {0, 0, 0, 0, 0, 0, 0};
     double rhoPi = 1.0;
     int status = 2, it = 0, it_done = 0;
     bool running = !ep_done;  // per instance: instances sharing a wavefront stop at their own iteration and then idle
+    if (!(lin0 <= 1e300)) { status = 4; running = false; }
 
 #ifdef MPC_PHASE_TIMING
     long long tacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

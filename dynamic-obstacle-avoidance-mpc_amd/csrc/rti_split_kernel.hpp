@@ -163,6 +163,13 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
         }
     }
     const bool ep_done = (ep_word & 1) != 0;
+    // Non-finite inputs must not pass as a converged solve (fmax() drops NaN, so the residual norm would not show them): one sum over
+    // everything this lane read decides, the instance then fails at once (status 4) -- see rti_solve_kernel
+    double fin = gl[0] + gl[1] + ui[0] + ui[1];
+#pragma unroll
+    for (int c = 0; c < 5; c++) fin += x0v[c] + xi[c] + xnext[c];
+#pragma unroll
+    for (int s = 0; s < NSL; s++) fin += pxy[s][0] + pxy[s][1];
 
     MPC_TICK(11);
     // ---- slack schedule, robot_ocp_problem.py:145-152 ----
@@ -288,12 +295,14 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
     for (int s = 0; s < NSL; s++) n_items_lane += sp[s] ? (soft ? 2 : 1) : 0;
     const double n_items = seg_sum<64>((double)n_items_lane, lane);
     const double inv_items = n_items > 0 ? 1.0 / n_items : 0.0;
+    if (!(fabs(fin) <= 1e300)) lin0 = INFINITY;
     lin0 = seg_max<64>(lin0, lane);
 
     double z[7] = {0, 0, 0, 0, 0, 0, 0};
     double rhoPi = 1.0;
     int status = 2, it = 0, it_done = 0;
     bool running = !ep_done;
+    if (!(lin0 <= 1e300)) { status = 4; running = false; }
 
     MPC_TICK(13);
     for (it = 0;; it++) {

@@ -764,6 +764,21 @@ int orc_rti_solve_alpha(const orc_config *c, const double *x0, const double *P, 
                         double *X, double *U, double *u0, double *cost, int *iters, double *kkt)
 {
     int N = c->N;
+    {   /* non-finite inputs fail at once (status 4, iterate untouched): shared specification with the HIP kernels, which would otherwise
+         * lose a NaN in the fmax() of their residual norms */
+        double fin = goal[0] + goal[1];
+        for (int k = 0; k < 5; k++) fin += x0[k];
+        for (int k = 0; k < 5 * (N + 1); k++) fin += X[k];
+        for (int k = 0; k < 2 * N; k++) fin += U[k];
+        for (int k = 0; k < 2 * c->n_obst * (N + 1); k++) fin += P[k];
+        if (!(fabs(fin) <= 1e300)) {
+            if (u0) { u0[0] = U[0]; u0[1] = U[1]; }
+            if (cost) *cost = NAN;
+            if (iters) *iters = 0;
+            if (kkt) for (int a = 0; a < 4; a++) kkt[a] = NAN;
+            return 4;
+        }
+    }
     qp_t Q; build_qp(c, x0, P, goal, X, U, &Q, alpha);
     iter_t I;
     I.z = malloc(sizeof(double[NZ]) * (N + 1)); I.pi = malloc(sizeof(double[NX]) * (N + 1)); I.s = malloc(sizeof(double) * (Q.n_s + 1));

@@ -580,3 +580,35 @@ def test_instance_scheduling(env, G):
             assert same.mean() > 0.999
             d = np.abs(Xa - Xb).reshape(B, -1).max(1)[same & (gb["status"] == 0)]
             assert np.median(d) < 1e-11 and np.quantile(d, 0.999) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [0, 21, 32, 64])
+def test_non_finite_inputs_are_contained(built, lanes):
+    """NaN / Inf in one instance's x0, goal or obstacle state (a diverged plant, a bad sensor frame): that instance fails at once (status 4,
+    no iterations, iterate untouched -- fmax() in the residual norms would otherwise swallow the NaN and report convergence); every OTHER instance of the
+    batch -- including those sharing its wavefront (two or three instances per wavefront) -- is bit for bit what a clean batch gives."""
+    import mpc_gpu
+    mpc_gpu.BatchedMpc.default_lanes_per_stage = 0
+    N, no, B = 20, 3, 90
+    x0, goal, obst = random_batch(B, no, seed=4242)
+    bad = {7: ("x0", np.nan), 8: ("goal", np.inf), 30: ("obst", np.nan), 31: ("x0", -np.inf), 64: ("obst", np.inf)}
+    x0b, goalb, obstb = x0.copy(), goal.copy(), obst.copy()
+    for b, (what, v) in bad.items():
+        if what == "x0": x0b[b, 1] = v
+        elif what == "goal": goalb[b, 0] = v
+        else: obstb[b, 1, 3] = v          # vy: the look-ahead uses vy on both axes (defect D1), vx alone would never reach the solve
+    res = []
+    for xx, gg, oo in ((x0, goal, obst), (x0b, goalb, obstb)):
+        with mpc_gpu.BatchedMpc(N, no, 2.0, max_batch=B) as s:
+            if lanes: s.set_lanes_per_stage(1); s.set_lanes_per_instance(lanes)
+            s.reset_guess(x0); Xg, Ug = s.get_traj(B)
+            g = s.solve(xx, oo, gg); X, U = s.get_traj(B)
+            res.append((g, X, U))
+    (gc, Xc, Uc), (gb, Xb, Ub) = res
+    clean = np.array([b not in bad for b in range(B)])
+    assert np.array_equal(Xc[clean], Xb[clean]) and np.array_equal(Uc[clean], Ub[clean])
+    assert np.array_equal(gc["status"][clean], gb["status"][clean]) and np.array_equal(gc["iters"][clean], gb["iters"][clean])
+    for b in bad:
+        assert gb["status"][b] == 4 and gb["iters"][b] == 0, (b, gb["status"][b], gb["iters"][b])      # as the oracle (test_oracle_math.py)
+        assert np.array_equal(Xb[b], Xg[b]) and np.array_equal(Ub[b], Ug[b])                           # iterate untouched

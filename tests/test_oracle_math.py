@@ -167,3 +167,19 @@ def test_cost_definition(orc):
     v = -h
     want = 4 * 0.1 * 0.5 * (2 * 1.0 + 0.15 * 2) + 0.5 * 5 * 1.0 + sum(0.1 * a[i] * (v + 0.5 * v * v) for i in range(4))
     assert orc.cost(cfg, x0, P, goal, X, U) == pytest.approx(want, rel=1e-12)
+
+
+def test_non_finite_inputs_fail_with_status_4_and_leave_the_iterate(orc):
+    """shared specification with the HIP kernels (tests/test_gpu_parity.py::test_non_finite_inputs_are_contained)"""
+    cfg = orc.config(20, 3, 2.0)
+    x0 = np.array([-6.0, -6.0, 0.7, 0.0, 0.0]); goal = np.array([6.0, 6.0])
+    obst = np.array([[0.0, 0.0, 1.0, 0.5], [2.0, -3.0, -1.0, 0.2], [-3.0, 3.0, 0.0, 1.0]])
+    P = orc.predict_params(cfg, obst); X, U = orc.initial_guess(cfg, x0)
+    assert orc.rti_solve(cfg, x0, P, goal, X, U)["status"] == 0
+    for what in ("x0", "goal", "P", "X", "U"):
+        for v in (np.nan, np.inf, -np.inf):
+            a = dict(x0=x0.copy(), goal=goal.copy(), P=P.copy(), X=X.copy(), U=U.copy())
+            a[what].reshape(-1)[1] = v
+            r = orc.rti_solve(cfg, a["x0"], a["P"], a["goal"], a["X"], a["U"])
+            assert r["status"] == 4 and r["iters"] == 0
+            assert np.array_equal(r["X"], a["X"], equal_nan=True) and np.array_equal(r["U"], a["U"], equal_nan=True)
