@@ -60,11 +60,17 @@ struct mpc_handle {
 
 namespace {
 
+// Row capacity of the kernel instantiation that runs a problem with n obstacles (NOBST of rti_solve_kernel / rti_split_kernel), and whether
+// the problem leaves some of it unused (then only the mappings that take a run-time obstacle count are dispatched: the stage-split kernel for
+// N <= 31, one instance per wavefront with row-parallel sweeps beyond)
+int row_capacity(int n) { return n <= 3 ? 3 : (n <= 5 ? 5 : 10); }
+bool partial_rows(const mpc_handle *h);
+
 mpc::KParams make_params(const mpc_config &c, int batch)
 {
     mpc::KParams p;
     memset(&p, 0, sizeof(p));
-    p.N = c.N; p.batch = batch;
+    p.N = c.N; p.batch = batch; p.n_obst = c.n_obst;
     p.soft_h = c.soft_h; p.bx_terminal = c.bx_terminal; p.iter_max = c.qp_iter_max;
     p.dt = c.Tf / c.N; p.h2 = 0.5 * p.dt * p.dt;
     const double cs = c.cost_scale_dt ? p.dt : 1.0;
@@ -104,8 +110,11 @@ hipStream_t pick(mpc_handle *h, void *stream) { return stream ? (hipStream_t)str
 // Lanes per instance of the one-lane-per-stage mapping: the smallest of {16, 32, 64} with N + 1 < G (an idle lane separates instances that
 // share a wavefront), or 21 -- three instances per wavefront on compact LDS blocks -- for 16 <= N <= 20 once pick_split hands a large batch
 // to this mapping; unless overridden.  Packing instances into one wavefront multiplies throughput for large batches.
+bool partial_rows(const mpc_handle *h) { return row_capacity(h->cfg.n_obst) != h->cfg.n_obst; }
+
 int pick_lanes(mpc_handle *h, int batch)
 {
+    if (partial_rows(h)) return 64;
     const int need = h->cfg.N + 2;
     int G = need <= 16 ? 16 : (need <= 32 ? 32 : 64);
     // the matrix-core factorisation (opt-in, mpc_set_matrix_cores) maps one instance per wavefront; it is used for
@@ -137,9 +146,10 @@ int pick_lanes(mpc_handle *h, int batch)
 //   20 < N <= 31 beyond; with more obstacles the 256-register build spills 500 - 1150 bytes per lane and loses.
 int pick_split(mpc_handle *h, int batch)
 {
-    if (h->use_mfma || !h->row_parallel || h->lanes_override) return 1;
-    const int N = h->cfg.N, no = h->cfg.n_obst;
+    const int N = h->cfg.N, no = row_capacity(h->cfg.n_obst);
     const int fit = N <= 20 ? 3 : (N <= 31 ? 2 : 1);
+    if (partial_rows(h)) return (h->split_override > 1 && h->split_override <= fit) ? h->split_override : fit;
+    if (h->use_mfma || !h->row_parallel || h->lanes_override) return 1;
     if (h->split_override) return h->split_override <= fit ? h->split_override : fit;
     if (no != 10 && N + 2 <= 16 && batch > 12 * h->simd_count) return 1;                      // four instances per wavefront (G = 16)
     if (no != 10 && N + 2 > 16 && N <= 20 && batch > (no == 3 ? 8 : 12) * h->simd_count) return 1;   // three instances per wavefront (G = 21)
@@ -148,6 +158,7 @@ int pick_split(mpc_handle *h, int batch)
 
 int pick_waves(mpc_handle *h, int batch)
 {
+    if (partial_rows(h)) return 1;
     if (h->waves_override) return h->waves_override;
     return (h->cfg.n_obst == 3 && batch > 4 * h->simd_count) ? 2 : 1;
 }
@@ -166,28 +177,29 @@ int grant_lds(K kernel, int (&granted)[kMaxDevices], int device, size_t lds)
     return MPC_OK;
 }
 
-template <int NO, int LPS, bool W2>
+template <int NO, int LPS, bool W2, bool MASKED = false>
 int launch_split_w(mpc_handle *h, const mpc::KParams &p, hipStream_t s)
 {
     static int granted[kMaxDevices] = {};
     const size_t lds = (size_t)mpc::SplitLds<LPS, NO, W2>::total(p.N, p.obst != nullptr) * sizeof(double);
-    int rc = grant_lds(&mpc::rti_split_kernel<NO, LPS, W2>, granted, h->device, lds); if (rc) return rc;
-    hipLaunchKernelGGL((mpc::rti_split_kernel<NO, LPS, W2>), dim3(p.batch), dim3(64), lds, s, p);
+    int rc = grant_lds(&mpc::rti_split_kernel<NO, LPS, W2, MASKED>, granted, h->device, lds); if (rc) return rc;
+    hipLaunchKernelGGL((mpc::rti_split_kernel<NO, LPS, W2, MASKED>), dim3(p.batch), dim3(64), lds, s, p);
     return MPC_OK;
 }
 
 template <int NO, int LPS>
 int launch_split(mpc_handle *h, const mpc::KParams &p, hipStream_t s)
 {
+    if (p.n_obst != NO) return launch_split_w<NO, LPS, false, true>(h, p, s);      // fewer obstacles than rows: the run-time-count variant
     return pick_waves(h, p.batch) == 2 ? launch_split_w<NO, LPS, true>(h, p, s) : launch_split_w<NO, LPS, false>(h, p, s);
 }
 
-template <int NO, int G, int FACT>
+template <int NO, int G, int FACT, bool MASKED = false>
 int launch_one_lane(mpc_handle *h, const mpc::KParams &p, hipStream_t s, dim3 grid, size_t lds)
 {
     static int granted[kMaxDevices] = {};
-    int rc = grant_lds(&mpc::rti_solve_kernel<NO, G, FACT>, granted, h->device, lds); if (rc) return rc;
-    hipLaunchKernelGGL((mpc::rti_solve_kernel<NO, G, FACT>), grid, dim3(64), lds, s, p);
+    int rc = grant_lds(&mpc::rti_solve_kernel<NO, G, FACT, MASKED>, granted, h->device, lds); if (rc) return rc;
+    hipLaunchKernelGGL((mpc::rti_solve_kernel<NO, G, FACT, MASKED>), grid, dim3(64), lds, s, p);
     return MPC_OK;
 }
 
@@ -201,15 +213,15 @@ struct SolvePlan {
 SolvePlan plan_solve(mpc_handle *h, int batch, bool lookahead)
 {
     SolvePlan q = {1, 1, 64, 2, 0};
-    const int N = h->cfg.N, no = h->cfg.n_obst;
+    const int N = h->cfg.N, no = row_capacity(h->cfg.n_obst);
     q.lps = pick_split(h, batch);
     if (q.lps > 1) {
         q.waves = pick_waves(h, batch);
         return q;          // (the LDS size of a split launch is a compile-time function of the kernel's template arguments: launch_split_w)
     }
     q.G = pick_lanes(h, batch);
-    const bool use_mfma = (q.G == 64) && h->use_mfma;
-    const bool rowpar = !use_mfma && h->row_parallel;
+    const bool use_mfma = (q.G == 64) && h->use_mfma && !partial_rows(h);
+    const bool rowpar = (!use_mfma && h->row_parallel) || partial_rows(h);
     const int ipw = 64 / q.G;
     const size_t dense = ((lookahead ? (size_t)ipw * (N + 1) * no * 2 : 0) + (use_mfma ? (size_t)mpc::MfmaLds::doubles(N) : 0) +
                           (rowpar ? (size_t)mpc::RowLds::total(N, ipw) : 0)) * sizeof(double);
@@ -226,6 +238,11 @@ SolvePlan plan_solve(mpc_handle *h, int batch, bool lookahead)
 template <int NO>
 int launch_one_lane_g(mpc_handle *h, const mpc::KParams &p, hipStream_t s, dim3 grid, const SolvePlan &q)
 {
+    if (p.n_obst != NO) {        // fewer obstacles than rows: the run-time-count variants (one instance per wavefront, row-parallel sweeps)
+        if (q.G == 64 && q.fact == 2) return launch_one_lane<NO, 64, 2, true>(h, p, s, grid, q.lds);
+        if (q.G == 64 && q.fact == 3) return launch_one_lane<NO, 64, 3, true>(h, p, s, grid, q.lds);
+        return fail(MPC_ERR_ARG, "no kernel variant for this lane mapping with n_obst outside {3, 5, 10}");
+    }
     switch (q.G * 10 + q.fact) {
     case 213: return launch_one_lane<NO, 21, 3>(h, p, s, grid, q.lds);
     case 162: return launch_one_lane<NO, 16, 2>(h, p, s, grid, q.lds);
@@ -245,22 +262,22 @@ int dispatch_solve(mpc_handle *h, const mpc::KParams &p, hipStream_t s, const So
 {
     int rc = MPC_OK;
     if (q.lps > 1) {
-        switch (h->cfg.n_obst * 10 + q.lps) {
+        switch (row_capacity(h->cfg.n_obst) * 10 + q.lps) {
         case 32: rc = launch_split<3, 2>(h, p, s); break;
         case 33: rc = launch_split<3, 3>(h, p, s); break;
         case 52: rc = launch_split<5, 2>(h, p, s); break;
         case 53: rc = launch_split<5, 3>(h, p, s); break;
         case 102: rc = launch_split<10, 2>(h, p, s); break;
         case 103: rc = launch_split<10, 3>(h, p, s); break;
-        default: return fail(MPC_ERR_ARG, "n_obst must be 3, 5 or 10");
+        default: return fail(MPC_ERR_ARG, "n_obst must be in [1, 10]");
         }
     } else {
         const dim3 grid((p.batch + 64 / q.G - 1) / (64 / q.G));
-        switch (h->cfg.n_obst) {
+        switch (row_capacity(h->cfg.n_obst)) {
         case 3: rc = launch_one_lane_g<3>(h, p, s, grid, q); break;
         case 5: rc = launch_one_lane_g<5>(h, p, s, grid, q); break;
         case 10: rc = launch_one_lane_g<10>(h, p, s, grid, q); break;
-        default: return fail(MPC_ERR_ARG, "n_obst must be 3, 5 or 10");
+        default: return fail(MPC_ERR_ARG, "n_obst must be in [1, 10]");
         }
     }
     if (rc) return rc;
@@ -376,7 +393,7 @@ int mpc_create(const mpc_config *cfg, int device, int max_batch, mpc_handle **ou
 {
     if (!cfg || !out) return fail(MPC_ERR_ARG, "null argument");
     if (cfg->N < 2 || cfg->N > 62) return fail(MPC_ERR_ARG, "N must be in [2, 62] (one horizon stage per lane, N + 1 < 64)");
-    if (cfg->n_obst != 3 && cfg->n_obst != 5 && cfg->n_obst != 10) return fail(MPC_ERR_ARG, "n_obst must be 3, 5 or 10");
+    if (cfg->n_obst < 1 || cfg->n_obst > 10) return fail(MPC_ERR_ARG, "n_obst must be in [1, 10]");
     if (max_batch < 1) return fail(MPC_ERR_ARG, "max_batch must be >= 1");
     if (!(cfg->Tf > 0) || !(cfg->qp_tol > 0) || cfg->qp_iter_max < 1) return fail(MPC_ERR_ARG, "Tf, qp_tol, qp_iter_max must be positive");
     int ndev = 0;
@@ -815,8 +832,11 @@ int mpc_get_kernel_name(mpc_handle *h, int batch, int lookahead, char *buf, int 
 {
     if (!h || !buf || len < 1) return fail(MPC_ERR_ARG, "null argument");
     const SolvePlan q = plan_solve(h, batch, lookahead != 0);
-    if (q.lps > 1) snprintf(buf, (size_t)len, "rti_split_kernel<%d, %d, %s>", h->cfg.n_obst, q.lps, q.waves == 2 ? "true" : "false");
-    else snprintf(buf, (size_t)len, "rti_solve_kernel<%d, %d, %d>", h->cfg.n_obst, q.G, q.fact);
+    const int cap = row_capacity(h->cfg.n_obst);
+    if (q.lps > 1 && partial_rows(h)) snprintf(buf, (size_t)len, "rti_split_kernel<%d, %d, false, true>", cap, q.lps);
+    else if (q.lps > 1) snprintf(buf, (size_t)len, "rti_split_kernel<%d, %d, %s>", cap, q.lps, q.waves == 2 ? "true" : "false");
+    else if (partial_rows(h)) snprintf(buf, (size_t)len, "rti_solve_kernel<%d, %d, %d, true>", cap, q.G, q.fact);
+    else snprintf(buf, (size_t)len, "rti_solve_kernel<%d, %d, %d>", cap, q.G, q.fact);
     return MPC_OK;
 }
 

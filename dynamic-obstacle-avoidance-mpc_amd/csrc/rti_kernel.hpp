@@ -55,6 +55,7 @@ enum : int {
 
 struct KParams {
     int N, batch;
+    int n_obst;               // obstacles of the problem: 1 .. NOBST of the instantiation that runs it (rows beyond it do not exist)
     int soft_h, bx_terminal, iter_max;
     double dt, h2;            // dt, dt^2/2
     double Hd_stage[7];       // diag of the GN Hessian + LM, z order (ua, ual, x, y, psi, v, om), stages < N
@@ -1585,9 +1586,15 @@ __device__ __forceinline__ void systolic_rollout(int stage, int N, const StageLi
 // FACT selects the Riccati factorisation sweep: 0 one-lane systolic, 1 matrix cores (G = 64 only), 2 row-parallel DPP on dense LDS stage
 // blocks (RowLds), 3 row-parallel DPP on compact stage blocks (RowLdsC: what three instances per wavefront, G = 21, and long horizons need
 // to keep four wavefronts on a CU).
-template <int NOBST, int G, int FACT>
+// MASKED: the problem has p.n_obst < NOBST obstacles (any count the reference's N_OBST may take); the rows of obstacle j >= p.n_obst do not exist
+// (skipped by wave-uniform branches), the input arrays are strided by p.n_obst, and the unused position slots replicate the last obstacle so
+// that everything computed from them stays finite.  Instantiated for one instance per wavefront only; the stage-split kernel takes any count.
+template <int NOBST, int G, int FACT, bool MASKED = false>
 __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 {
+    const int nact = MASKED ? p.n_obst : NOBST;
+#define ROW_OFF(j) (MASKED && (j) >= nact)
+#define OBST_IN(j) (MASKED ? ((j) < nact ? (j) : nact - 1) : (j))
     constexpr bool USE_MFMA = FACT == 1, ROWPAR = FACT >= 2, COMPACT = FACT == 3;
     constexpr bool LEAN = NOBST >= 10;          // ten obstacle pairs: recomputable row state is not carried (see obst_view below)
     constexpr bool PLDS = LEAN && COMPACT;      // ... and the obstacle positions of a stage stay in LDS behind the compact stage blocks
@@ -1641,14 +1648,14 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                           : (COMPACT ? RL.H : lds_P + (size_t)slot * (N + 1) * NOBST * 2);
         if (!p.obst) {              // PLDS with explicit parameters (parameterize_model): every stage lane copies its row of P
             if (act) {
-                const double *Pg = p.P + ((size_t)inst * (N + 1) + i) * NOBST * 2;
+                const double *Pg = p.P + ((size_t)inst * (N + 1) + i) * nact * 2;
 #pragma unroll
-                for (int e = 0; e < 2 * NOBST; e++) Pl[i * NOBST * 2 + e] = Pg[e];
+                for (int e = 0; e < 2 * NOBST; e++) Pl[i * NOBST * 2 + e] = Pg[2 * OBST_IN(e >> 1) + (e & 1)];
             }
         } else if (2 * NOBST <= G) {
             if (i < 2 * NOBST) {   // lane i walks coordinate i & 1 of obstacle i >> 1 through the horizon (Obstacle.predict_trajectory, visualization.py:62-79)
-                const int j = i >> 1, c = i & 1;
-                const double *o = p.obst + ((size_t)inst * NOBST + j) * 4;
+                const int j = OBST_IN(i >> 1), c = i & 1;
+                const double *o = p.obst + ((size_t)inst * nact + j) * 4;
                 double q = o[c], v = (c == 0 && !p.world.bug_compat_predict) ? o[2] : o[3];      // defect D1: vx = self.vy (:69)
                 const double lo = c ? p.world.ymin : p.world.xmin, hi = c ? p.world.ymax : p.world.xmax;
                 Pl[i] = q;
@@ -1658,7 +1665,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 }
             }
         } else if (i < NOBST) {       // lane j = i walks obstacle j through the horizon
-            const double *o = p.obst + ((size_t)inst * NOBST + i) * 4;
+            const double *o = p.obst + ((size_t)inst * nact + OBST_IN(i)) * 4;
             double ox = o[0], oy = o[1], ovy = o[3];
             double ovx = p.world.bug_compat_predict ? o[3] : o[2];
             Pl[i * 2] = ox; Pl[i * 2 + 1] = oy;
@@ -1674,9 +1681,9 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             for (int j = 0; j < NOBST; j++) { pxy[j][0] = act ? Pl[(i * NOBST + j) * 2] : 0.0; pxy[j][1] = act ? Pl[(i * NOBST + j) * 2 + 1] : 0.0; }
         }
     } else {
-        const double *Pg = p.P + ((size_t)inst * (N + 1) + (act ? i : 0)) * NOBST * 2;
+        const double *Pg = p.P + ((size_t)inst * (N + 1) + (act ? i : 0)) * nact * 2;
 #pragma unroll
-        for (int j = 0; j < NOBST; j++) { pxy[j][0] = act ? Pg[2 * j] : 0.0; pxy[j][1] = act ? Pg[2 * j + 1] : 0.0; }
+        for (int j = 0; j < NOBST; j++) { pxy[j][0] = act ? Pg[2 * OBST_IN(j)] : 0.0; pxy[j][1] = act ? Pg[2 * OBST_IN(j) + 1] : 0.0; }
     }
     // position of obstacle j at this lane's stage
     auto pos_x = [&](int j) { if constexpr (PLDS) return myP[2 * j]; else return pxy[j][0]; };
@@ -1831,7 +1838,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             t2[j] = fmax(sv[j], p.thr0);
         } else {
             sv[j] = 0.0; t1[j] = fmax(h0, p.thr0); t2[j] = 1.0;
-            if (vs) lin0 = fmax(lin0, t1[j] - h0);
+            if (vs && !ROW_OFF(j)) lin0 = fmax(lin0, t1[j] - h0);
         }
         const double r1 = rcp_nr(t1[j]), r2 = rcp_nr(t2[j]);
         l1[j] = p.mu0 * r1; l2[j] = soft ? p.mu0 * r2 : 0.0;
@@ -1840,7 +1847,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     int n_items_lane = 0;
 #pragma unroll
     for (int k = 0; k < NB; k++) n_items_lane += ((k < 2) ? vbu : vbx) ? 2 : 0;
-    n_items_lane += vs ? (soft ? 2 * NOBST : NOBST) : 0;
+    n_items_lane += vs ? (soft ? 2 * nact : nact) : 0;
     const double n_items = seg_sum<G>((double)n_items_lane, lane);
     const double inv_items = n_items > 0 ? 1.0 / n_items : 0.0;
     {   // Non-finite inputs (a diverged plant, a bad sensor frame, a poisoned warm start) must not pass as a converged solve: fmax() drops NaN, so
@@ -1883,6 +1890,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         if (vs) {
 #pragma unroll
             for (int j = 0; j < NOBST; j++) {
+                if (ROW_OFF(j)) continue;
                 const double a = l1[j] * t1[j];
                 msum += a;
                 if (!(t1[j] <= 2 * kTLMin || l1[j] <= 2 * kTLMin)) cmax = fmax(cmax, a);
@@ -1990,6 +1998,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 const double pz = phase_zero();
 #pragma unroll
                 for (int j = 0; j < NOBST; j++) {
+                    if (ROW_OFF(j)) continue;
                     const ObstView v = obst_view(j, pz);
                     const SoftT o = soft_terms(j, v, z);
                     double weff, geff;
@@ -2162,7 +2171,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #pragma unroll
             for (int j = 0; j < NOBST; j++) {
                 dt1_[j] = dl1_[j] = dt2_[j] = dl2_[j] = 0.0; pp1[j] = pp2[j] = 0.0;
-                if (vs) {
+                if (vs && !ROW_OFF(j)) {
                     const ObstView v = obst_view(j, pz);
                     const SoftT o = soft_terms(j, v, z);
                     const double y = v.ax * za[2] + v.ay * za[3];
@@ -2189,6 +2198,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             if (vs) {
 #pragma unroll
                 for (int j = 0; j < NOBST; j++) {
+                    if (ROW_OFF(j)) continue;
                     maff += (l1[j] + a_affd * dl1_[j]) * (t1[j] + a_aff * dt1_[j]);
                     if (soft) maff += (l2[j] + a_affd * dl2_[j]) * (t2[j] + a_aff * dt2_[j]);
                 }
@@ -2221,6 +2231,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 const double pz = phase_zero();
 #pragma unroll
                 for (int j = 0; j < NOBST; j++) {
+                    if (ROW_OFF(j)) continue;
                     const ObstView v = obst_view(j, pz);
                     const double db1 = (pp1[j] - smu) * v.rt1;
                     double geff;
@@ -2312,7 +2323,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #pragma unroll
             for (int j = 0; j < NOBST; j++) {
                 dt1_[j] = dl1_[j] = dt2_[j] = dl2_[j] = ds_[j] = 0.0;
-                if (vs) {
+                if (vs && !ROW_OFF(j)) {
                     const ObstView v = obst_view(j, pz);
                     const SoftT o = soft_terms(j, v, z);
                     const double y = v.ax * dz[2] + v.ay * dz[3];
@@ -2349,6 +2360,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 if (vs) {
 #pragma unroll
                     for (int j = 0; j < NOBST; j++) {
+                        if (ROW_OFF(j)) continue;
                         t1[j] = fmax(t1[j] + alpha * dt1_[j], kTLMin); l1[j] = fmax(l1[j] + alphad * dl1_[j], kTLMin);
                         if constexpr (!LEAN) rt1[j] = rcp_nr(t1[j]);
                         if (soft) {
@@ -2416,13 +2428,13 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             for (int c = 0; c < 5; c++) p.x0_rw[(size_t)inst * 5 + c] = xnew[c];
         }
         double margin = INFINITY;
-        if (p.obst && i < NOBST) {                           // ground-truth motion of obstacle j = i
-            const double *o = p.obst + ((size_t)inst * NOBST + i) * 4;
+        if (p.obst && i < nact) {                            // ground-truth motion of obstacle j = i
+            const double *o = p.obst + ((size_t)inst * nact + i) * 4;
             double ox = o[0], oy = o[1], ovx = o[2], ovy = o[3];
             if (p.fused & kFuseObstacles) {
-                if (p.noise) obstacle_noise(p.randomness, p.vmax, p.noise[((size_t)inst * NOBST + i) * 2], p.noise[((size_t)inst * NOBST + i) * 2 + 1], ovx, ovy);
+                if (p.noise) obstacle_noise(p.randomness, p.vmax, p.noise[((size_t)inst * nact + i) * 2], p.noise[((size_t)inst * nact + i) * 2 + 1], ovx, ovy);
                 obstacle_advance(p.world, dt, ox, ovx, oy, ovy);
-                if (store && p.obst_rw) { double *w = p.obst_rw + ((size_t)inst * NOBST + i) * 4; w[0] = ox; w[1] = oy; w[2] = ovx; w[3] = ovy; }
+                if (store && p.obst_rw) { double *w = p.obst_rw + ((size_t)inst * nact + i) * 4; w[0] = ox; w[1] = oy; w[2] = ovx; w[3] = ovy; }
             }
             const double ddx = xnew[0] - ox, ddy = xnew[1] - oy;
             margin = sqrt(ddx * ddx + ddy * ddy) - p.r_hit;  // :222-228
@@ -2453,6 +2465,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             else J = 0.5 * (p.Weg[0] * ex * ex + p.Weg[1] * ey * ey + p.Weg[2] * xi[3] * xi[3] + p.Weg[3] * xi[4] * xi[4]);
 #pragma unroll
             for (int j = 0; j < NOBST; j++) {
+                if (ROW_OFF(j)) continue;
                 const double dx = xi[0] - pos_x(j), dy = xi[1] - pos_y(j);
                 const double hv = dx * dx + dy * dy - p.r2;
                 const double v = hv < 0 ? -hv : 0.0;
@@ -2469,5 +2482,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         if (p.iters) p.iters[inst] = it_done;
     }
 }
+#undef ROW_OFF
+#undef OBST_IN
 
 }  // namespace mpc

@@ -53,7 +53,9 @@ __device__ __forceinline__ double nth_of_six(double a0, double a1, double a2, do
 #else
 #define MPC_SPLIT_BOUNDS(W2) __launch_bounds__(64, (W2) ? 2 : 1)
 #endif
-template <int NOBST, int LPS, bool W2 = false>
+// MASKED: fewer obstacles than row pairs (p.n_obst < NOBST, see rti_solve_kernel): a template flag, because with the count known at compile time
+// the per-slot row flags fold into the stage flags (measured: the run-time count costs 1 % at C2)
+template <int NOBST, int LPS, bool W2 = false, bool MASKED = false>
 __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
 {
     static_assert(LPS == 2 || LPS == 3, "two or three lanes per horizon stage");
@@ -64,6 +66,7 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
     const int lane = threadIdx.x;
     const int inst = p.order ? p.order[blockIdx.x] : (int)blockIdx.x;     // grid = batch: one instance per wavefront; instance scheduling: longest-running first
     const int N = p.N;
+    const int nact = MASKED ? p.n_obst : NOBST;   // obstacles of the problem (<= NOBST, the row capacity this instantiation was built for)
     const int i = lane / LPS;                 // this lane's stage
     const int h = lane - i * LPS;             // ... and its part of the stage's rows
     const bool own = (h == 0);                // the part that stages the stage's blocks in LDS and stores the iterate
@@ -133,9 +136,9 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
     // or the look-ahead computed here (Obstacle.predict_trajectory, src/utils/visualization.py:62-79)
     double pxy[NSL][2];
     if (p.obst) {
-        if (lane < 2 * NOBST) {    // lane walks coordinate lane & 1 of obstacle lane >> 1 through the horizon
+        if (lane < 2 * nact) {     // lane walks coordinate lane & 1 of obstacle lane >> 1 through the horizon
             const int j = lane >> 1, c = lane & 1;
-            const double *o = p.obst + ((size_t)inst * NOBST + j) * 4;
+            const double *o = p.obst + ((size_t)inst * nact + j) * 4;
             double q = o[c], v = (c == 0 && !p.world.bug_compat_predict) ? o[2] : o[3];      // defect D1: vx = self.vy (visualization.py:69)
             const double lo = c ? p.world.ymin : p.world.xmin, hi = c ? p.world.ymax : p.world.xmax;
             lds_P[lane] = q;
@@ -150,15 +153,15 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
     if (p.obst) {       // (two branches, not a select between an LDS and a global pointer: that would be a flat load)
 #pragma unroll
         for (int s = 0; s < NSL; s++) {
-            const int j = s * LPS + h, jj = j < NOBST ? j : NOBST - 1;
+            const int j = s * LPS + h, jj = j < nact ? j : nact - 1;
             const double *src = lds_P + ((act ? i : 0) * NOBST + jj) * 2;
             pxy[s][0] = src[0]; pxy[s][1] = src[1];
         }
     } else {
 #pragma unroll
         for (int s = 0; s < NSL; s++) {
-            const int j = s * LPS + h, jj = j < NOBST ? j : NOBST - 1;
-            const double *src = p.P + (((size_t)inst * (N + 1) + (act ? i : 0)) * NOBST + jj) * 2;
+            const int j = s * LPS + h, jj = j < nact ? j : nact - 1;
+            const double *src = p.P + (((size_t)inst * (N + 1) + (act ? i : 0)) * nact + jj) * 2;
             pxy[s][0] = src[0]; pxy[s][1] = src[1];
         }
     }
@@ -274,7 +277,7 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
     double hh[NSL], ax[NSL], ay[NSL], sv[NSL], l1[NSL], t1[NSL], l2[NSL], t2[NSL], rt1[NSL], rt2[NSL];
 #pragma unroll
     for (int s = 0; s < NSL; s++) {
-        sp[s] = vs && (s * LPS + h < NOBST);
+        sp[s] = vs && (s * LPS + h < nact);
         const double ex = xi[0] - pxy[s][0], ey = xi[1] - pxy[s][1];
         hh[s] = ex * ex + ey * ey - p.r2; ax[s] = 2 * ex; ay[s] = 2 * ey;
         if (soft) {
@@ -747,13 +750,13 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
             for (int c = 0; c < 5; c++) p.x0_rw[(size_t)inst * 5 + c] = xnew[c];
         }
         double margin = INFINITY;
-        if (p.obst && lane < NOBST) {                        // ground-truth motion of obstacle j = lane
-            const double *o = p.obst + ((size_t)inst * NOBST + lane) * 4;
+        if (p.obst && lane < nact) {                         // ground-truth motion of obstacle j = lane
+            const double *o = p.obst + ((size_t)inst * nact + lane) * 4;
             double ox = o[0], oy = o[1], ovx = o[2], ovy = o[3];
             if (p.fused & kFuseObstacles) {
-                if (p.noise) obstacle_noise(p.randomness, p.vmax, p.noise[((size_t)inst * NOBST + lane) * 2], p.noise[((size_t)inst * NOBST + lane) * 2 + 1], ovx, ovy);
+                if (p.noise) obstacle_noise(p.randomness, p.vmax, p.noise[((size_t)inst * nact + lane) * 2], p.noise[((size_t)inst * nact + lane) * 2 + 1], ovx, ovy);
                 obstacle_advance(p.world, dt, ox, ovx, oy, ovy);
-                if (store && p.obst_rw) { double *w = p.obst_rw + ((size_t)inst * NOBST + lane) * 4; w[0] = ox; w[1] = oy; w[2] = ovx; w[3] = ovy; }
+                if (store && p.obst_rw) { double *w = p.obst_rw + ((size_t)inst * nact + lane) * 4; w[0] = ox; w[1] = oy; w[2] = ovx; w[3] = ovy; }
             }
             const double ddx = xnew[0] - ox, ddy = xnew[1] - oy;
             margin = sqrt(ddx * ddx + ddy * ddy) - p.r_hit;  // :222-228
@@ -785,7 +788,7 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
                 else J = 0.5 * (p.Weg[0] * ex * ex + p.Weg[1] * ey * ey + p.Weg[2] * xi[3] * xi[3] + p.Weg[3] * xi[4] * xi[4]);
             }
 #pragma unroll
-            for (int s = 0; s < NSL; s++) if (s * LPS + h < NOBST) {
+            for (int s = 0; s < NSL; s++) if (s * LPS + h < nact) {
                 const double dx = xi[0] - pxy[s][0], dy = xi[1] - pxy[s][1];
                 const double hv = dx * dx + dy * dy - p.r2;
                 const double v = hv < 0 ? -hv : 0.0;

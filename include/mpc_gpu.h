@@ -42,7 +42,7 @@ extern "C" {
 /* Problem definition.  Defaults (mpc_default_config) are the reference's constants. */
 typedef struct mpc_config {
     int32_t N;              /* N_SOLV                     src/models/world_specification.py:44   */
-    int32_t n_obst;         /* N_OBST (3, 5 or 10 built)  world_specification.py:25              */
+    int32_t n_obst;         /* N_OBST, 1..10              world_specification.py:25              */
     double Tf;              /* TF                         world_specification.py:43              */
     double W[6];            /* diag W, y=[x,y,v,w,ua,ual] robot_ocp_problem.py:24-26,78-80       */
     double We[4];           /* diag W_e, y_e=[x,y,v,w]    robot_ocp_problem.py:27,83             */

@@ -65,7 +65,7 @@ def test_argument_validation_without_device(lib):
     assert L.mpc_default_config(None, 20, 3, 2.0) == lib.MPC_ERR_ARG
     cfg = lib.default_config(20, 3, 2.0)
     h = C.c_void_p()
-    for bad in (dict(N=1), dict(N=63), dict(n_obst=4)):
+    for bad in (dict(N=1), dict(N=63), dict(n_obst=0), dict(n_obst=11)):
         c2 = lib.default_config(20, 3, 2.0)
         for k, v in bad.items():
             setattr(c2, k, v)

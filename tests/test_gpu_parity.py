@@ -612,3 +612,55 @@ def test_non_finite_inputs_are_contained(built, lanes):
     for b in bad:
         assert gb["status"][b] == 4 and gb["iters"][b] == 0, (b, gb["status"][b], gb["iters"][b])      # as the oracle (test_oracle_math.py)
         assert np.array_equal(Xb[b], Xg[b]) and np.array_equal(Ub[b], Ug[b])                           # iterate untouched
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,no,B", [(20, 1, 60), (20, 2, 60), (20, 4, 80), (20, 7, 40), (31, 8, 30), (10, 6, 50), (40, 4, 24), (40, 9, 12), (55, 8, 8), (62, 1, 6)])
+def test_any_obstacle_count(built, N, no, B):
+    """N_OBST is a free constant of the reference (world_specification.py:25; its tables use 5, BASELINE's workloads 3 and 10): any count
+    1..10 runs on the instantiation with the next row capacity (3, 5 or 10), the rows of the missing obstacles switched off:
+    rti_split_kernel<cap, LPS, false, true> for N <= 31, beyond that rti_solve_kernel<cap, 64, FACT, true>.  Same contract as everywhere: statuses
+    equal, iterates to 1e-6 or judged by the QP; look-ahead in the kernel and explicit P; three closed-loop steps; a fused closed-loop step
+    moves exactly `no` obstacles."""
+    import mpc_gpu
+    from oracle import oracle as orc
+    mpc_gpu.BatchedMpc.default_lanes_per_stage = 0
+    x0, goal, obst = random_batch(B, no, seed=77 + 13 * N + no)
+    cfg = orc.config(N, no, 0.1 * N)
+    P = oracle_P(orc, cfg, obst); Xo, Uo = oracle_guess(orc, cfg, x0)
+    cap = 3 if no <= 3 else (5 if no <= 5 else 10)
+    with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
+        name = s.kernel_name(B)
+        assert name.startswith(f"rti_split_kernel<{cap}," if N <= 31 else f"rti_solve_kernel<{cap}, 64,") and name.endswith("true>"), name
+        s.reset_guess(x0)
+        for k in range(3):
+            g = s.solve(x0, obst if k != 1 else P, goal); X, U = s.get_traj(B)
+            o = orc.rti_solve_batch(cfg, x0, P, goal, Xo, Uo)
+            assert (g["status"] == o["status"]).all(), (k, g["status"], o["status"])
+            ok = o["status"] == 0
+            assert (g["iters"][ok] == o["iters"][ok]).mean() >= 0.9
+            d = np.abs(X - o["X"]).reshape(B, -1).max(1)
+            for b in np.nonzero(ok & (d > 1e-6))[0]:
+                fg, eqg, bg = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xo[b], Uo[b], X[b], U[b])
+                fo, _, _ = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xo[b], Uo[b], o["X"][b], o["U"][b])
+                assert eqg <= 1e-7 and bg <= 1e-7 and fg <= fo + 1e-7 * max(1.0, abs(fo)), (k, b, fg, fo)
+            assert np.median(d[ok]) < 1e-9
+            rel = np.abs(g["cost"][ok] - o["cost"][ok]) / np.maximum(1.0, np.abs(o["cost"][ok]))
+            assert np.median(rel) < 1e-10
+            # both sides continue from the oracle's iterate (single-solve parity on identical inputs)
+            Xo, Uo = o["X"].copy(), o["U"].copy()
+            for b in range(B):
+                Xo[b], Uo[b] = orc.shift(cfg, Xo[b], Uo[b])
+            s.set_warmstart(Xo, Uo)
+    # fused closed-loop step: plant + obstacle motion over exactly `no` obstacles, against the oracle's pieces
+    rng = np.random.default_rng(5)
+    noise = rng.standard_normal((3, B, no, 2))
+    r = mpc_gpu.run_episodes(x0, goal, obst, N=N, Tf=0.1 * N, max_iter=3, random_move=True, noise=noise, record=True)
+    live = r["table"][:, 1] == 0                      # (an instance that reached its goal stops moving its obstacles)
+    ob = obst.copy()
+    for k in range(3):
+        for b in range(B):
+            for j in range(no):
+                ob[b, j] = orc.obstacle_step(cfg, ob[b, j], 0.1, noise=noise[k, b, j])
+    assert r["obst_traj"].shape == (4, B, no, 4)
+    assert np.abs(r["obst_traj"][-1][live] - ob[live]).max() < 1e-12
