@@ -53,6 +53,8 @@ struct mpc_handle {
     unsigned *d_sched_hist;           // ... per-block histograms of the counting sort [bins][blocks]
     int order_batch;                  // batch size d_order is a permutation of (0 = none yet)
     double *d_alpha_own;              // handle-owned copy of a host slack schedule (mpc_set_slack_schedule)
+    double *h_pack, *d_pack;          // small host-pointer batches (the reference's own scalar loop): inputs and outputs travel packed, one copy each way
+    size_t pack_in, pack_out;         // doubles per instance in / out of the packed transfer
     const double *d_alpha;            // slack schedule in effect: d_alpha_own, a caller's device array, or null (the reference's formula)
     std::vector<hipEvent_t> ev_start, ev_stop;
     int ev_used;
@@ -64,6 +66,7 @@ namespace {
 // the problem leaves some of it unused (then only the mappings that take a run-time obstacle count are dispatched: the stage-split kernel for
 // N <= 31, one instance per wavefront with row-parallel sweeps beyond)
 int row_capacity(int n) { return n <= 3 ? 3 : (n <= 5 ? 5 : 10); }
+constexpr int kPackBatch = 64;   // host-pointer solves of at most this many instances use the packed transfer (solve_common)
 bool partial_rows(const mpc_handle *h);
 
 mpc::KParams make_params(const mpc_config &c, int batch)
@@ -307,6 +310,10 @@ int create_resources(mpc_handle *h)
     HIPCHK(hipMalloc(&h->d_iters, B * sizeof(int32_t)));
     HIPCHK(hipMalloc(&h->d_order, B * sizeof(int32_t)));
     HIPCHK(hipMalloc(&h->d_iters_sched, B * sizeof(int32_t)));
+    h->pack_in = 5 + 2 + (N + 1) * no * 2;      // x0 | goal | P (or the 4 n_obst obstacle states, which are fewer)
+    h->pack_out = 2 + 1 + 1;                    // u0 | cost | status, iters (two int32 in one double's space)
+    HIPCHK(hipHostMalloc((void **)&h->h_pack, (size_t)kPackBatch * (h->pack_in + h->pack_out) * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipMalloc(&h->d_pack, (size_t)kPackBatch * (h->pack_in + h->pack_out) * sizeof(double)));
     HIPCHK(hipMalloc(&h->d_sched_hist, (size_t)mpc::kSchedBins * ((B + mpc::kSchedChunk - 1) / mpc::kSchedChunk) * sizeof(unsigned)));
     HIPCHK(hipMemsetAsync(h->d_iters_sched, 0, B * sizeof(int32_t), h->stream));
     HIPCHK(hipMemsetAsync(h->dX, 0, B * (N + 1) * 5 * sizeof(double), h->stream));
@@ -418,6 +425,8 @@ int mpc_destroy(mpc_handle *h)
     void *bufs[] = {h->dX, h->dU, h->d_x0, h->d_P, h->d_goal, h->d_obst, h->d_u0, h->d_cost, h->d_xa, h->d_ua, h->d_xb, h->d_status, h->d_iters,
                     h->d_trace, h->d_alpha_own, h->d_order, h->d_iters_sched, h->d_sched_hist};
     for (void *b : bufs) if (b) (void)hipFree(b);
+    if (h->d_pack) (void)hipFree(h->d_pack);
+    if (h->h_pack) (void)hipHostFree(h->h_pack);
     for (auto e : h->ev_start) (void)hipEventDestroy(e);
     for (auto e : h->ev_stop) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -614,6 +623,30 @@ static int solve_common(mpc_handle *h, int batch, const double *x0, const double
     if (!x0 || !goal || (!P && !obst)) return fail(MPC_ERR_ARG, "null pointer");
     HIPCHK(hipSetDevice(h->device));
     const size_t N = h->cfg.N, no = h->cfg.n_obst;
+    if (batch <= kPackBatch) {
+        // The reference's own call pattern (one scenario, one solve per control step) is dominated by the eight small transfers and the
+        // separate look-ahead launch of the general path below: here the inputs travel as ONE pinned block, the look-ahead is computed
+        // inside the solve kernel (p.obst) and the four outputs come back as one block.
+        const size_t B = (size_t)batch, nin = 7 * B + (P ? B * (N + 1) * no * 2 : B * no * 4);
+        double *hin = h->h_pack, *hout = h->h_pack + (size_t)kPackBatch * h->pack_in;
+        double *din = h->d_pack, *dout = h->d_pack + (size_t)kPackBatch * h->pack_in;
+        memcpy(hin, x0, 5 * B * sizeof(double)); memcpy(hin + 5 * B, goal, 2 * B * sizeof(double));
+        memcpy(hin + 7 * B, P ? P : obst, (nin - 7 * B) * sizeof(double));
+        HIPCHK(hipMemcpyAsync(din, hin, nin * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        mpc::KParams p = make_params(h->cfg, batch);
+        p.x0 = din; p.goal = din + 5 * B; p.X = h->dX; p.U = h->dU;
+        if (P) p.P = din + 7 * B; else p.obst = din + 7 * B;
+        p.u0 = dout; p.cost = dout + 2 * B; p.status = (int32_t *)(dout + 3 * B); p.iters = p.status + B; p.trace = h->d_trace;
+        if (!P) p.world = make_world(h->cfg);
+        rc = launch_solve(h, p, h->stream); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(hout, dout, 4 * B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (u0) memcpy(u0, hout, 2 * B * sizeof(double));
+        if (cost) memcpy(cost, hout + 2 * B, B * sizeof(double));
+        if (status) memcpy(status, hout + 3 * B, B * sizeof(int32_t));
+        if (iters) memcpy(iters, (const int32_t *)(hout + 3 * B) + B, B * sizeof(int32_t));
+        return MPC_OK;
+    }
     HIPCHK(hipMemcpyAsync(h->d_x0, x0, (size_t)batch * 5 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_goal, goal, (size_t)batch * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (P) HIPCHK(hipMemcpyAsync(h->d_P, P, (size_t)batch * (N + 1) * no * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));

@@ -14,7 +14,8 @@ out = {}
 # lanes per instance of the one-lane kernel (21: three instances per wavefront, compact LDS blocks; 0: automatic)
 for N, no, B, lps, waves, lanes in [(20, 3, 20000, 1, 1, 32), (20, 3, 20000, 1, 1, 21), (20, 3, 20000, 3, 1, 0), (20, 3, 20000, 3, 2, 0),
                                     (20, 5, 20000, 1, 1, 32), (20, 5, 20000, 3, 1, 0), (10, 3, 20000, 1, 1, 16), (10, 3, 20000, 3, 1, 0),
-                                    (30, 3, 8000, 2, 1, 0), (30, 3, 8000, 2, 2, 0), (20, 10, 8000, 3, 1, 0), (50, 10, 4000, 1, 1, 0), (5, 5, 20000, 1, 1, 0)]:
+                                    (30, 3, 8000, 2, 1, 0), (30, 3, 8000, 2, 2, 0), (20, 10, 8000, 3, 1, 0), (50, 10, 4000, 1, 1, 0), (5, 5, 20000, 1, 1, 0),
+                                    (20, 4, 8000, 3, 1, 0), (40, 7, 3000, 1, 1, 0)]:      # obstacle counts between the instantiated row capacities
     x0, goal, obst = random_batch(B, no, seed=4242 + N + no)
     cfg = orc.config(N, no, 0.1 * N)
     res = []
