@@ -649,12 +649,16 @@ static int solve_common(mpc_handle *h, int batch, const double *x0, const double
     }
     HIPCHK(hipMemcpyAsync(h->d_x0, x0, (size_t)batch * 5 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_goal, goal, (size_t)batch * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (P) HIPCHK(hipMemcpyAsync(h->d_P, P, (size_t)batch * (N + 1) * no * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    else {
+    if (P) {
+        HIPCHK(hipMemcpyAsync(h->d_P, P, (size_t)batch * (N + 1) * no * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        rc = mpc_solve_dev(h, batch, h->d_x0, h->d_P, h->d_goal, h->dX, h->dU, h->d_u0, h->d_cost, h->d_status, h->d_iters, nullptr);
+    } else {        // obstacle states in: the look-ahead is computed inside the solve kernel (no P in HBM at all)
         HIPCHK(hipMemcpyAsync(h->d_obst, obst, (size_t)batch * no * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        rc = mpc_predict_dev(h, batch, h->d_obst, h->d_P, nullptr); if (rc) return rc;
+        mpc::KParams p = make_params(h->cfg, batch);
+        p.x0 = h->d_x0; p.obst = h->d_obst; p.goal = h->d_goal; p.X = h->dX; p.U = h->dU; p.world = make_world(h->cfg);
+        p.u0 = h->d_u0; p.cost = h->d_cost; p.status = h->d_status; p.iters = h->d_iters; p.trace = h->d_trace;
+        rc = launch_solve(h, p, h->stream);
     }
-    rc = mpc_solve_dev(h, batch, h->d_x0, h->d_P, h->d_goal, h->dX, h->dU, h->d_u0, h->d_cost, h->d_status, h->d_iters, nullptr);
     if (rc) return rc;
     if (u0) HIPCHK(hipMemcpyAsync(u0, h->d_u0, (size_t)batch * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (cost) HIPCHK(hipMemcpyAsync(cost, h->d_cost, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost, h->stream));

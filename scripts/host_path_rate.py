@@ -5,8 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "dynamic-obstacle-avoidance-mpc_amd")]
 import numpy as np
 import bench, mpc_gpu
-for B in (1, 1024, 65536):
-    x0, goal, obst, desc = bench.make_workload("c2" if B <= 1024 else "c3", B, 20, 3)
+from mpc_gpu.sharding import shard_slice
+for B in (1, 64, 1024, 65536):
+    x0, goal, obst = bench.make_workload("c2" if B <= 1024 else "c3", 1, 0, shard_slice)[:3]
+    x0, goal, obst = x0[:B], goal[:B], obst[:B]
     with mpc_gpu.BatchedMpc(20, 3, 2.0, max_batch=B) as s:
         s.reset_guess(x0)
         for _ in range(3): s.solve(x0, obst, goal); s.shift(B)

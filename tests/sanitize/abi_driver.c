@@ -19,7 +19,7 @@ int main(void)
     }
     mpc_config c2 = c; c2.N = 63;
     if (mpc_create(&c2, 0, 1, &h) != MPC_ERR_ARG) bad++;
-    c2 = c; c2.n_obst = 4;
+    c2 = c; c2.n_obst = 11;
     if (mpc_create(&c2, 0, 1, &h) != MPC_ERR_ARG) bad++;
     if (mpc_create(&c, 0, 0, &h) != MPC_ERR_ARG) bad++;
     if (mpc_create(NULL, 0, 1, &h) != MPC_ERR_ARG) bad++;
