@@ -436,7 +436,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3, help="untimed episodes")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the supplementary C3 and C1 measurements")
+    ap.add_argument("--no-extra", action="store_true", help="skip the supplementary C3, C5 and C1 measurements")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the multi-rank plumbing (gloo), no kernels")
     args = ap.parse_args()
 
@@ -512,6 +512,15 @@ def main():
                         "ms_per_step": r3["elapsed"] / 3 * 1e3, "ms_per_control_step": r3["elapsed"] / (3 * EPISODE) * 1e3,
                         "mean_ipm_iters": r3["mean_iters"], "qp_failure_frac": r3["fail"], "roofline": roofline(l3, N, no, r3)}
         del l3
+        # ... and the long-horizon configuration (configs[4]: N = 50, 10 obstacles, 32768 scenarios) on this one GPU, two episodes
+        N5, no5 = WORKLOADS["c5"][:2]
+        x5, g5, o5, d5, _, G5 = make_workload("c5", 1, 0, shard_slice)
+        l5 = Loop(mpc_gpu, torch, N5, no5, x5, g5, o5, dev)
+        r5 = measure(torch, None, l5, 1, None, 2, 1, dev)
+        out["extra_c5"] = {"workload": d5, "value": G5 * EPISODE * 2 / r5["elapsed"], "unit": "solves/s", "steps": 2, "warmup": 1,
+                           "ms_per_step": r5["elapsed"] / 2 * 1e3, "ms_per_control_step": r5["elapsed"] / (2 * EPISODE) * 1e3,
+                           "mean_ipm_iters": r5["mean_iters"], "qp_failure_frac": r5["fail"], "roofline": roofline(l5, N5, no5, r5)}
+        del l5
         out["c1"] = c1_latency(mpc_gpu, N, no)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, no, x0, goal, obst)
