@@ -46,6 +46,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--child": child(sys.argv[2]); sys.exit(0)
     import numpy as np
     od = os.path.join(ROOT, "gpurun_out"); os.makedirs(od, exist_ok=True)
+    variant = os.path.join(ROOT, "build", "libmpcgpu_plain.so")          # the comparison build: compiled here when it is not there yet
+    if not os.path.exists(variant) or "--rebuild" in sys.argv:
+        os.makedirs(os.path.dirname(variant), exist_ok=True)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-DMPC_COMPACT_PLAIN",
+                               "-o", variant, os.path.join(PKG, "csrc", "mpc_api.hip")])
     outs = {}
     for tag, lib in (("asm", None), ("plain", os.path.join(ROOT, "build", "libmpcgpu_plain.so"))):
         env = dict(os.environ); 
