@@ -492,7 +492,7 @@ def main():
                       "step": f"one episode of the whole batch = set_initial_guess + {EPISODE} closed-loop control steps; a control step is ONE fused "
                               "launch (obstacle look-ahead + RTI solve + plant step + obstacle motion + warm-start shift), device resident",
                       "control_steps_per_step": EPISODE, "solves_per_step": G * EPISODE,
-                      "comparability": ("whole episodes (11.5 interior-point iterations per solve); round 1's driver line timed control steps 5-25 of one "
+                      "comparability": ("whole episodes (10.7 interior-point iterations per solve; 11.5 with round 1's interior-point constants: 6.95e6 solves/s); round 1's driver line timed control steps 5-25 of one "
                                         "episode (7.5 iterations per solve: 9.4e6 solves/s) and its own 500-step run gave 6.95e6 -- the C2 kernel is the same")
                                        if args.workload == "c2" else None,
                       "parallelism": (f"batch slices over {world} ranks (mpc_gpu.sharding.shard_slice), no data-path collective; per-scenario costs "

@@ -870,10 +870,9 @@ int mpc_get_kernel_name(mpc_handle *h, int batch, int lookahead, char *buf, int 
     if (!h || !buf || len < 1) return fail(MPC_ERR_ARG, "null argument");
     const SolvePlan q = plan_solve(h, batch, lookahead != 0);
     const int cap = row_capacity(h->cfg.n_obst);
-    if (q.lps > 1 && partial_rows(h)) snprintf(buf, (size_t)len, "rti_split_kernel<%d, %d, false, true>", cap, q.lps);
-    else if (q.lps > 1) snprintf(buf, (size_t)len, "rti_split_kernel<%d, %d, %s>", cap, q.lps, q.waves == 2 ? "true" : "false");
-    else if (partial_rows(h)) snprintf(buf, (size_t)len, "rti_solve_kernel<%d, %d, %d, true>", cap, q.G, q.fact);
-    else snprintf(buf, (size_t)len, "rti_solve_kernel<%d, %d, %d>", cap, q.G, q.fact);
+    const char *masked = partial_rows(h) ? "true" : "false";      // (all template arguments, as rocprofv3 prints the instantiation)
+    if (q.lps > 1) snprintf(buf, (size_t)len, "rti_split_kernel<%d, %d, %s, %s>", cap, q.lps, (q.waves == 2 && !partial_rows(h)) ? "true" : "false", masked);
+    else snprintf(buf, (size_t)len, "rti_solve_kernel<%d, %d, %d, %s>", cap, q.G, q.fact, masked);
     return MPC_OK;
 }
 

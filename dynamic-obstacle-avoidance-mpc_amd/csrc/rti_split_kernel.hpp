@@ -333,7 +333,7 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
         const double mu = msum * inv_items;
         const double lin = rhoPi * lin0;
         if (running) {
-            if (!(mu == mu) || !(fabs(mu) <= 1e300)) { status = 4; running = false; it_done = it; }
+            if (!(mu == mu) || !(fabs(mu) <= kMuDiverged * p.mu0)) { status = 4; running = false; it_done = it; }      // NaN, or diverged: an infeasible QP
             else if (lin <= p.tol && cmax <= p.tol) { status = 0; running = false; it_done = it; }
             else if (it >= p.iter_max) { status = 2; running = false; it_done = it; }
         }
@@ -551,7 +551,7 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
             }
             maff = seg_sum<64>(maff, lane) * inv_items;
             double sigma = mu > 0 ? maff / mu : 0.0;
-            sigma = sigma * sigma * sigma;
+            sigma = sigma * sigma;
             if (sigma > 1.0) sigma = 1.0;
             smu = sigma * mu;
 #ifndef MPC_PHASE_TIMING
@@ -673,8 +673,8 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
             }
             seg_reduce2<64, false>(rmax, rmaxd, lane);
             const double amax = rmax > 1.0 ? 1.0 / rmax : 1.0, amaxd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;
-            const double alpha = (amax >= 1.0) ? 1.0 : 0.9995 * amax;        // primal step: z, s, t
-            const double alphad = (amaxd >= 1.0) ? 1.0 : 0.9995 * amaxd;     // dual step: lam
+            const double alpha = (amax >= 1.0) ? 1.0 : kFracToBoundary * amax;        // primal step: z, s, t
+            const double alphad = (amaxd >= 1.0) ? 1.0 : kFracToBoundary * amaxd;     // dual step: lam
 #ifndef MPC_PHASE_TIMING
             if (p.trace && lane == 0) p.trace[((size_t)inst * p.iter_max + it) * 4 + 2] = alpha;
 #endif

@@ -628,6 +628,8 @@ static void residuals(const qp_t *Q, iter_t *I, double (*rg)[NZ], double *rs, do
  * Returns 0 converged, 2 max-iter, 4 failure (NaN / step collapse).
  */
 /* optional per-iteration trace (mu, sigma, alpha, cmax) for debugging parity; not thread-safe */
+#define MU_DIVERGED 1e8
+#define FRAC_TO_BOUNDARY 0.999995   /* step = this fraction of the largest step that keeps t, lam > 0 */
 static double *g_trace = NULL; static int g_trace_cap = 0;
 void orc_set_trace(double *buf, int cap) { g_trace = buf; g_trace_cap = cap; }
 
@@ -667,6 +669,10 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
         residuals(Q, I, rg, rs, rb, re0, res);
         double mu = 0; for (int e = 0; e < ni; e++) mu += Q->it[e].lam * Q->it[e].t; mu = ni ? mu / ni : 0.0;
         if (!(res[0] == res[0]) || !(res[1] == res[1]) || !(mu == mu)) { status = 4; break; }
+        /* divergence (an infeasible QP: the hard boxes cannot be met): the complementarity measure of a healthy solve never leaves [~0, 1e2 mu0]
+         * (measured: <= 7e5 at mu0 = 1e4), that of an infeasible one grows without bound -- stop at 1e8 mu0 instead of iterating until the step
+         * collapses or the cap; shared with the HIP kernels (status 4, iterate untouched) */
+        if (mu > MU_DIVERGED * c->mu0) { status = 4; break; }
         /* Termination (shared spec with the HIP kernel): linear residuals (dynamics, initial condition, rho - t; they
          * all decay by the same factor prod(1 - alpha_k)) and the largest complementarity product below qp_tol.
          * The stationarity residual res[0] is REPORTED, not gated: late in the iteration its rounding floor is
@@ -733,13 +739,13 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
                 for (int e = 0; e < ni; e++) { item_t *q = &Q->it[e]; mu_aff += (q->lam + amaxd * q->dlam) * (q->t + amax * q->dt_); q->dlam_aff = q->dlam; q->dt_aff = q->dt_; }
                 mu_aff = ni ? mu_aff / ni : 0.0;
                 double ratio = mu > 0 ? mu_aff / mu : 0.0;
-                sigma = ratio * ratio * ratio;
+                sigma = ratio * ratio;      /* centring: (mu_aff / mu)^2, shared with the HIP kernels (rti_kernel.hpp kFracToBoundary) */
                 if (sigma > 1.0) sigma = 1.0;
                 if (ni == 0) { alpha = 1.0; break; }
             } else {
                 /* separate primal and dual step lengths (z, s, t move by alpha; lam by alphad) */
-                alpha = 0.9995 * amax; if (amax >= 1.0) alpha = 1.0; if (alpha > 1.0) alpha = 1.0;
-                alphad = 0.9995 * amaxd; if (amaxd >= 1.0) alphad = 1.0;
+                alpha = FRAC_TO_BOUNDARY * amax; if (amax >= 1.0) alpha = 1.0; if (alpha > 1.0) alpha = 1.0;
+                alphad = FRAC_TO_BOUNDARY * amaxd; if (amaxd >= 1.0) alphad = 1.0;
             }
         }
         if (g_trace && it < g_trace_cap) { g_trace[4 * it] = mu; g_trace[4 * it + 1] = sigma; g_trace[4 * it + 2] = alpha; g_trace[4 * it + 3] = res[3]; }

@@ -12,8 +12,8 @@
  * from /root/reference and from this image), and the reference holds no unit tests or golden vectors for (X+, U+, u*).  What it does
  * hold are the closed-loop tables it RECORDED (src/simulation/test_data/20221031_*_experiment_data.csv: 100 seeds x
  * [hit, reached, min_margin, dist_to_goal, iters, out_of_bounds], protocol src/simulation/experiments.py:20-36).  Driven with the
- * reference's own numpy random streams per seed, this oracle's closed loop (tests/helpers.py::OracleLoop) reproduces 337 of the 800
- * recorded rows with the control-step count exact and min_margin / dist_to_goal to 1e-3 (249 to 1e-6, median deviation 5e-9):
+ * reference's own numpy random streams per seed, this oracle's closed loop (tests/helpers.py::OracleLoop) reproduces 342 of the 800
+ * recorded rows with the control-step count exact and min_margin / dist_to_goal to 1e-3 (243 to 1e-6, median deviation per table 2e-9 .. 3e-7):
  * every row on which acados' QP converged throughout.  The remaining rows contain a QP that hit HPIPM's iteration cap or failed,
  * where the recorded tables themselves disagree between caps.  That pins cost scaling, the levenberg_marquardt term (scaled by the
  * stage interval), the slack schedule, the integrator, the status-4 reset and the aliasing defect D2 -- any other setting of the

@@ -341,7 +341,7 @@ def test_longest_horizon_with_ten_obstacles_takes_the_compact_stage_blocks(env, 
     P = oracle_P(orc, cfg, obst); Xg, Ug = oracle_guess(orc, cfg, x0)
     o = orc.rti_solve_batch(cfg, x0, P, goal, Xg, Ug)
     with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
-        assert s.kernel_name(B) == "rti_solve_kernel<10, 64, 3>"
+        assert s.kernel_name(B) == "rti_solve_kernel<10, 64, 3, false>"
         s.reset_guess(x0); g = s.solve(x0, obst, goal); X, U = s.get_traj(B)     # obstacle states in: look-ahead staged in LDS
     assert (g["status"] == o["status"]).all()
     ok = o["status"] == 0
@@ -406,7 +406,7 @@ def test_automatic_lane_mapping(env):
             assert s.lanes_per_stage(1) == 3 and s.lanes_per_stage(1024) == 3 and s.lanes_per_instance(1024) == 64
             assert s.lanes_per_stage(8192) == 3 and s.waves_per_simd(4096) == 1 and s.waves_per_simd(4097) == 2 and s.waves_per_simd(8192) == 2
             assert s.lanes_per_stage(8193) == 1 and s.lanes_per_instance(8193) == 21 and s.lanes_per_instance(65536) == 21     # three per wavefront
-            assert s.kernel_name(65536) == "rti_solve_kernel<3, 21, 3>" and s.kernel_name(1024) == "rti_split_kernel<3, 3, false>"
+            assert s.kernel_name(65536) == "rti_solve_kernel<3, 21, 3, false>" and s.kernel_name(1024) == "rti_split_kernel<3, 3, false, false>"
             s.set_waves_per_simd(1)
             assert s.waves_per_simd(8192) == 1
             assert _lib.lib().mpc_set_waves_per_simd(s._h, 3) == _lib.MPC_ERR_ARG
@@ -419,7 +419,7 @@ def test_automatic_lane_mapping(env):
         with mpc_gpu.BatchedMpc(10, 3, 1.0, max_batch=70000) as s:
             assert s.lanes_per_stage(12288) == 3 and s.lanes_per_stage(12289) == 1 and s.lanes_per_instance(65536) == 16
         with mpc_gpu.BatchedMpc(50, 10, 5.0, max_batch=8) as s:
-            assert s.kernel_name(8) == "rti_solve_kernel<10, 64, 3>"                        # long horizon: compact LDS stage blocks
+            assert s.kernel_name(8) == "rti_solve_kernel<10, 64, 3, false>"                        # long horizon: compact LDS stage blocks
         with mpc_gpu.BatchedMpc(31, 3, 3.1, max_batch=8) as s:
             assert s.lanes_per_stage(8) == 2
         with mpc_gpu.BatchedMpc(32, 3, 3.2, max_batch=8) as s:

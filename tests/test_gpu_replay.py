@@ -7,7 +7,7 @@ obstacles, init_guess_when_error, at most 400 control steps; the obstacle noise 
 What is asserted, and why these numbers (profiles/r02_seed_replay.json has the full scan over the 16 switch combinations):
   * the seeds SURVEY.md section 4 lists as bit-stable across the recorded QP_ITER caps (acados' QP always converged, so the closed loop is
     a function of the mathematical problem alone) reproduce the recorded row: control-step count EXACTLY, min_margin to 1e-4
-    (measured: <= 6e-8 RANDOM, <= 2.4e-6 EDGE after 100+ closed-loop steps), dist_to_goal to 1e-3 (measured <= 3.2e-4), all three flags;
+    (measured: <= 2e-8 RANDOM, <= 2.7e-6 EDGE after 100+ closed-loop steps), dist_to_goal to 1e-3 (measured <= 3.2e-4), all three flags;
   * over all 100 seeds at least 40 rows are reproduced to 1e-3 with exact step counts (measured 48 / 55): the remainder contains an
     acados QP that hit its cap or failed, where the recorded tables themselves disagree between caps (57 / 63 rows keep their step count
     from QP_ITER 100 to 50);
@@ -66,7 +66,7 @@ def test_recorded_rows_are_reproduced_per_seed(mapping, stem):
 def test_short_horizon_table_and_iteration_cap(mapping):
     """TF = 1 / N = 10 / QP_ITER = 50 (20221031_224515) and the QP_ITER = 25 table of the long horizon (20221031_221343)"""
     tb, rows, _ = replay(mapping, "20221031_224515")
-    assert row_match(tb, rows, 1e-3).sum() >= 45 and row_match(tb, rows, 1e-6).sum() >= 40           # measured 53 / 50
+    assert row_match(tb, rows, 1e-3).sum() >= 45 and row_match(tb, rows, 1e-6).sum() >= 40           # measured 54 / 49
     tb, rows, _ = replay(mapping, "20221031_221343")
     assert row_match(tb, rows, 1e-3).sum() >= 15                                                      # measured 21 (cap 25 truncates often)
 

@@ -86,8 +86,8 @@ def test_recorded_tables_are_the_expected_statistics():
 
 
 # ---- the oracle against the closed loops the reference RECORDED (per seed) --------------------------------------------------------
-# Seeds of four recorded tables whose row the oracle reproduces to 1e-6 (profiles/r02_oracle_seed_replay.json lists all of them: 249 of
-# the 800 recorded rows to 1e-6, 337 to 1e-3; the others contain an acados QP that hit its iteration cap or failed, where the recorded
+# Seeds of four recorded tables whose row the oracle reproduces to 1e-6 (profiles/r02_oracle_seed_replay.json lists all of them: 243 of
+# the 800 recorded rows to 1e-6, 342 to 1e-3; the others contain an acados QP that hit its iteration cap or failed, where the recorded
 # tables themselves disagree between caps).  This is what pins the oracle's SOLVE -- cost scaling, LM term, slack
 # schedule, integrator, status-4 handling, the aliasing defect D2 -- to what acados computed in October 2022.
 RECORDED_SEEDS = {
