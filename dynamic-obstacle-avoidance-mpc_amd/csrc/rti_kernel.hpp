@@ -503,6 +503,17 @@ struct RowLdsC {
     __device__ __forceinline__ RowLdsC(double *base, int N, double *table) : W(base), H(base + WS * N), R(base + WS * N), C(table) {}
 };
 
+// Every solve kernel is ONE wavefront per workgroup, and the LDS executes a wavefront's requests in order: a write is visible to a later read of
+// another lane without waiting for it.  A workgroup barrier (__syncthreads) would drain the LDS queue first (s_waitcnt lgkmcnt(0), ~100 cycles a
+// lone wavefront cannot hide, eight to fourteen times per interior-point iteration); release / acquire at wavefront scope orders the accesses for
+// the compiler and emits nothing.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ uint32_t lds_address(const void *p) { return (uint32_t)(uintptr_t)p; }     // low half of a flat LDS address = LDS byte offset
 
 template <class LT>
@@ -1527,12 +1538,12 @@ __device__ __forceinline__ void mfma_factor(int lane, int N, const MfmaLds L, do
         // (every kSymPeriod-th stage is enough to keep the antisymmetric part at rounding level; the transpose costs ~400 cycles)
         if ((t % kSymPeriod) == 0) {
             if (in8) { L.TT[MfmaLds::at(grp, col)] = Pt[0]; L.TT[MfmaLds::at(grp + 4, col)] = Pt[1]; }
-            __syncthreads();
+            wave_sync();
             if (in8) {
                 Pt[0] = 0.5 * (Pt[0] + L.TT[MfmaLds::at(col, grp)]);
                 Pt[1] = 0.5 * (Pt[1] + L.TT[MfmaLds::at(col, grp + 4)]);
             }
-            __syncthreads();
+            wave_sync();
         }
         if (grp >= 2 && col < 6) L.KO[16 * t + (grp - 2) * 6 + col] = Kt[0];
         if (lane == 0) { L.KO[16 * t + 12] = i00; L.KO[16 * t + 13] = l; L.KO[16 * t + 14] = i11; }
@@ -1680,7 +1691,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 Pl[(k * NOBST + i) * 2] = ox; Pl[(k * NOBST + i) * 2 + 1] = oy;
             }
         }
-        __syncthreads();
+        wave_sync();
         if constexpr (PLDS) myP = Pl + (act ? i : 0) * NOBST * 2;
         else {
 #pragma unroll
@@ -1741,7 +1752,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     if (USE_MFMA) {
         // zero the operand tiles once, then every stage lane writes its W~_t = [A b B; 0 1 0] (cols: x0..x4, 1, ua, ual)
         for (int k = lane; k < 64 * N + 64 * (N + 1); k += 64) ML.WB[k] = 0.0;
-        __syncthreads();
+        wave_sync();
         if (has_u) {
             double *w = ML.WB + 64 * i;
             const double Arow[5][5] = {{1.0, 0.0, S.a02, S.a03, S.a04}, {0.0, 1.0, S.a12, S.a13, S.a14}, {0.0, 0.0, 1.0, 0.0, dt},
@@ -2034,9 +2045,9 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                     hc[MfmaLds::at(6, 5)] = lu0; hc[MfmaLds::at(5, 6)] = lu0;
                     hc[MfmaLds::at(7, 5)] = lu1; hc[MfmaLds::at(5, 7)] = lu1;
                 }
-                __syncthreads();
+                wave_sync();
                 mfma_factor(lane, N, ML, rhoPi);
-                __syncthreads();
+                wave_sync();
                 F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;
 #pragma unroll
                 for (int c = 0; c < 5; c++) { F.K0[c] = 0.0; F.K1[c] = 0.0; }
@@ -2072,7 +2083,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                     }
                     }
                 }
-                __syncthreads();
+                wave_sync();
                 MPC_TICK(9);
 #ifdef MPC_FACTOR_PLAIN
                 rowpar_factor(lane, N, RS, sweep_worker);
@@ -2090,7 +2101,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                     rowpar_factor_fast(lane, N, RS, sweep_worker);
                 }
 #endif
-                __syncthreads();
+                wave_sync();
                 F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;
 #pragma unroll
                 for (int c = 0; c < 5; c++) { F.K0[c] = 0.0; F.K1[c] = 0.0; }
@@ -2130,9 +2141,9 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #pragma unroll
                 for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = SLDS ? rhoPi * lds_raw[RowLdsC::CT + slot * 5 + c] : x_init[c];
             }
-            __syncthreads();
+            wave_sync();
             rowpar_vector_fast<true>(lane, N, RS, sweep_worker);
-            __syncthreads();
+            wave_sync();
             if (act) {
                 const double *xx = RL.H + LT::HS * i + RowVec::X;
                 double u0 = F.k0, u1 = F.k1;
@@ -2256,9 +2267,9 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #pragma unroll
                     for (int c = 0; c < 5; c++) cc[c] = gc[2 + c] + F.K0[c] * gc[0] + F.K1[c] * gc[1];
                 }
-                __syncthreads();
+                wave_sync();
                 rowpar_vector_fast<false>(lane, N, RS, sweep_worker);
-                __syncthreads();
+                wave_sync();
                 if (has_u) {    // feed-forward of the corrector right-hand side: k = -Muu^-1 (gc_u + B' p_{t+1})
                     const double *pp = RL.H + LT::HS * (i + 1) + RowVec::P;
                     const double pv[5] = {pp[0], pp[1], pp[2], pp[3], pp[4]};
@@ -2282,9 +2293,9 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #pragma unroll
                 for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = 0.0;
             }
-            __syncthreads();
+            wave_sync();
             rowpar_vector_fast<true>(lane, N, RS, sweep_worker);
-            __syncthreads();
+            wave_sync();
             if (act) {
                 const double *xx = RL.H + LT::HS * i + RowVec::X;
                 double u0 = F.k0, u1 = F.k1;

@@ -147,7 +147,7 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
                 lds_P[k * NOBST * 2 + lane] = q;
             }
         }
-        __syncthreads();
+        wave_sync();
     }
     MPC_TICK(10);
     if (p.obst) {       // (two branches, not a select between an LDS and a global pointer: that would be a flat load)
@@ -444,7 +444,7 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
         MPC_TICK(9);
         // (the one-block asm variant rowpar_factor_fast saves 12 instructions per stage but claims 84 fixed registers: here, where the row
         // state lives in VGPRs next to the sweep, the extra AGPR round trips cost more than it gains -- measured 150.7 vs 148.0 us at C2)
@@ -452,7 +452,7 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
         if constexpr (!W2) mfma4_factor(lane, N, RL); else
 #endif
         rowpar_factor(lane, N, RL, lane < 16);
-        __syncthreads();
+        wave_sync();
         StageFac F;
         F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;
 #pragma unroll
@@ -486,11 +486,11 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
 #pragma unroll
             for (int c = 0; c < 5; c++) RL.R[RowVec::X + c] = x_init[c];
         }
-        __syncthreads();
+        wave_sync();
         MPC_TICK(3);
         rowpar_vector_fast<true>(lane, N, RL, lane < 16);
         MPC_TICK(15);
-        __syncthreads();
+        wave_sync();
         double za[7] = {0, 0, 0, 0, 0, 0, 0};
         if (act) {
             const double *xx = RL.R + LT::HS * i + RowVec::X;
@@ -601,9 +601,9 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
 #pragma unroll
                 for (int c = 0; c < 5; c++) cc[c] = gc[2 + c] + F.K0[c] * gc[0] + F.K1[c] * gc[1];
             }
-            __syncthreads();
+            wave_sync();
             rowpar_vector_fast<false>(lane, N, RL, lane < 16);
-            __syncthreads();
+            wave_sync();
             if (has_u) {        // feed-forward of the corrector right-hand side: k = -Muu^-1 (gc_u + B' p_{t+1}); owner lane (it has gc)
                 const double *pp = RL.R + LT::HS * (i + 1) + RowVec::P;
                 const double pv[5] = {pp[0], pp[1], pp[2], pp[3], pp[4]};
@@ -623,9 +623,9 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
 #pragma unroll
             for (int c = 0; c < 5; c++) RL.R[RowVec::X + c] = 0.0;
         }
-        __syncthreads();
+        wave_sync();
         rowpar_vector_fast<true>(lane, N, RL, lane < 16);
-        __syncthreads();
+        wave_sync();
         double dz[7] = {0, 0, 0, 0, 0, 0, 0};
         if (act) {
             const double *xx = RL.R + LT::HS * i + RowVec::X;
