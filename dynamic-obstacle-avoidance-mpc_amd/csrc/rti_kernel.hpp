@@ -27,7 +27,10 @@
 #include <stdint.h>
 #include <type_traits>
 
-// Diagnostic build only (-DMPC_PHASE_TIMING, scripts/phase_timing.py): per-phase cycle counts into KParams::trace.
+// Diagnostic builds (never the shipped library; each script compiles its own copy):
+//   -DMPC_PHASE_TIMING   scripts/phase_timing.py      per-phase cycle counts into KParams::trace
+//   -DMPC_COMPACT_PLAIN  scripts/asm_factor_check.py  compiler-scheduled factor sweep on the compact stage blocks instead of the one-block asm
+//   -DMPC_MFMA4          scripts/mfma4_check.py       factor sweep on 4x4x4 matrix-core blocks (one instance per wavefront, dense blocks)
 #ifdef MPC_PHASE_TIMING
 #define MPC_T0() long long t_prev_ = clock64()
 #define MPC_TICK(k) do { const long long t_now_ = clock64(); tacc_[k] += t_now_ - t_prev_; t_prev_ = t_now_; } while (0)
