@@ -216,8 +216,9 @@ int mpc_get_lanes_per_stage(mpc_handle *h, int batch);
 int mpc_set_instance_scheduling(mpc_handle *h, int on);
 int mpc_get_instance_order(mpc_handle *h, int batch, int32_t *order);
 /* name of the solve kernel instantiation a batch of this size runs (as rocprofv3 prints it, without the namespace), for measurement
- * records: "rti_split_kernel<n_obst, lanes per stage, two wavefronts per SIMD>" or "rti_solve_kernel<n_obst, lanes per instance, sweeps>"
- * (sweeps: 0 systolic, 1 matrix cores, 2 row-parallel on dense LDS blocks, 3 row-parallel on compact LDS blocks).  lookahead: whether the
+ * records: "rti_split_kernel<row capacity, lanes per stage, two wavefronts per SIMD, masked>" or "rti_solve_kernel<row capacity, lanes per
+ * instance, sweeps, masked>" (row capacity: 3, 5 or 10 obstacle row pairs per stage, the smallest that holds n_obst; masked: n_obst is below it;
+ * sweeps: 0 systolic, 1 matrix cores, 2 row-parallel on dense LDS blocks, 3 row-parallel on compact LDS blocks).  lookahead: whether the
  * obstacle look-ahead runs inside the kernel (mpc_closed_loop_step_dev) -- it enters the LDS budget that selects the block layout. */
 int mpc_get_kernel_name(mpc_handle *h, int batch, int lookahead, char *buf, int len);
 int mpc_set_waves_per_simd(mpc_handle *h, int waves);
