@@ -239,3 +239,27 @@ def test_visualisation_inputs_match_the_shim_loop(env):
     assert (vis["pred"][0] == 0).all() and np.abs(vis["pred"][1:] - prob.pred).max() < 1e-9
     for j, o in enumerate(prob.obstacles):
         assert np.abs(vis["obstacles"][j] - o.get_trajectory().T).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_packed_small_batch_transfer_equals_the_general_host_path(env):
+    """Host-pointer solves of up to 64 instances travel as one pinned block each way with the look-ahead computed in the solve kernel
+    (mpc_api.hip::solve_common); larger batches take separate copies.  Same instances, same kernel -> bit-identical outputs, for obstacle
+    states and for explicit P, over three closed-loop steps."""
+    mpc_gpu, orc = env
+    from helpers import random_batch, oracle_P
+    N, no = 20, 3
+    x0, goal, obst = random_batch(70, no, seed=31)
+    P = oracle_P(orc, orc.config(N, no, 2.0), obst)
+    outs = {}
+    for B in (64, 70):
+        with mpc_gpu.BatchedMpc(N, no, 2.0, max_batch=B) as s:
+            s.reset_guess(x0[:B]); rec = []
+            for k in range(3):
+                g = s.solve(x0[:B], (obst if k != 1 else P)[:B], goal[:B]); X, U = s.get_traj(B); s.shift(B)
+                rec.append((g, X, U))
+            outs[B] = rec
+    for (ga, Xa, Ua), (gb, Xb, Ub) in zip(outs[64], outs[70]):
+        assert np.array_equal(Xa, Xb[:64]) and np.array_equal(Ua, Ub[:64])
+        for k in ("u0", "cost", "status", "iters"):
+            assert np.array_equal(np.asarray(ga[k]), np.asarray(gb[k])[:64]), k
