@@ -95,6 +95,8 @@ static constexpr double kTLMin = 1e-13;  // floor for lam and t (see oracle/mpc_
 static constexpr double kFracToBoundary = 0.999995;
 // mu of a healthy solve stays below ~1e2 mu0, that of an infeasible QP grows without bound: beyond kMuDiverged * mu0 the solve has failed (status 4)
 static constexpr double kMuDiverged = 1e8;
+// ... and a solve that reaches the iteration cap with mu above kMuCapFailed * mu0 was on its way there: status 4, not 2 (its step is not applied)
+static constexpr double kMuCapFailed = 1e4;
 
 // Gauss-Legendre 4-point rule on [0,1]: the reference's IRK integrator (robot_ocp_problem.py:129) with acados defaults
 // (GL, 4 stages, 1 step) collapses to closed-form psi,v,omega and this quadrature for x,y.
@@ -492,7 +494,12 @@ struct RowLdsC {
     static constexpr int CT = 24;                     // constant table: [3 j + m] = W~[2 + m][j] for j != 5
     static constexpr bool COMPACT = true;
     static __host__ __device__ constexpr int per_instance(int N) { return WS * N + HS * (N + 1); }
-    static __host__ __device__ constexpr int pad_front(int N) { return AHEAD * HS > WS * (N - 1) ? AHEAD * HS - WS * (N - 1) : WS; }
+    // front padding: what the operand requests ahead of stage 0 may touch -- and, with the lean row state, 5 words per instance of the wavefront for
+    // the initial-condition residual (at least 16 words: N = 9 would leave 3, found by scripts/fuzz_parity.py)
+    static __host__ __device__ constexpr int pad_front(int N)
+    {
+        return (AHEAD * HS > WS * (N - 1) ? AHEAD * HS - WS * (N - 1) : WS) < 16 ? 16 : (AHEAD * HS > WS * (N - 1) ? AHEAD * HS - WS * (N - 1) : WS);
+    }
     static __host__ __device__ constexpr int pad_rear() { return AHEAD * HS; }
     static __host__ __device__ constexpr int total(int N, int instances) { return CT + pad_front(N) + instances * per_instance(N) + pad_rear(); }
     // with the obstacle look-ahead of the instances kept resident behind the blocks (10 obstacles, "lean" row state): the rear padding is only
@@ -1927,7 +1934,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         if (running) {
             if (!(mu == mu) || !(fabs(mu) <= kMuDiverged * p.mu0)) { status = 4; running = false; it_done = it; }      // NaN, or diverged: an infeasible QP
             else if (lin <= p.tol && cmax <= p.tol) { status = 0; running = false; it_done = it; }
-            else if (it >= p.iter_max) { status = 2; running = false; it_done = it; }
+            else if (it >= p.iter_max) { status = (mu > kMuCapFailed * p.mu0) ? 4 : 2; running = false; it_done = it; }      // at the cap with mu far above a healthy solve's: diverging, not slow
         }
         if (__ballot(running) == 0ull) break;
         MPC_TICK(0);

@@ -456,7 +456,7 @@ def test_two_wavefronts_per_simd_variant_is_bitwise_the_one_wavefront_variant(en
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,no,B", [(20, 3, 500), (20, 5, 100), (10, 3, 200), (17, 10, 40), (2, 3, 31)])
+@pytest.mark.parametrize("N,no,B", [(20, 3, 500), (20, 5, 100), (10, 3, 200), (17, 10, 40), (9, 10, 30), (8, 10, 30), (2, 3, 31)])
 def test_three_instances_per_wavefront(env, N, no, B):
     """G = 21 (lanes [0,21), [21,42), [42,63) of a wavefront hold three instances; compact LDS stage blocks; the sweeps of the three
     instances run in DPP rows 0..2) against two / four instances per wavefront and against the oracle: statuses equal, iteration counts
