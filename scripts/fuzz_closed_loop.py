@@ -1,0 +1,71 @@
+"""Randomised sweep of the FUSED closed-loop control step (mpc_closed_loop_step_dev) against the oracle-side loop (tests/helpers.py::OracleLoop),
+resynchronised before every step: horizon, obstacle count, batch, lane mapping, the aliasing defect switch and the noise drawn at random.
+Per step and instance: status, obstacle states bit for bit, episode flags and step counter, plant state / warm start / margin to 1e-6 (or the
+step judged by the QP).  usage (GPU box): python scripts/fuzz_closed_loop.py [seconds] [seed]   -> gpurun_out/fuzz_closed_loop.json"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "dynamic-obstacle-avoidance-mpc_amd"), os.path.join(ROOT, "tests")]
+import numpy as np
+import mpc_gpu
+from mpc_gpu import _lib
+from oracle import oracle as orc
+from helpers import OracleLoop, qp_merit, random_batch
+from test_gpu_closed_loop import GpuLoop
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+t0 = time.time(); log = []; fails = []
+while time.time() - t0 < budget:
+    N = int(rng.choice([3, 9, 10, 15, 20, 21, 31, 40, 50])); no = int(rng.integers(1, 11)); B = int(rng.choice([1, 3, 8, 21, 40]))
+    if N > 31: B = min(B, 12)
+    alias = bool(rng.random() > 0.4); lps = int(rng.choice([0, 1])); lanes = int(rng.choice([0, 0, 16, 21, 32, 64])); K = 6
+    seed = int(rng.integers(1 << 30))
+    x0, goal, obst = random_batch(B, no, seed=seed)
+    x0[:, 3] = rng.uniform(-0.5, 1.5, B)
+    noise = np.random.default_rng(seed).standard_normal((K, B, no, 2))
+    cfg = orc.config(N, no, 0.1 * N, qp_tol=1e-8)
+    rec = dict(N=N, n_obst=no, B=B, alias=alias, lps=lps, lanes=lanes, seed=seed)
+    mpc_gpu.BatchedMpc.default_lanes_per_stage = lps
+    try:
+        g = GpuLoop(mpc_gpu, N, no, 0.1 * N, x0, goal, obst, alias=alias)
+        if lanes: _lib.lib().mpc_set_lanes_per_instance(g.m._h, lanes)
+        rec["kernel"] = g.m.kernel_name(B)
+        loops = [OracleLoop(orc, cfg, x0[b], goal[b], obst[b], alias=alias) for b in range(B)]
+        worst = 0.0
+        for k in range(K):
+            before = g.host()
+            for b, L in enumerate(loops):
+                L.x, L.obst = before["x0"][b].copy(), before["obst"][b].copy(); L.X, L.U = before["X"][b].copy(), before["U"][b].copy()
+                L.min_margin, L.flags, L.steps = float(before["margin"][b]), int(before["flags"][b]), int(before["steps"][b])
+            g.step(noise[k]); after = g.host()
+            for b, L in enumerate(loops):
+                r = L.step(noise[k, b])
+                why = None
+                if r is None:
+                    if not all(np.array_equal(after[key][b], before[key][b]) for key in ("x0", "obst", "X", "U")) or after["steps"][b] != before["steps"][b]: why = "finished episode moved"
+                elif after["status"][b] != r["status"]: why = f"status {after['status'][b]} vs {r['status']}"
+                elif not np.array_equal(after["obst"][b], L.obst): why = "obstacle motion"
+                elif after["flags"][b] != L.flags or after["steps"][b] != L.steps: why = f"flags/steps {after['flags'][b]},{after['steps'][b]} vs {L.flags},{L.steps}"
+                elif r["status"] == 0:
+                    d = max(np.abs(after["X"][b] - L.X).max(), np.abs(after["U"][b] - L.U).max(), np.abs(after["x0"][b] - L.x).max())
+                    if d > 1e-6:
+                        Xn = np.vstack([before["x0"][b][None], after["X"][b][:N]]); Un = np.vstack([after["u0"][b][None], after["U"][b][:N - 1]])
+                        P = orc.predict_params(cfg, before["obst"][b])
+                        fg, eqg, bg = qp_merit(orc, cfg, before["x0"][b], P, goal[b], before["X"][b], before["U"][b], Xn, Un)
+                        fo, _, _ = qp_merit(orc, cfg, before["x0"][b], P, goal[b], before["X"][b], before["U"][b], r["X"], r["U"])
+                        if not (eqg <= 1e-7 and bg <= 1e-7 and fg <= fo + 1e-7 * max(1.0, abs(fo))): why = f"iterate d={d:.2e} f_gpu={fg} f_oracle={fo}"
+                    else:
+                        worst = max(worst, d)
+                        if abs(after["margin"][b] - L.min_margin) > 1e-6: why = "margin"
+                if why: fails.append(dict(rec, step=k, inst=b, why=why))
+        rec["worst"] = worst
+        g.close()
+    except Exception as e:
+        fails.append(dict(rec, why="exception", msg=str(e)[:300]))
+    log.append(rec)
+mpc_gpu.BatchedMpc.default_lanes_per_stage = 0
+kernels = sorted({r.get("kernel", "?") for r in log})
+out = dict(configurations=len(log), distinct_kernels=len(kernels), kernels=kernels, failures=fails, worst=max((r.get("worst", 0.0) for r in log), default=0.0))
+print(json.dumps({k: out[k] for k in ("configurations", "distinct_kernels", "failures", "worst")}, indent=1)[:5000])
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "fuzz_closed_loop.json"), "w"), indent=1)
+sys.exit(1 if fails else 0)
