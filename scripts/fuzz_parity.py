@@ -23,7 +23,9 @@ while time.time() - t0 < budget:
     seed = int(rng.integers(1 << 30))
     x0, goal, obst = random_batch(B, no, seed=seed)
     cfg = orc.config(N, no, 0.1 * N, soft_h=soft, bx_terminal=bxt)
-    rec = dict(N=N, n_obst=no, B=B, lps=lps, lanes=lanes, waves=waves, soft_h=soft, bx_terminal=bxt, seed=seed)
+    use_alpha = bool(soft and B <= 65 and rng.random() < 0.3)     # an explicit slack schedule (mpc_set_slack_schedule), some stages with zero weight
+    alpha = rng.uniform(0.0, 3e4, (B, N + 1)) * (rng.random((B, N + 1)) > 0.15) if use_alpha else None
+    rec = dict(N=N, n_obst=no, B=B, lps=lps, lanes=lanes, waves=waves, soft_h=soft, bx_terminal=bxt, seed=seed, explicit_slack_schedule=use_alpha)
     try:
         with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B, soft_h=soft, bx_terminal=bxt) as s:
             L = _lib.lib()
@@ -31,12 +33,17 @@ while time.time() - t0 < budget:
             if lanes: L.mpc_set_lanes_per_instance(s._h, lanes)
             if waves: L.mpc_set_waves_per_simd(s._h, waves)
             rec["kernel"] = s.kernel_name(B)
+            if use_alpha: s.set_slack_schedule(alpha)
             Xo, Uo = oracle_guess(orc, cfg, x0); s.reset_guess(x0)
             P = oracle_P(orc, cfg, obst)
             worst = 0.0
             for k in range(2):
                 g = s.solve(x0, obst if k == 0 else P, goal); X, U = s.get_traj(B)
-                o = orc.rti_solve_batch(cfg, x0, P, goal, Xo, Uo)
+                if use_alpha:
+                    rs = [orc.rti_solve(cfg, x0[b], P[b], goal[b], Xo[b], Uo[b], alpha=alpha[b]) for b in range(B)]
+                    o = {kk: np.array([r[kk] for r in rs]) for kk in ("X", "U", "u0", "cost", "status", "iters")}
+                else:
+                    o = orc.rti_solve_batch(cfg, x0, P, goal, Xo, Uo)
                 if not (g["status"] == o["status"]).all():
                     import ctypes as C
                     det = []
@@ -50,6 +57,9 @@ while time.time() - t0 < budget:
                 ok = o["status"] == 0
                 d = np.abs(X - o["X"]).reshape(B, -1).max(1)
                 for b in np.nonzero(ok & (d > 1e-6))[0]:
+                    if use_alpha:          # (qp_merit assembles the QP with the built-in schedule: a plain bound instead)
+                        if d[b] > 1e-4: fails.append(dict(rec, step=k, why="iterate (explicit slack schedule)", inst=int(b), d=float(d[b])))
+                        continue
                     fg, eqg, bg = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xo[b], Uo[b], X[b], U[b])
                     fo, _, _ = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xo[b], Uo[b], o["X"][b], o["U"][b])
                     if not (eqg <= 1e-7 and bg <= 1e-7 and fg <= fo + 1e-7 * max(1.0, abs(fo))):
