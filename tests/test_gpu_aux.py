@@ -192,6 +192,23 @@ def test_scenario_generator_kernel_bit_exact_vs_reference_draws(env, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 4, 7, 9])
+def test_scenario_generator_and_look_ahead_for_any_obstacle_count(env, n):
+    """obstacle counts the golden vectors do not hold: the device generator against mpc_gpu.world.reference_streams (plain numpy; the recorded-table replays of
+    test_oracle_golden.py / test_gpu_replay.py stand on it), bit for bit; the look-ahead kernel against the oracle's predictor"""
+    mpc_gpu, orc = env
+    from mpc_gpu.world import reference_streams
+    with mpc_gpu.BatchedMpc(20, n, 2.0, max_batch=64) as s:
+        for scen in ("RANDOM", "EDGE", "CENTER"):
+            want = reference_streams(scen, range(5, 45), n, 1)[0]
+            got = s.generate_scenarios(scen, 40, seed0=5)
+            assert got.shape == want.shape and (got == want).all(), scen
+        cfg = orc.config(20, n, 2.0)
+        P = s.predict(want)
+        assert np.array_equal(P, np.stack([orc.predict_params(cfg, o) for o in want]))
+
+
+@pytest.mark.gpu
 def test_episode_harness_accepts_scenario_names(env):
     """run_episodes("EDGE") == run_episodes(<the reference's EDGE draws>) : same table (same noise stream, same scenarios)"""
     mpc_gpu, _ = env
