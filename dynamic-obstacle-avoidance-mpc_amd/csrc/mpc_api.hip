@@ -126,7 +126,8 @@ int pick_lanes(mpc_handle *h, int batch)
     if (h->lanes_override == 21) return 21;       // three instances per wavefront (N <= 20, row-parallel sweeps)
     // automatic: 17 <= N + 2 <= 22 (two instances per wavefront otherwise) with 3 or 5 obstacles, whenever pick_split leaves such a batch
     // to this mapping (more than 8 resp. 12 instances per SIMD)
-    if (!h->lanes_override && !h->use_mfma && h->row_parallel && h->cfg.n_obst != 10 && need > 16 && h->cfg.N <= 20 && batch > 8 * h->simd_count) return 21;
+    if (!h->lanes_override && !h->use_mfma && h->row_parallel && h->cfg.n_obst != 10 && need > 16 && h->cfg.N <= 20 &&
+        batch > (h->cfg.n_obst == 3 ? 8 : 7) * h->simd_count) return 21;
     if (h->lanes_override >= G || (h->lanes_override && h->lanes_override >= need)) G = h->lanes_override;
     return G;
 }
@@ -136,11 +137,11 @@ int pick_lanes(mpc_handle *h, int batch)
 // with 2 (N = 20) or 4 (N = 10) instances per wavefront | with 3 instances per wavefront):
 //                          batch 4096                  8192                       16384                      65536
 //   N = 20,  3 obstacles:  7.0 | 6.1 | 5.5 | 5.4      9.7 | 10.1 |  9.8 |  9.7    10.6 | 12.6 | 16.0 | 16.0   11.3 | 14.0 | 20.7 | 20.7
-//   N = 20,  5 obstacles:  6.1 | 4.7 | 4.3 | 4.2      8.0 |  7.2 |  7.4 |  7.7     8.7 |  8.7 |  9.4 | 11.3    9.2 |  9.5 | 10.7 | 14.2
+//   N = 20,  5 obstacles:  7.1 | 5.5 | 5.3 | 5.2      8.5 |  7.8 |  8.4 |  9.0     9.3 |  9.2 | 12.9 | 13.0    9.7 | 10.0 | 16.1 | 16.1   (lean row state, new constants)
 //   N = 20, 10 obstacles:  4.7 | 2.7 | 2.4 | 2.6      5.7 |  3.7 |  3.1 |  3.9     6.1 |  4.2 |  3.5 |  4.6    6.5 |  4.6 |  3.8 |  5.3
 //   N = 31,  3 obstacles:  4.2 | 3.4 | 4.0 |  -       4.9 |  5.2 |  5.2 |  -       5.1 |  6.0 |  5.7 |  -      5.4 |  6.6 |  6.1 |  -
 //   N = 10,  3 obstacles:  9.9 | 8.4 | 6.9 | 6.6     14.5 | 13.8 | 12.5 | 11.8    15.9 | 19.0 | 22.6 | 21.1   16.9 | 21.0 | 37.0 | 28.7
-//   N = 10,  5 obstacles:  8.5 | 6.0 | 5.2 | 4.8     12.1 |  9.4 |  9.6 |  9.1    13.2 | 12.0 | 15.2 | 14.8   14.0 | 13.0 | 19.6 | 19.6
+//   N = 10,  5 obstacles: 10.4 | 7.3 | 7.0 | 6.4     13.6 | 10.7 | 12.2 | 11.3    14.5 | 12.9 | 18.5 | 17.5   15.2 | 14.0 | 23.3 | 22.6   (lean row state, new constants)
 // * the stage-split mapping (rows of a stage over 3 lanes for N <= 20, 2 for N <= 31, one instance per wavefront; rti_split_kernel.hpp) wins
 //   up to ~8 instances per SIMD everywhere, and at every batch size with 10 obstacles (the one-lane row state spills) and for 20 < N <= 31;
 // * beyond that the one-lane mappings that pack 3 (17 <= N + 2 <= 22) or 4 (N + 2 <= 16) instances into a wavefront win for 3 and 5
@@ -155,7 +156,7 @@ int pick_split(mpc_handle *h, int batch)
     if (h->use_mfma || !h->row_parallel || h->lanes_override) return 1;
     if (h->split_override) return h->split_override <= fit ? h->split_override : fit;
     if (no != 10 && N + 2 <= 16 && batch > 12 * h->simd_count) return 1;                      // four instances per wavefront (G = 16)
-    if (no != 10 && N + 2 > 16 && N <= 20 && batch > (no == 3 ? 8 : 12) * h->simd_count) return 1;   // three instances per wavefront (G = 21)
+    if (no != 10 && N + 2 > 16 && N <= 20 && batch > (no == 3 ? 8 : 7) * h->simd_count) return 1;    // three instances per wavefront (G = 21)
     return fit;
 }
 

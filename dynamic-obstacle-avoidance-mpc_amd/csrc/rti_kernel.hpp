@@ -1623,8 +1623,12 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #define ROW_OFF(j) (MASKED && (j) >= nact)
 #define OBST_IN(j) (MASKED ? ((j) < nact ? (j) : nact - 1) : (j))
     constexpr bool USE_MFMA = FACT == 1, ROWPAR = FACT >= 2, COMPACT = FACT == 3;
-    constexpr bool LEAN = NOBST >= 10;          // ten obstacle pairs: recomputable row state is not carried (see obst_view below)
-    constexpr bool PLDS = LEAN && COMPACT;      // ... and the obstacle positions of a stage stay in LDS behind the compact stage blocks
+    // five and more obstacle pairs: recomputable row state is not carried (see obst_view below).  Measured per obstacle count (scripts/ab_workload.py,
+    // 65536 random scenarios): 3 obstacles -4.6 % (their state fits the registers: recomputing only adds instructions), 5 obstacles +8 % at N = 20 and
+    // +10 % at N = 10 (84 B of scratch and 58 accumulation registers less), 10 obstacles: the difference between 784 and 12 B of scratch
+    constexpr bool LEAN = NOBST >= 5;
+    constexpr bool PLDS = LEAN && COMPACT && NOBST >= 10;      // ... and, with ten, the obstacle positions of a stage stay in LDS behind the compact stage blocks (with five they
+                                                               // would cost the CU its fourth wavefront of three instances: 44 KB each)
     constexpr bool SLDS = PLDS;                 // ... as do the A / B entries (re-read from the W~ block) and the initial residual (front padding); on the
                                                 // 3-obstacle kernels, which do not spill, the same move costs 2 % (measured at C3) and is not made
     static_assert(!USE_MFMA || G == 64, "the matrix-core factorisation maps one instance per wavefront");

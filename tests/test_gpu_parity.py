@@ -413,7 +413,7 @@ def test_automatic_lane_mapping(env):
             s.set_lanes_per_instance(64)
             assert s.lanes_per_stage(8) == 1 and s.waves_per_simd(65536) == 1 and s.lanes_per_instance(65536) == 64
         with mpc_gpu.BatchedMpc(20, 5, 2.0, max_batch=70000) as s:
-            assert s.lanes_per_stage(12288) == 3 and s.waves_per_simd(12288) == 1 and s.lanes_per_instance(12289) == 21
+            assert s.lanes_per_stage(7168) == 3 and s.waves_per_simd(7168) == 1 and s.lanes_per_stage(7169) == 1 and s.lanes_per_instance(7169) == 21
         with mpc_gpu.BatchedMpc(20, 10, 2.0, max_batch=70000) as s:
             assert s.lanes_per_stage(65536) == 3 and s.waves_per_simd(65536) == 1           # 10 obstacles: never the 256-register build
         with mpc_gpu.BatchedMpc(10, 3, 1.0, max_batch=70000) as s:
