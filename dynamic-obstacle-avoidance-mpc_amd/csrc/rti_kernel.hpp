@@ -280,6 +280,14 @@ __device__ __forceinline__ double seg21_reduce(double v, int lane)
 }
 
 // reciprocal: hardware seed + two Newton steps (1-2 ulp); used for 1/t of the inequality rows
+// a value every lane of the wavefront holds identically (one instance per wavefront), moved to a scalar register pair
+__device__ __forceinline__ double wave_uniform(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __device__ __forceinline__ double rcp_nr(double x)
 {
     double r = __builtin_amdgcn_rcp(x);
@@ -1653,6 +1661,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #pragma unroll
     for (int c = 0; c < 5; c++) x0v[c] = p.x0[(size_t)inst * 5 + c];
     gl[0] = p.goal[(size_t)inst * 2]; gl[1] = p.goal[(size_t)inst * 2 + 1];
+    if constexpr (G == 64) { gl[0] = wave_uniform(gl[0]); gl[1] = wave_uniform(gl[1]); }      // one instance per wavefront: the goal is the same in every lane -> scalar registers
+                                                                                              // (with ten obstacles these four registers are the difference between 28 and 0 B of scratch)
     double *Xg = p.X + (size_t)inst * (N + 1) * 5, *Ug = p.U + (size_t)inst * N * 2;
     // episode already finished (goal reached): the instance idles, nothing of it is touched
     const bool ep_done = (p.fused & kFuseMetrics) && p.ep_flags && (p.ep_flags[inst] & 1);
@@ -1880,7 +1890,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     for (int k = 0; k < NB; k++) n_items_lane += ((k < 2) ? vbu : vbx) ? 2 : 0;
     n_items_lane += vs ? (soft ? 2 * nact : nact) : 0;
     const double n_items = seg_sum<G>((double)n_items_lane, lane);
-    const double inv_items = n_items > 0 ? 1.0 / n_items : 0.0;
+    double inv_items = n_items > 0 ? 1.0 / n_items : 0.0;
+    if constexpr (G == 64) inv_items = wave_uniform(inv_items);
     {   // Non-finite inputs (a diverged plant, a bad sensor frame, a poisoned warm start) must not pass as a converged solve: fmax() drops NaN, so
         // the residual norm above would not show them.  One sum over everything this lane read decides; the instance then fails at once (status 4).
         double fin = gl[0] + gl[1] + ui[0] + ui[1];
@@ -1893,6 +1904,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         if (!(fabs(fin) <= 1e300)) lin0 = INFINITY;
     }
     lin0 = seg_max<G>(lin0, lane);
+    if constexpr (G == 64) lin0 = wave_uniform(lin0);
 
     double z[7] = {0, 0, 0, 0, 0, 0, 0};
     double rhoPi = 1.0;

@@ -297,9 +297,9 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
 #pragma unroll
     for (int s = 0; s < NSL; s++) n_items_lane += sp[s] ? (soft ? 2 : 1) : 0;
     const double n_items = seg_sum<64>((double)n_items_lane, lane);
-    const double inv_items = n_items > 0 ? 1.0 / n_items : 0.0;
+    const double inv_items = wave_uniform(n_items > 0 ? 1.0 / n_items : 0.0);      // one instance per wavefront: per-instance scalars live in scalar registers
     if (!(fabs(fin) <= 1e300)) lin0 = INFINITY;
-    lin0 = seg_max<64>(lin0, lane);
+    lin0 = wave_uniform(seg_max<64>(lin0, lane));
 
     double z[7] = {0, 0, 0, 0, 0, 0, 0};
     double rhoPi = 1.0;
@@ -701,7 +701,7 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
                         rt2[s] = rcp_nr(t2[s]);
                     }
                 }
-                rhoPi *= (1.0 - alpha);
+                rhoPi = wave_uniform(rhoPi * (1.0 - alpha));
             }
         }
         MPC_TICK(8);
