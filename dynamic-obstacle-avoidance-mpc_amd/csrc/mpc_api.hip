@@ -232,7 +232,7 @@ SolvePlan plan_solve(mpc_handle *h, int batch, bool lookahead)
     // Compact stage blocks (look-ahead staged inside them): always with three instances per wavefront (13.5 KB per instance at N = 20:
     // four wavefronts of three per CU), and for long horizons on 64 lanes whenever the dense blocks would leave a CU fewer than the four
     // wavefronts its SIMDs can hold (N = 50, 10 obstacles: 51 KB -> 3 per CU dense, 32 KB -> 4 compact)
-    const bool compact = rowpar && (q.G == 21 || (q.G == 64 && dense > 40960));
+    const bool compact = rowpar && (q.G == 21 || (q.G == 64 && (dense > 40960 || no >= 10)));     // (ten row pairs: the compact kernel keeps its positions in LDS and has no scratch)
     q.fact = use_mfma ? 1 : (rowpar ? (compact ? 3 : 2) : 0);
     // (compact blocks with 10 obstacles: the look-ahead positions stay resident behind the blocks, rti_kernel.hpp PLDS)
     q.lds = compact ? (size_t)(no >= 10 ? mpc::RowLdsC::total_with_positions(N, ipw, no) : mpc::RowLdsC::total(N, ipw)) * sizeof(double) : dense;
