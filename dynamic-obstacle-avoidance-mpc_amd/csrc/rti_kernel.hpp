@@ -2423,11 +2423,16 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     if (p.trace && i == 0 && valid) { for (int k = 0; k < 10; k++) p.trace[((size_t)inst * p.iter_max) * 4 + k] = (double)tacc_[k]; }
 #endif
 
-    if constexpr (LEAN) {       // the plant state is read again here instead of being carried through the interior point (5 doubles per lane less)
-        const double *xg = p.x0 + (size_t)inst * 5;
+    if constexpr (LEAN || G != 64) {       // the plant state and the goal are read again here instead of being carried through the interior point (7 doubles per
+        const double *xg = p.x0 + (size_t)inst * 5;     // lane less; with one instance per wavefront the goal sits in scalar registers anyway)
         asm volatile("" : "+v"(xg));
 #pragma unroll
         for (int c = 0; c < 5; c++) x0v[c] = xg[c];
+        if constexpr (G != 64) {
+            const double *gg = p.goal + (size_t)inst * 2;
+            asm volatile("" : "+v"(gg));
+            gl[0] = gg[0]; gl[1] = gg[1];
+        }
     }
     // ---- full step on the iterate; status 4 leaves it unchanged ----
     const bool store = valid && !ep_done;
