@@ -715,6 +715,13 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
         if (!running) break;
     }
 
+    if constexpr (!W2) {        // the plant state and the goal are read again here instead of being carried through the interior point (14 registers less across
+        const double *xg = p.x0 + (size_t)inst * 5, *gg = p.goal + (size_t)inst * 2;      // the loop; the 256-register build keeps them in scalar registers)
+        asm volatile("" : "+v"(xg), "+v"(gg));
+#pragma unroll
+        for (int c = 0; c < 5; c++) x0v[c] = xg[c];
+        gl[0] = gg[0]; gl[1] = gg[1];
+    }
     // ---- full step on the iterate; status 4 leaves it unchanged ----
     const bool store = !ep_done;
     if (status != 4) {
