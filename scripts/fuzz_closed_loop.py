@@ -63,6 +63,7 @@ while time.time() - t0 < budget:
     except Exception as e:
         fails.append(dict(rec, why="exception", msg=str(e)[:300]))
     log.append(rec)
+    if len(log) % 100 == 0: print(f"{len(log)} configurations, {len(fails)} findings, {time.time() - t0:.0f} s", flush=True)      # (a silent GPU job is taken for hung)
 mpc_gpu.BatchedMpc.default_lanes_per_stage = 0
 kernels = sorted({r.get("kernel", "?") for r in log})
 out = dict(configurations=len(log), distinct_kernels=len(kernels), kernels=kernels, failures=fails, worst=max((r.get("worst", 0.0) for r in log), default=0.0))

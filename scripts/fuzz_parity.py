@@ -72,6 +72,7 @@ while time.time() - t0 < budget:
     except Exception as e:                      # an API error is a finding too
         fails.append(dict(rec, why="exception", msg=str(e)[:300]))
     log.append(rec)
+    if len(log) % 100 == 0: print(f"{len(log)} configurations, {len(fails)} findings, {time.time() - t0:.0f} s", flush=True)      # (a silent GPU job is taken for hung)
 kernels = sorted({r.get("kernel", "?") for r in log})
 out = dict(configurations=len(log), distinct_kernels=len(kernels), kernels=kernels, failures=fails, worst_dX=max((r.get("worst_dX", 0.0) for r in log), default=0.0), seconds=time.time() - t0)
 print(json.dumps({k: out[k] for k in ("configurations", "distinct_kernels", "failures", "worst_dX")}, indent=1)[:6000])
