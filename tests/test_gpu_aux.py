@@ -280,3 +280,36 @@ def test_packed_small_batch_transfer_equals_the_general_host_path(env):
         assert np.array_equal(Xa, Xb[:64]) and np.array_equal(Ua, Ub[:64])
         for k in ("u0", "cost", "status", "iters"):
             assert np.array_equal(np.asarray(ga[k]), np.asarray(gb[k])[:64]), k
+
+
+@pytest.mark.gpu
+def test_c_host_example_runs_the_same_closed_loop(env, tmp_path):
+    """examples/closed_loop.c links nothing but libmpcgpu.so (the C ABI of include/mpc_gpu.h) and must end where the Python mirror ends,
+    bit for bit: same entry points underneath, same host-pointer path."""
+    import shutil
+    import subprocess
+    mpc_gpu, _ = env
+    from mpc_gpu import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "closed_loop")
+    cc = shutil.which("gcc") or shutil.which("cc")
+    subprocess.check_call([cc, "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "closed_loop.c"), "-o", exe,
+                           "-L", libdir, "-lmpcgpu", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lm"])
+    steps = 25
+    out = subprocess.run([exe, str(steps)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rows = np.array([[float(v) for v in ln.split()] for ln in out.stdout.strip().splitlines()])
+    B, no = 4, 3
+    x = np.array([[-6.0 + b, -6.0, 0.7853981633974483, 0.0, 0.0] for b in range(B)])
+    goal = np.array([[5.0 - b, 5.0] for b in range(B)])
+    obst = np.array([[[-2.0 + 2.5 * j, -1.5 + 1.5 * j + 0.3 * b, 0.0, 0.0] for j in range(no)] for b in range(B)])
+    total = np.zeros(B); failed = np.zeros(B)
+    with mpc_gpu.BatchedMpc(20, no, 2.0, max_batch=B) as s:
+        s.reset_guess(x)
+        for k in range(steps):
+            g = s.solve(x, obst, goal)
+            x = s.plant_step(x, g["u0"]); s.shift(B)
+            total += g["cost"]; failed += g["status"] == 4
+    assert np.array_equal(rows[:, 1:6], x) and np.array_equal(rows[:, 6], total) and np.array_equal(rows[:, 7], failed)
+    assert np.linalg.norm(x[:, :2] - goal, axis=1).max() < np.linalg.norm(np.array([[-6.0 + b, -6.0] for b in range(B)]) - goal, axis=1).min()      # they did move towards their goals
