@@ -664,3 +664,33 @@ def test_any_obstacle_count(built, N, no, B):
                 ob[b, j] = orc.obstacle_step(cfg, ob[b, j], 0.1, noise=noise[k, b, j])
     assert r["obst_traj"].shape == (4, B, no, 4)
     assert np.abs(r["obst_traj"][-1][live] - ob[live]).max() < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,no,B", [(20, 4, 3001), (40, 7, 2500), (20, 8, 2200)])
+def test_instance_scheduling_with_fewer_obstacles_than_rows(built, N, no, B):
+    """the kernels with a run-time obstacle count under instance scheduling (more than one wavefront per SIMD): one instance per wavefront,
+    so the scheduled launches must give the natural order's results bit for bit, over three closed-loop steps, and match the oracle"""
+    import mpc_gpu
+    from oracle import oracle as orc
+    mpc_gpu.BatchedMpc.default_lanes_per_stage = 0
+    x0, goal, obst = random_batch(B, no, seed=99 + N + no)
+    res = {}
+    for on in (1, 0):
+        with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
+            assert s.kernel_name(B).endswith("true>")
+            s.set_instance_scheduling(bool(on)); s.reset_guess(x0); outs = []; xk = x0.copy()
+            for k in range(3):
+                g = s.solve(xk, obst, goal); X, U = s.get_traj(B)
+                assert (s.instance_order(B) is not None) == bool(on)
+                outs.append((g, X, U)); xk = s.plant_step(xk, g["u0"]); s.shift(B)
+            res[on] = outs
+    for (ga, Xa, Ua), (gb, Xb, Ub) in zip(res[1], res[0]):
+        assert np.array_equal(Xa, Xb) and np.array_equal(Ua, Ub) and np.array_equal(ga["iters"], gb["iters"]) and np.array_equal(ga["status"], gb["status"])
+    cfg = orc.config(N, no, 0.1 * N)
+    Xg, Ug = oracle_guess(orc, cfg, x0[:200]); P = oracle_P(orc, cfg, obst[:200])
+    o = orc.rti_solve_batch(cfg, x0[:200], P, goal[:200], Xg, Ug)
+    g, X, U = res[1][0]
+    assert (g["status"][:200] == o["status"]).all()
+    ok = o["status"] == 0
+    assert np.median(np.abs(X[:200] - o["X"]).reshape(200, -1).max(1)[ok]) < 1e-9
