@@ -97,6 +97,7 @@ static constexpr double kFracToBoundary = 0.999995;
 static constexpr double kMuDiverged = 1e8;
 // ... and a solve that reaches the iteration cap with mu above kMuCapFailed * mu0 was on its way there: status 4, not 2 (its step is not applied)
 static constexpr double kMuCapFailed = 1e4;
+static constexpr int kMuCapSettled = 10;       // ... and from this iteration on, above mu0 itself (oracle/mpc_oracle.c MU_CAP_SETTLED)
 
 // Gauss-Legendre 4-point rule on [0,1]: the reference's IRK integrator (robot_ocp_problem.py:129) with acados defaults
 // (GL, 4 stages, 1 step) collapses to closed-form psi,v,omega and this quadrature for x,y.
@@ -1950,7 +1951,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         if (running) {
             if (!(mu == mu) || !(fabs(mu) <= kMuDiverged * p.mu0)) { status = 4; running = false; it_done = it; }      // NaN, or diverged: an infeasible QP
             else if (lin <= p.tol && cmax <= p.tol) { status = 0; running = false; it_done = it; }
-            else if (it >= p.iter_max) { status = (mu > kMuCapFailed * p.mu0) ? 4 : 2; running = false; it_done = it; }      // at the cap with mu far above a healthy solve's: diverging, not slow
+            else if (it >= p.iter_max) { status = (mu > kMuCapFailed * p.mu0 || (it >= kMuCapSettled && mu > p.mu0)) ? 4 : 2; running = false; it_done = it; }      // at the cap with mu above a healthy solve's: diverging or stalled, not slow
         }
         if (__ballot(running) == 0ull) break;
         MPC_TICK(0);

@@ -342,7 +342,7 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
         if (running) {
             if (!(mu == mu) || !(fabs(mu) <= kMuDiverged * p.mu0)) { status = 4; running = false; it_done = it; }      // NaN, or diverged: an infeasible QP
             else if (lin <= p.tol && cmax <= p.tol) { status = 0; running = false; it_done = it; }
-            else if (it >= p.iter_max) { status = (mu > kMuCapFailed * p.mu0) ? 4 : 2; running = false; it_done = it; }      // at the cap with mu far above a healthy solve's: diverging, not slow
+            else if (it >= p.iter_max) { status = (mu > kMuCapFailed * p.mu0 || (it >= kMuCapSettled && mu > p.mu0)) ? 4 : 2; running = false; it_done = it; }      // at the cap with mu above a healthy solve's: diverging or stalled, not slow
         }
         if (!running) break;      // wave-uniform: one instance per wavefront
         MPC_TICK(0);

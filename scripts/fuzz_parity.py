@@ -1,6 +1,6 @@
 """Randomised configuration sweep: horizon, obstacle count, batch size and lane mapping drawn at random, GPU against the oracle on identical
 inputs over two closed-loop steps (statuses equal; iterates to 1e-6 or judged by the QP, helpers.qp_merit).  A net for rarely taken dispatch
-paths.  usage (GPU box): python scripts/fuzz_parity.py [seconds] [seed]   -> gpurun_out/fuzz_parity.json"""
+paths.  usage (GPU box): python scripts/fuzz_parity.py [seconds] [seed] [big]   -> gpurun_out/fuzz_parity.json   (big: batches of 1025 ... 20000 instances)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "dynamic-obstacle-avoidance-mpc_amd"), os.path.join(ROOT, "tests")]
@@ -12,12 +12,14 @@ from helpers import oracle_P, oracle_guess, qp_merit, random_batch
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
 t0 = time.time(); log = []; fails = []
 while time.time() - t0 < budget:
     N = int(rng.choice([2, 3, 5, 9, 10, 14, 15, 17, 19, 20, 21, 25, 30, 31, 32, 40, 47, 50, 62]))
     no = int(rng.integers(1, 11))
     B = int(rng.choice([1, 2, 3, 7, 33, 64, 65, 100, 257]))
     if N > 31: B = min(B, 65)
+    if BIG: B = int(rng.choice([1025, 3000, 4097, 8193, 12289, 20000])) if N <= 31 else 1500      # batches deep enough for instance scheduling and every packing rule
     lps = int(rng.choice([0, 1, 2, 3])); lanes = int(rng.choice([0, 0, 16, 21, 32, 64])); waves = int(rng.choice([0, 1, 2]))
     soft = int(rng.random() > 0.15); bxt = int(rng.random() > 0.7)
     seed = int(rng.integers(1 << 30))
@@ -72,7 +74,7 @@ while time.time() - t0 < budget:
     except Exception as e:                      # an API error is a finding too
         fails.append(dict(rec, why="exception", msg=str(e)[:300]))
     log.append(rec)
-    if len(log) % 100 == 0: print(f"{len(log)} configurations, {len(fails)} findings, {time.time() - t0:.0f} s", flush=True)      # (a silent GPU job is taken for hung)
+    if len(log) % (5 if BIG else 100) == 0: print(f"{len(log)} configurations, {len(fails)} findings, {time.time() - t0:.0f} s", flush=True)      # (a silent GPU job is taken for hung)
 kernels = sorted({r.get("kernel", "?") for r in log})
 out = dict(configurations=len(log), distinct_kernels=len(kernels), kernels=kernels, failures=fails, worst_dX=max((r.get("worst_dX", 0.0) for r in log), default=0.0), seconds=time.time() - t0)
 print(json.dumps({k: out[k] for k in ("configurations", "distinct_kernels", "failures", "worst_dX")}, indent=1)[:6000])
