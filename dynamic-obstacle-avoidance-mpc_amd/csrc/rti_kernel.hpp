@@ -97,7 +97,7 @@ static constexpr double kFracToBoundary = 0.999995;
 static constexpr double kMuDiverged = 1e8;
 // ... and a solve that reaches the iteration cap with mu above kMuCapFailed * mu0 was on its way there: status 4, not 2 (its step is not applied)
 static constexpr double kMuCapFailed = 1e4;
-static constexpr int kMuCapSettled = 10;       // ... and from this iteration on, above mu0 itself (oracle/mpc_oracle.c MU_CAP_SETTLED)
+static constexpr int kMuCapSettled = 20;       // ... and from this iteration on, above mu0 itself (oracle/mpc_oracle.c MU_CAP_SETTLED)
 
 // Gauss-Legendre 4-point rule on [0,1]: the reference's IRK integrator (robot_ocp_problem.py:129) with acados defaults
 // (GL, 4 stages, 1 step) collapses to closed-form psi,v,omega and this quadrature for x,y.
