@@ -53,6 +53,9 @@ struct mpc_handle {
     unsigned *d_sched_hist;           // ... per-block histograms of the counting sort [bins][blocks]
     int order_batch;                  // batch size d_order is a permutation of (0 = none yet)
     double *d_alpha_own;              // handle-owned copy of a host slack schedule (mpc_set_slack_schedule)
+    int alpha_batch;                  // ... and the number of instances it was given for (a solve of more instances than that is refused)
+    hipEvent_t sched_done;            // recorded behind the scheduling launches: a later launch on ANOTHER stream waits for it before it reads d_order
+    hipStream_t sched_stream;         // the stream those launches ran on
     double *h_pack, *d_pack;          // small host-pointer batches (the reference's own scalar loop): inputs and outputs travel packed, one copy each way
     size_t pack_in, pack_out;         // doubles per instance in / out of the packed transfer
     const double *d_alpha;            // slack schedule in effect: d_alpha_own, a caller's device array, or null (the reference's formula)
@@ -336,6 +339,9 @@ int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
 {
     p.iters_acc = h->d_iters_acc; p.status_acc = h->d_status_acc;
     p.alpha = h->d_alpha;
+    // an uploaded schedule covers the instances it was uploaded for: rows behind them were never written (the kernels index alpha[inst][i])
+    if (h->d_alpha && h->d_alpha == h->d_alpha_own && p.batch > h->alpha_batch)
+        return fail(MPC_ERR_ARG, "the slack schedule set by mpc_set_slack_schedule covers fewer instances than this solve");
     const SolvePlan q = plan_solve(h, p.batch, p.obst != nullptr);
     // Instance scheduling (aux_kernels.hpp::schedule_kernel): wavefront slots are dealt the instances in the order of their iteration counts
     // in this handle's previous launch of the same batch size, longest first -- instances that share a wavefront then stop together, and
@@ -344,6 +350,9 @@ int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
     const bool sched = h->scheduling && p.batch > h->simd_count;
     p.order = (sched && h->order_batch == p.batch) ? h->d_order : nullptr;
     if (sched && !p.iters) p.iters = h->d_iters_sched;
+    // the order, its histograms and d_iters_sched belong to the handle but the launches go to the caller's stream: a launch on a different stream
+    // than the one that built them must not start (nor rebuild them) while that one is still writing
+    if (sched && h->sched_done && h->order_batch && h->sched_stream != s) HIPCHK(hipStreamWaitEvent(s, h->sched_done, 0));
     // profiling: a start / stop event pair from the pool (created by mpc_profile_enable, never here) around every k-th launch; the pair
     // counts only when both records and the launch between them succeeded
     const bool timed = h->profiling && (h->launch_count++ % h->profiling) == 0 && h->ev_used < (int)h->ev_start.size();
@@ -357,6 +366,9 @@ int launch_solve(mpc_handle *h, mpc::KParams &p, hipStream_t s)
     if (sched) {
         h->order_batch = 0;
         rc = launch_schedule(h, p.batch, p.iters, s); if (rc) return rc;
+        if (!h->sched_done) HIPCHK(hipEventCreateWithFlags(&h->sched_done, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(h->sched_done, s));
+        h->sched_stream = s;
         h->order_batch = p.batch;
     }
     return MPC_OK;
@@ -430,6 +442,7 @@ int mpc_destroy(mpc_handle *h)
     if (h->h_pack) (void)hipHostFree(h->h_pack);
     for (auto e : h->ev_start) (void)hipEventDestroy(e);
     for (auto e : h->ev_stop) (void)hipEventDestroy(e);
+    if (h->sched_done) (void)hipEventDestroy(h->sched_done);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MPC_OK;
@@ -744,6 +757,7 @@ int mpc_set_slack_schedule(mpc_handle *h, int batch, const double *alpha)
     HIPCHK(hipMemcpyAsync(h->d_alpha_own, alpha, (size_t)batch * row * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->d_alpha = h->d_alpha_own;
+    h->alpha_batch = batch;
     return MPC_OK;
 }
 
@@ -861,6 +875,7 @@ int mpc_get_instance_order(mpc_handle *h, int batch, int32_t *order)
     if (!order) return fail(MPC_ERR_ARG, "null pointer");
     if (h->order_batch != batch) return 0;          // no order in effect for this batch size: natural order
     HIPCHK(hipSetDevice(h->device));
+    if (h->sched_done) HIPCHK(hipEventSynchronize(h->sched_done));      // the order was built on the stream of the launch that preceded it, not necessarily ours
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(order, h->d_order, (size_t)batch * sizeof(int32_t), hipMemcpyDeviceToHost));
     return 1;

@@ -1649,7 +1649,12 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     const int inst_raw = blockIdx.x * IPW + slot;
     const bool valid = inst_raw < p.batch;    // tail wavefront: surplus slots replay the last instance and store nothing
     const int sidx = valid ? inst_raw : p.batch - 1;
-    const int inst = p.order ? p.order[sidx] : sidx;      // instance scheduling: which instance this slot works on
+    int inst_ = p.order ? p.order[sidx] : sidx;           // instance scheduling: which instance this slot works on
+    // one instance per wavefront: the index is wave-uniform -> a scalar register.  Not a speed matter: a per-lane copy of it has to survive the
+    // whole interior point in the register file, and a live-range split copy of exactly this value is what the toolchain once placed in front of
+    // the exec restore of an if / else join (scripts/isa_audit.py rule P1) -- scalar spills (v_writelane) ignore EXEC
+    if constexpr (G == 64) inst_ = __builtin_amdgcn_readfirstlane(inst_);
+    const int inst = inst_;
     const int N = p.N;
     const int i = lane - slot * G;            // this lane's stage
     const bool act = (i <= N);

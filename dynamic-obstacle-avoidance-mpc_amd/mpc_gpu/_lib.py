@@ -94,8 +94,23 @@ def sources():
         [os.path.join(REPO_ROOT, "include", "mpc_gpu.h")]
 
 
-def build(force=False, verbose=False):
-    """Compile csrc/*.hip for gfx950 into libmpcgpu.so (in-tree).  hipcc cross-compiles without a GPU."""
+ISA_PATH = os.path.join(REPO_ROOT, "build", "mpc_api-gfx950.s")
+
+
+def _audit_isa(path):
+    """scripts/isa_audit.py over the device listing of the library: data hazards hipcc cannot see across an inline-asm boundary, and per-lane
+    instructions the register allocator placed in front of the exec restore of an if / else join (rule P1: the cause of the build variant
+    that stored status / iterations / cost to wrong addresses).  Returns the findings as text ('' = clean)."""
+    script = os.path.join(REPO_ROOT, "scripts", "isa_audit.py")
+    r = subprocess.run([os.environ.get("PYTHON", "python3"), script, path], capture_output=True, text=True)
+    return "" if r.returncode == 0 else (r.stdout + r.stderr)
+
+
+def build(force=False, verbose=False, audit=True):
+    """Compile csrc/*.hip for gfx950 into libmpcgpu.so (in-tree).  hipcc cross-compiles without a GPU.
+    The same command with -S runs beside it and its listing (build/mpc_api-gfx950.s) is audited: a build that fails the audit is deleted and
+    the call raises -- a library with a lost-lane copy in it stores to wrong addresses without any test having to notice (MPC_SKIP_ISA_AUDIT=1
+    skips the listing, for diagnostic builds)."""
     if os.environ.get("MPC_GPU_LIB"):
         return LIB_PATH                  # a diagnostic build supplied by the caller is used as it is
     srcs = sources()
@@ -104,11 +119,32 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", LIB_PATH, os.path.join(CSRC, "mpc_api.hip")]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value"] + os.environ.get("MPC_EXTRA_HIPCC_FLAGS", "").split()
+    src = os.path.join(CSRC, "mpc_api.hip")
+    cmd = [hipcc] + flags + ["-fPIC", "-shared", "-o", LIB_PATH + ".new", src]
+    audit = audit and not os.environ.get("MPC_SKIP_ISA_AUDIT")
+    lister = None
+    if audit:
+        os.makedirs(os.path.dirname(ISA_PATH), exist_ok=True)
+        lister = subprocess.Popen([hipcc] + flags + ["--cuda-device-only", "-S", "-o", ISA_PATH, src], stderr=subprocess.PIPE, text=True)
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+    except BaseException:
+        if lister is not None:
+            lister.kill()
+        raise
+    if lister is not None:
+        err = lister.communicate()[1]
+        if lister.returncode != 0:
+            os.remove(LIB_PATH + ".new")
+            raise MpcError(f"device listing failed:\n{err}")
+        findings = _audit_isa(ISA_PATH)
+        if findings:
+            os.remove(LIB_PATH + ".new")
+            raise MpcError("ISA audit of the new build failed (scripts/isa_audit.py; the previous library, if any, is left in place):\n" + findings[-4000:])
+    os.replace(LIB_PATH + ".new", LIB_PATH)
     return LIB_PATH
 
 

@@ -26,10 +26,11 @@ class EpisodeState:
     x: np.ndarray                                   # plant state
     goal: np.ndarray                                # current sub-goal
     obstacles: list
-    steps: int = 0                                  # completed control steps (the reference's `i`)
-    reached: bool = False
+    steps: int = 0                                  # control steps completed by the current / last rollout() (the reference's local `i`, :183)
+    total_steps: int = 0                            # ... and over all rollouts of this episode
+    reached: bool = False                           # per rollout, as the reference's locals `reached_subgoal`, `out_of_bounds`, `u_max` (:177-182)
     left_arena: bool = False
-    min_margin: float = np.inf
+    min_margin: float = np.inf                      # kept across rollouts, as the reference's self.min_margin_traj
     u_peak: float = 0.0
     xs: list = field(default_factory=list)          # visited plant states, starting with the initial one
     us: list = field(default_factory=list)
@@ -105,7 +106,10 @@ class ShimLoop:
         return status
 
     def rollout(self, st, max_steps):
-        """:180-260: cold start, then control steps until the goal region is reached or max_steps are done."""
+        """:177-260: cold start, then control steps until the goal region is reached or max_steps are done.  Step count, goal / arena
+        flags and peak control are those of THIS call (locals of the reference's step(), :177-183): a caller that alternates
+        set_subgoal() and step(n) -- the sub-goal hook of SURVEY 8(f)-3 -- gets n fresh control steps every time."""
+        st.steps, st.reached, st.left_arena, st.u_peak = 0, False, False, 0.0
         self.cold_start(st)
         while st.steps < max_steps:
             self.control_step(st)
@@ -113,6 +117,7 @@ class ShimLoop:
                 break                                # the reference leaves its loop before `i += 1`
             self.shift_warm_start()
             st.steps += 1
+            st.total_steps += 1
         return st
 
 

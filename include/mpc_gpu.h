@@ -201,11 +201,6 @@ int mpc_set_row_parallel(mpc_handle *h, int on);
  * Same arithmetic specification either way.  No reference counterpart (tuning / test hook). */
 int mpc_set_lanes_per_stage(mpc_handle *h, int lanes);
 int mpc_get_lanes_per_stage(mpc_handle *h, int batch);
-/* Wavefronts per SIMD of the stage-split mapping.  0 (default): automatic -- one (all 512 registers, dense LDS blocks) for a batch of at
- * most two instances per SIMD, whose wavefronts are alone on their SIMDs anyway; two (256 registers per lane, compact LDS blocks: 14.7 KB
- * per wavefront at N = 20, eight wavefronts per CU) for deeper batches, where a second resident wavefront fills the LDS and
- * dependent-issue stalls of the first.  1 / 2: forced.  The one-lane-per-stage mapping always runs one wavefront per SIMD (449 registers).
- * Same arithmetic specification either way.  No reference counterpart (tuning / test hook). */
 /* Instance scheduling (default on).  Where several instances share a wavefront (one lane per stage: 2, 3 or 4 of them) the wavefront runs
  * until its slowest instance has converged; iteration counts are heavy-tailed (C3: mean 6.6, mean of the per-wavefront maximum 9.4 with
  * three per wavefront) but strongly correlated between consecutive control steps of an instance.  The library therefore deals the instances
@@ -221,6 +216,12 @@ int mpc_get_instance_order(mpc_handle *h, int batch, int32_t *order);
  * sweeps: 0 systolic, 1 matrix cores, 2 row-parallel on dense LDS blocks, 3 row-parallel on compact LDS blocks).  lookahead: whether the
  * obstacle look-ahead runs inside the kernel (mpc_closed_loop_step_dev) -- it enters the LDS budget that selects the block layout. */
 int mpc_get_kernel_name(mpc_handle *h, int batch, int lookahead, char *buf, int len);
+/* Wavefronts per SIMD of the stage-split mapping.  0 (default): automatic -- two (256 registers per lane, compact LDS blocks: 14.7 KB per
+ * wavefront at N = 20, eight wavefronts per CU) only for 3-obstacle problems in batches of more than four instances per SIMD of the device,
+ * where a second resident wavefront fills the LDS and dependent-issue stalls of the first; one (all 512 registers, dense LDS blocks)
+ * otherwise -- with 5 or 10 obstacle row pairs the 256-register build spills and loses at every batch, and a problem that uses fewer rows than
+ * its kernel's capacity always runs one.  1 / 2: forced (ignored for such partial-row problems).  The one-lane-per-stage mapping always runs one
+ * wavefront per SIMD.  Same arithmetic specification either way.  No reference counterpart (tuning / test hook). */
 int mpc_set_waves_per_simd(mpc_handle *h, int waves);
 int mpc_get_waves_per_simd(mpc_handle *h, int batch);
 

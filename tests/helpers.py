@@ -98,3 +98,51 @@ class OracleLoop:
     def row(self):
         return [float(bool(self.flags & 4)), float(bool(self.flags & 1)), self.min_margin, float(np.linalg.norm(self.x[:2] - self.goal)),
                 float(self.steps), float(bool(self.flags & 2))]
+
+
+class OracleAsAcados:
+    """The oracle behind AcadosOcpSolver's method names (set / get / cost_set / reset / solve), so that host logic written against the
+    shims (mpc_gpu.closed_loop.ShimLoop) can be exercised without a GPU.  Test infrastructure."""
+
+    def __init__(self, orc, cfg, goal):
+        self.orc, self.cfg = orc, cfg
+        self.X = np.zeros((cfg.N + 1, 5)); self.U = np.zeros((cfg.N, 2)); self.P = np.zeros((cfg.N + 1, cfg.n_obst, 2))
+        self.alpha = np.zeros(cfg.N + 1); self.goal = np.array(goal, float); self.x0 = np.zeros(5)
+
+    def set(self, stage, fieldname, v):
+        if fieldname == "x": self.X[stage] = v
+        elif fieldname == "u": self.U[stage] = v
+        elif fieldname == "p": self.P[stage] = np.asarray(v).reshape(-1, 2)
+        else: self.x0 = np.array(v, float)
+
+    def cost_set(self, stage, fieldname, v):
+        if fieldname == "yref": self.goal = np.array(v[:2], float)        # the shim applies the position to stage and terminal reference
+        else: self.alpha[stage] = v[0]
+
+    def get(self, stage, fieldname):
+        return (self.X if fieldname == "x" else self.U)[stage].copy()
+
+    def reset(self):
+        self.X[:] = 0; self.U[:] = 0
+
+    def solve(self):
+        r = self.orc.rti_solve(self.cfg, self.x0, self.P, self.goal, self.X, self.U, alpha=self.alpha)
+        self.X, self.U = r["X"], r["U"]
+        return r["status"]
+
+
+class OraclePlant:
+    """AcadosSimSolver's surface over the oracle's integrator step."""
+
+    def __init__(self, orc, dt):
+        self.orc, self.dt, self.x, self.u = orc, dt, np.zeros(5), np.zeros(2)
+
+    def set(self, fieldname, v):
+        if fieldname == "x": self.x = np.array(v, float)
+        else: self.u = np.array(v, float)
+
+    def solve(self):
+        self.x = self.orc.dynamics(self.x, self.u, self.dt)[0]
+
+    def get(self, fieldname):
+        return self.x.copy()

@@ -184,6 +184,16 @@ def test_explicit_slack_schedule(env):
         assert np.array_equal(Xa, Xd)
         with pytest.raises(mpc_gpu.MpcError):
             s.set_slack_schedule(-other)
+        # a schedule uploaded for k instances covers k instances: the rows behind them were never written, so a larger solve is refused
+        # (it used to read them as slack weights) -- and works again once the schedule is dropped or uploaded for the whole batch
+        s.set_slack_schedule(other[:16])
+        s.set_warmstart(Xg[:16], Ug[:16]); e = s.solve(x0[:16], P[:16], goal[:16])
+        assert np.array_equal(e["status"], c["status"][:16]) and np.array_equal(e["iters"], c["iters"][:16])
+        with pytest.raises(mpc_gpu.MpcError, match="covers fewer instances"):
+            s.solve(x0, P, goal)
+        s.set_slack_schedule(other)
+        s.set_warmstart(Xg, Ug); f = s.solve(x0, P, goal)
+        assert np.array_equal(f["status"], c["status"]) and np.array_equal(f["u0"], c["u0"])
     moved = 0
     for i in range(B):
         r = orc.rti_solve(cfg, x0[i], P[i], goal[i], Xg[i], Ug[i], alpha=other[i])

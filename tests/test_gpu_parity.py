@@ -583,6 +583,41 @@ def test_instance_scheduling(env, G):
 
 
 @pytest.mark.gpu
+def test_instance_scheduling_across_streams(built):
+    """The instance order belongs to the handle, the launches to the caller's stream: consecutive *_dev solves of one batch size on two DIFFERENT
+    streams (no host synchronisation between them) must see a complete order -- the second launch waits for the event recorded behind the
+    first one's sort.  Results equal those of the same sequence on one stream, bit for bit (two instances per wavefront)."""
+    import torch
+    import mpc_gpu
+    N, no, B = 20, 3, 6000
+    x0, goal, obst = random_batch(B, no, seed=99)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    res = []
+    for two_streams in (False, True):
+        sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        with mpc_gpu.BatchedMpc(N, no, 2.0, max_batch=B) as s:
+            s.set_lanes_per_stage(1); s.set_lanes_per_instance(32)
+            x0d, gd, od = t(x0), t(goal), t(obst)
+            P = torch.zeros(B, N + 1, no, 2, dtype=torch.float64, device=dev)
+            X = torch.zeros(B, N + 1, 5, dtype=torch.float64, device=dev); U = torch.zeros(B, N, 2, dtype=torch.float64, device=dev)
+            it = torch.zeros(B, dtype=torch.int32, device=dev); st = torch.zeros(B, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            s.predict_dev(B, od, P, stream=sa.cuda_stream); s.reset_guess_dev(B, x0d, X, U, stream=sa.cuda_stream)
+            for k in range(6):
+                cur = (sa, sb)[k % 2] if two_streams else sa
+                if two_streams and k:
+                    cur.wait_stream((sa, sb)[(k - 1) % 2])      # the DATA dependency (X, U) is the caller's to order; the handle's own order array is not
+                s.solve_dev(B, x0d, P, gd, X, U, None, None, st, it, stream=cur.cuda_stream)
+            torch.cuda.synchronize()
+            order = s.instance_order(B)
+            assert order is not None and np.array_equal(np.sort(order), np.arange(B))
+            res.append((X.cpu().numpy(), U.cpu().numpy(), it.cpu().numpy(), st.cpu().numpy(), order))
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("lanes", [0, 21, 32, 64])
 def test_non_finite_inputs_are_contained(built, lanes):
     """NaN / Inf in one instance's x0, goal or obstacle state (a diverged plant, a bad sensor frame): that instance fails at once (status 4,

@@ -95,3 +95,39 @@ def test_bench_multi_rank_path_world_size_2_gloo(built, workload, total):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["gather_check"] is True and line["config"]["global_batch"] == total
     assert line["config"]["rank0_slice"] == [0, total // 2] and line["scaling"] == ("weak" if workload == "c2" else "strong")
+
+
+def test_step_counts_per_call_for_the_subgoal_hook(built):
+    """RobotOcpProblem.step(n) / set_subgoal() / step(n) (the RL hook, robot_ocp_problem.py:168-284): step count, goal / arena flags and peak
+    control are locals of every step() call in the reference (:177-183), min_margin_traj persists.  ShimLoop.rollout on oracle-backed
+    acados-shaped objects, twice on one EpisodeState with a sub-goal change in between, against OracleLoop driven the same way."""
+    from oracle import oracle as orc
+    from helpers import OracleAsAcados, OracleLoop, OraclePlant
+    from mpc_gpu.closed_loop import EpisodeState, ShimLoop
+    from mpc_gpu.world import Obstacle
+    N, no, k = 10, 3, 7
+    cfg = orc.config(N, no, 1.0, qp_tol=1e-8)
+    x0 = np.array([-5.0, -4.0, 0.3, 0.0, 0.0]); g1, g2 = np.array([4.0, 3.0]), np.array([-2.0, 5.0])
+    obst = np.array([[0.0, -1.0, 0.4, 0.6], [2.0, 2.5, -0.5, 0.3], [-3.0, 1.0, 0.2, -0.7]])
+    ocp = OracleAsAcados(orc, cfg, g1); sim = OraclePlant(orc, 0.1)
+    st = EpisodeState(x=x0.copy(), goal=g1.copy(), obstacles=[Obstacle(*o, dt=0.1) for o in obst], xs=[x0.copy()])
+    loop = ShimLoop(ocp, sim, N, soft=True, reset_on_failure=True)
+    ref = OracleLoop(orc, cfg, x0, g1, obst, reset_on_fail=True, alias=True)
+    loop.rollout(st, k)
+    for _ in range(k):
+        ref.step()
+    assert st.steps == k == ref.steps and not st.reached
+    assert np.abs(st.x - ref.x).max() < 1e-9 and abs(st.min_margin - ref.min_margin) < 1e-9
+    margin_after_first = st.min_margin
+    # sub-goal change, then a second step(k): k MORE control steps (the base class ran zero), counted from zero, cold-started like the first
+    st.goal = g2.copy(); ocp.cost_set(N, "yref", np.array([g2[0], g2[1], 0, 0, 0]))
+    ref.goal = g2.copy(); ref.x[3:] = 0.0; ref.X, ref.U = orc.initial_guess(cfg, ref.x)
+    loop.rollout(st, k)
+    for _ in range(k):
+        ref.step()
+    assert st.steps == k and st.total_steps == 2 * k == ref.steps
+    assert len(st.us) == 2 * k
+    assert np.abs(st.x - ref.x).max() < 1e-9
+    assert st.min_margin <= margin_after_first and abs(st.min_margin - ref.min_margin) < 1e-9     # min_margin_traj persists (:228-229)
+    row = st.table_row()
+    assert row[4] == k and row[1] is False
