@@ -1843,8 +1843,24 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     const int zidx[NB] = {0, 1, 2, 3, 5, 6};
     double ll[NB], tl[NB], lh[NB], th[NB], rtl[NB], rth[NB];
     const bool vbu = has_u, vbx = xb;            // input-box rows (k < 2) / state-box rows (k >= 2) present at this stage
-    const double lo[NB] = {p.bu_lo[0], p.bu_lo[1], p.bx_lo[0], p.bx_lo[1], p.bx_lo[2], p.bx_lo[3]};
-    const double hi[NB] = {p.bu_hi[0], p.bu_hi[1], p.bx_hi[0], p.bx_hi[1], p.bx_hi[2], p.bx_hi[3]};
+    double lo[NB] = {p.bu_lo[0], p.bu_lo[1], p.bx_lo[0], p.bx_lo[1], p.bx_lo[2], p.bx_lo[3]};
+    double hi[NB] = {p.bu_hi[0], p.bu_hi[1], p.bx_hi[0], p.bx_hi[1], p.bx_hi[2], p.bx_hi[3]};
+    // Inside the interior point the wave-uniform constants of the problem (12 bounds, 22 cost weights: 68 scalar registers) are RE-READ from the
+    // kernel-argument segment at the head of every phase that uses them -- three scalar loads -- instead of staying live across the sweeps: held in
+    // scalar registers they do not fit next to the lane masks and LDS addresses (102 registers), and every spilled one comes back through a
+    // v_readlane, a VECTOR instruction of the wavefront's one issue stream (150 per iteration before).  The pointer passes through an opaque copy
+    // per phase, so that the loads are neither hoisted out of the loop nor merged across phases.
+    typedef const __attribute__((address_space(4))) KParams KArg;
+    auto reload_bounds = [&]() {
+#ifdef MPC_NO_RELOAD      // diagnostic build: the constants stay in (spilled) scalar registers, as in round 2
+        return;
+#endif
+        KArg *pk = (KArg *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(pk));
+        lo[0] = pk->bu_lo[0]; lo[1] = pk->bu_lo[1]; hi[0] = pk->bu_hi[0]; hi[1] = pk->bu_hi[1];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { lo[2 + k] = pk->bx_lo[k]; hi[2 + k] = pk->bx_hi[k]; }
+    };
     {
         const double val[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
 #pragma unroll
@@ -1914,6 +1930,15 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 
     double z[7] = {0, 0, 0, 0, 0, 0, 0};
     double rhoPi = 1.0;
+    // BRANCH-FREE ROW PHASES.  Which rows exist differs per lane (no input rows in the terminal lane, no state box at stage 0, no obstacle rows at
+    // stage 0 or where the penalty is zero), but a wave instruction costs the same for 1 or 64 active lanes and every `if (row exists)` around a
+    // row's arithmetic is an EXEC save / restore plus a branch that also ends the scheduling region (a lone wavefront issues a dependent FP64
+    // instruction every 8.4 cycles, an independent one every 5: the rows of a stage are independent of each other only inside ONE region).
+    // So every lane computes all rows of its stage; rows that do not exist carry finite dummy state that nothing reads: their contributions to
+    // whatever is shared (sums, maxima, Hessian / gradient entries) enter through the 0 / 1 factors below, as the multiplier of the fused
+    // multiply-add that would have been an add.
+    const double m_u = vbu ? 1.0 : 0.0, m_x = vbx ? 1.0 : 0.0, m_s = vs ? 1.0 : 0.0;
+#define MPC_MK(k) ((k) < 2 ? m_u : m_x)
     int status = 2, it = 0, it_done = 0;
     bool running = !ep_done;  // per instance: instances sharing a wavefront stop at their own iteration and then idle
     if (!(lin0 <= 1e300)) { status = 4; running = false; }
@@ -1926,6 +1951,566 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     // sweeps need ~100 doubles of their own and VALU operands can address only 256 VGPRs.  OPAQUE() hides a value's
     // history from the optimiser (no instruction is emitted), so that recomputations are neither hoisted nor merged back.
 #define OPAQUE(x) asm volatile("" : "+v"(x))
+    // Two forms of the iteration's row phases (same arithmetic, same interior point):
+    //   BRANCHFREE (3 and 5 obstacle row pairs): every row of the stage computed by every lane, existence as 0 / 1 factors (see m_u, m_x, m_s);
+    //   the branched form (10 row pairs): the rows under `if (row exists)`.  With ten obstacles the register file is full to the last
+    //   register (256 + 240 and no scratch); the branch-free form needs ~30 registers more at its peak and pays for them in scratch memory
+    //   (60..104 B per lane in every arrangement tried: measured 17.7 against 17.2 ms per C5 control step), so that kernel keeps the branches.
+    constexpr bool BRANCHFREE = NOBST < 10;
+    if constexpr (BRANCHFREE) {
+    for (it = 0;; it++) {
+        // ---- complementarity measures ----
+        double msum = 0.0, cmax = 0.0;
+        {   // per row group (input box, state box, obstacle rows): sum and maximum over the group's rows, entered at once if the group exists
+            double sg = 0.0, cg = 0.0;
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                const double a = ll[k] * tl[k], b = lh[k] * th[k];
+                sg += a + b;
+                cg = fmax(cg, (tl[k] <= 2 * kTLMin || ll[k] <= 2 * kTLMin) ? 0.0 : a);
+                cg = fmax(cg, (th[k] <= 2 * kTLMin || lh[k] <= 2 * kTLMin) ? 0.0 : b);
+                if (k == 1 || k == NB - 1) { msum = fma(MPC_MK(k), sg, msum); cmax = fmax(cmax, MPC_MK(k) * cg); sg = 0.0; cg = 0.0; }
+            }
+#pragma unroll
+            for (int j = 0; j < NOBST; j++) {
+                if (ROW_OFF(j)) continue;
+                const double a = l1[j] * t1[j];
+                sg += a;
+                cg = fmax(cg, (t1[j] <= 2 * kTLMin || l1[j] <= 2 * kTLMin) ? 0.0 : a);
+                if (soft) {
+                    const double b = l2[j] * t2[j];
+                    sg += b;
+                    cg = fmax(cg, (t2[j] <= 2 * kTLMin || l2[j] <= 2 * kTLMin) ? 0.0 : b);
+                }
+            }
+            msum = fma(m_s, sg, msum); cmax = fmax(cmax, m_s * cg);
+        }
+        seg_reduce2<G, true>(msum, cmax, lane);
+        const double mu = msum * inv_items;
+        const double lin = rhoPi * lin0;
+        if (running) {
+            if (!(mu == mu) || !(fabs(mu) <= kMuDiverged * p.mu0)) { status = 4; running = false; it_done = it; }      // NaN, or diverged: an infeasible QP
+            else if (lin <= p.tol && cmax <= p.tol) { status = 0; running = false; it_done = it; }
+            else if (it >= p.iter_max) { status = (mu > kMuCapFailed * p.mu0 || (it >= kMuCapSettled && mu > p.mu0)) ? 4 : 2; running = false; it_done = it; }      // at the cap with mu above a healthy solve's: diverging or stalled, not slow
+        }
+        if (__ballot(running) == 0ull) break;
+        MPC_TICK(0);
+
+        // residual r_d = rho(z) - t of the box rows of variable k, from the iterate (never stored)
+        auto box_rd = [&](int k, const double vals[NB], const double zz[7], double &rdl, double &rdh) {
+            const double zk = zz[zidx[k]];
+            rdl = ((vals[k] - lo[k]) + zk) - tl[k];
+            rdh = ((hi[k] - vals[k]) - zk) - th[k];
+        };
+        // weights / residuals of obstacle row pair j at the iterate zz
+        struct SoftT { double w1, w2, rD, be1, be2, rs, rd1, rd2; };
+        auto soft_terms = [&](int j, const ObstView &v, const double zz[7]) {
+            SoftT o;
+            const double y = v.ax * zz[2] + v.ay * zz[3];
+            o.w1 = l1[j] * v.rt1;
+            if (soft) {
+                o.rd1 = (v.hh + y + sv[j]) - t1[j]; o.rd2 = sv[j] - t2[j];
+                o.be1 = (l1[j] * t1[j] + l1[j] * o.rd1) * v.rt1;
+                o.w2 = l2[j] * v.rt2;
+                o.be2 = (l2[j] * t2[j] + l2[j] * o.rd2) * v.rt2;
+                o.rs = zpen * sv[j] + zpen - l1[j] - l2[j];
+                o.rD = rcp_nr(zpen + o.w1 + o.w2);
+            } else {
+                o.rd1 = (v.hh + y) - t1[j]; o.rd2 = 0.0;
+                o.be1 = (l1[j] * t1[j] + l1[j] * o.rd1) * v.rt1;
+                o.w2 = 0.0; o.be2 = 0.0; o.rs = 0.0; o.rD = 0.0;
+            }
+            return o;
+        };
+        // an opaque 0.0 per phase (one v_mov; see obst_view)
+        auto phase_zero = [&]() { double zz_ = 0.0; if constexpr (LEAN) asm volatile("" : "+v"(zz_)); return zz_; };
+        // LEAN: the reciprocals of the box rows are phase-local as well (recomputed at the head of every phase that uses them)
+        auto refresh_box_rcp = [&]() {
+            if constexpr (LEAN) {
+                const double pz = phase_zero();
+#pragma unroll
+                for (int k = 0; k < NB; k++) { rtl[k] = rcp_nr(tl[k] + pz); rth[k] = rcp_nr(th[k] + pz); }
+            }
+        };
+
+        // ---- predictor (sigma = 0): local gradient, barrier terms, reduced Hessian ----
+        StageFac F;
+        double za[7] = {0, 0, 0, 0, 0, 0, 0};
+        double bbr[5], x_init[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) { bbr[c] = rhoPi * bb[c]; x_init[c] = SLDS ? 0.0 : rhoPi * d0[c]; }
+        {
+            refresh_box_rcp();
+            reload_bounds();
+            double vals[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
+#pragma unroll
+            for (int k = 0; k < NB; k++) OPAQUE(vals[k]);
+            // Gauss-Newton gradient q and diagonal Hessian, z order (ua, ual, x, y, psi, v, om); robot_ocp_problem.py:59-83
+            double Hd[7], gloc[7], cb[7];
+            {   // stage / terminal weights chosen per lane as a select of VALUES: the wave-uniform kernel arguments pass through an opaque
+                // scalar copy first -- written as if / else on the argument arrays, the optimiser selects the ADDRESS and issues five
+                // per-lane global loads from the kernel-argument segment inside the iteration loop
+                double hs[7], ht[5], wg[6], we[4];
+#ifdef MPC_NO_RELOAD
+#pragma unroll
+                for (int c = 0; c < 7; c++) { hs[c] = p.Hd_stage[c]; asm volatile("" : "+s"(hs[c])); }
+#pragma unroll
+                for (int c = 0; c < 5; c++) { ht[c] = p.Hd_term[c]; asm volatile("" : "+s"(ht[c])); }
+#pragma unroll
+                for (int c = 0; c < 6; c++) { wg[c] = p.Wg[c]; asm volatile("" : "+s"(wg[c])); }
+#pragma unroll
+                for (int c = 0; c < 4; c++) { we[c] = p.Weg[c]; asm volatile("" : "+s"(we[c])); }
+#else
+                KArg *pk = (KArg *)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(pk));
+#pragma unroll
+                for (int c = 0; c < 7; c++) hs[c] = pk->Hd_stage[c];
+#pragma unroll
+                for (int c = 0; c < 5; c++) ht[c] = pk->Hd_term[c];
+#pragma unroll
+                for (int c = 0; c < 6; c++) wg[c] = pk->Wg[c];
+#pragma unroll
+                for (int c = 0; c < 4; c++) we[c] = pk->Weg[c];
+#endif
+                Hd[0] = has_u ? hs[0] : 0.0; Hd[1] = has_u ? hs[1] : 0.0;
+#pragma unroll
+                for (int c = 0; c < 5; c++) Hd[2 + c] = has_u ? hs[2 + c] : ht[c];
+                gloc[0] = (has_u ? wg[4] : 0.0) * vals[0]; gloc[1] = (has_u ? wg[5] : 0.0) * vals[1];
+                gloc[2] = (has_u ? wg[0] : we[0]) * (vals[2] - gl[0]); gloc[3] = (has_u ? wg[1] : we[1]) * (vals[3] - gl[1]); gloc[4] = 0.0;
+                gloc[5] = (has_u ? wg[2] : we[2]) * vals[4]; gloc[6] = (has_u ? wg[3] : we[3]) * vals[5];
+            }
+            double Hq[8] = {has_u ? Hd[0] : 1.0, has_u ? Hd[1] : 1.0, Hd[2], Hd[3], Hd[4], Hd[5], Hd[6], 0.0};   // diagonal in z order, then Qxy
+#pragma unroll
+            for (int c = 0; c < 7; c++) { gloc[c] += Hd[c] * z[c]; cb[c] = 0.0; }                              // (H z + q - C'lam), sum_c c beta_c
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                double rdl, rdh;
+                box_rd(k, vals, z, rdl, rdh);
+                const double wl = ll[k] * rtl[k], wh = lh[k] * rth[k];
+                const double bl = (ll[k] * tl[k] + ll[k] * rdl) * rtl[k], bh = (lh[k] * th[k] + lh[k] * rdh) * rth[k];
+                Hq[zidx[k]] = fma(MPC_MK(k), wl + wh, Hq[zidx[k]]);
+                gloc[zidx[k]] = fma(MPC_MK(k), lh[k] - ll[k], gloc[zidx[k]]);
+                cb[zidx[k]] = fma(MPC_MK(k), bl - bh, cb[zidx[k]]);
+            }
+            {
+                const double pz = phase_zero();
+                double hxx = 0.0, hyy = 0.0, hxy = 0.0, gx = 0.0, gy = 0.0, cx = 0.0, cy = 0.0;      // the obstacle rows' sums, entered below if the rows exist
+#pragma unroll
+                for (int j = 0; j < NOBST; j++) {
+                    if (ROW_OFF(j)) continue;
+                    const ObstView v = obst_view(j, pz);
+                    const SoftT o = soft_terms(j, v, z);
+                    double weff, geff;
+                    if (soft) {
+                        weff = o.w1 * (zpen + o.w2) * o.rD;
+                        geff = (o.be1 * (zpen + o.w2) - o.w1 * (o.rs + o.be2)) * o.rD;
+                    } else { weff = o.w1; geff = o.be1; }
+                    hxx += weff * v.ax * v.ax; hyy += weff * v.ay * v.ay; hxy += weff * v.ax * v.ay;
+                    gx += l1[j] * v.ax; gy += l1[j] * v.ay;
+                    cx += geff * v.ax; cy += geff * v.ay;
+                }
+                Hq[2] = fma(m_s, hxx, Hq[2]); Hq[3] = fma(m_s, hyy, Hq[3]); Hq[7] = fma(m_s, hxy, Hq[7]);
+                gloc[2] = fma(-m_s, gx, gloc[2]); gloc[3] = fma(-m_s, gy, gloc[3]);
+                cb[2] = fma(m_s, cx, cb[2]); cb[3] = fma(m_s, cy, cb[3]);
+            }
+            MPC_TICK(1);
+            double gxs[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) gxs[c] = gloc[2 + c] + cb[2 + c];
+            if (USE_MFMA) {
+                if (act) {      // H~aug_t in accumulator layout: z~ order (x0..x4, 1, ua, ual)
+                    double *hc = ML.HC + 64 * i;
+                    const double lu0 = gloc[0] + cb[0], lu1 = gloc[1] + cb[1];
+                    hc[MfmaLds::at(0, 0)] = Hq[2]; hc[MfmaLds::at(1, 1)] = Hq[3]; hc[MfmaLds::at(2, 2)] = Hq[4];
+                    hc[MfmaLds::at(3, 3)] = Hq[5]; hc[MfmaLds::at(4, 4)] = Hq[6];
+                    hc[MfmaLds::at(0, 1)] = Hq[7]; hc[MfmaLds::at(1, 0)] = Hq[7];
+                    hc[MfmaLds::at(6, 6)] = Hq[0]; hc[MfmaLds::at(7, 7)] = Hq[1];
+#pragma unroll
+                    for (int c = 0; c < 5; c++) { hc[MfmaLds::at(c, 5)] = gxs[c]; hc[MfmaLds::at(5, c)] = gxs[c]; }
+                    hc[MfmaLds::at(6, 5)] = lu0; hc[MfmaLds::at(5, 6)] = lu0;
+                    hc[MfmaLds::at(7, 5)] = lu1; hc[MfmaLds::at(5, 7)] = lu1;
+                }
+                wave_sync();
+                mfma_factor(lane, N, ML, rhoPi);
+                wave_sync();
+                F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;
+#pragma unroll
+                for (int c = 0; c < 5; c++) { F.K0[c] = 0.0; F.K1[c] = 0.0; }
+                if (has_u) {
+                    const double *ko = ML.KO + 16 * i;
+#pragma unroll
+                    for (int c = 0; c < 5; c++) { F.K0[c] = ko[c]; F.K1[c] = ko[6 + c]; }
+                    F.k0 = ko[5]; F.k1 = ko[11]; F.i00 = ko[12]; F.l = ko[13]; F.i11 = ko[14];
+                }
+            } else if (ROWPAR) {
+                if (act) {      // H~aug_t, dense 8 x 8, z~ order (x0..x4, 1, ua, ual); affine column of W~_t
+                    const double lu0 = gloc[0] + cb[0], lu1 = gloc[1] + cb[1];
+                    const double Hrow[8][8] = {{Hq[2], Hq[7], 0.0, 0.0, 0.0, gxs[0], 0.0, 0.0}, {Hq[7], Hq[3], 0.0, 0.0, 0.0, gxs[1], 0.0, 0.0},
+                                               {0.0, 0.0, Hq[4], 0.0, 0.0, gxs[2], 0.0, 0.0}, {0.0, 0.0, 0.0, Hq[5], 0.0, gxs[3], 0.0, 0.0},
+                                               {0.0, 0.0, 0.0, 0.0, Hq[6], gxs[4], 0.0, 0.0}, {gxs[0], gxs[1], gxs[2], gxs[3], gxs[4], 0.0, lu0, lu1},
+                                               {0.0, 0.0, 0.0, 0.0, 0.0, lu0, Hq[0], 0.0}, {0.0, 0.0, 0.0, 0.0, 0.0, lu1, 0.0, Hq[1]}};
+                    double *hc = RL.H + LT::HS * i;
+                    if constexpr (COMPACT) {    // rows 0..5, then H66 and H77 (rows 6, 7 are synthesised by the sweep, RowLdsC)
+#pragma unroll
+                        for (int r = 0; r < 6; r++)
+#pragma unroll
+                            for (int c = 0; c < 8; c++) hc[r * 8 + c] = Hrow[r][c];
+                        hc[48] = Hq[0]; hc[51] = Hq[1];
+                        if (has_u) { double *w = RL.W + LT::WS * i; w[5] = bbr[0]; w[13] = bbr[1]; w[16] = bbr[2]; w[17] = bbr[3]; w[18] = bbr[4]; }
+                    } else {
+#pragma unroll
+                    for (int r = 0; r < 8; r++)
+#pragma unroll
+                        for (int c = 0; c < 8; c++) hc[r * 8 + c] = Hrow[r][c];
+                    if (has_u) {
+#pragma unroll
+                        for (int k = 0; k < 5; k++) RL.W[RowLds::WS * i + k * 8 + 5] = bbr[k];
+                    }
+                    }
+                }
+                wave_sync();
+                MPC_TICK(9);
+#ifdef MPC_FACTOR_PLAIN
+                rowpar_factor(lane, N, RS, sweep_worker);
+#else
+                if constexpr (COMPACT) {
+#ifdef MPC_COMPACT_PLAIN
+                    rowpar_factor(lane, N, RS, sweep_worker);
+#else
+                    rowpar_factor_fast_c(lane, N, RS, sweep_worker);
+#endif
+                } else {
+#ifdef MPC_MFMA4
+                    if constexpr (G == 64) mfma4_factor(lane, N, RS); else
+#endif
+                    rowpar_factor_fast(lane, N, RS, sweep_worker);
+                }
+#endif
+                wave_sync();
+                F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;
+#pragma unroll
+                for (int c = 0; c < 5; c++) { F.K0[c] = 0.0; F.K1[c] = 0.0; }
+                if (has_u) {
+                    const double *ko = RL.H + LT::HS * i;
+#pragma unroll
+                    for (int c = 0; c < 5; c++) { F.K0[c] = ko[c]; F.K1[c] = ko[8 + c]; }
+                    F.k0 = ko[5]; F.k1 = ko[13]; F.i00 = ko[6]; F.l = ko[7]; F.i11 = ko[14];
+                }
+                // (no barrier: every lane overwrites only the block it has just read, and a wavefront's LDS operations complete in order)
+                if (has_u) {    // closed-loop matrix Acl = A + B K of this stage, row-major, for the row-parallel vector recursions
+                    double *acl = RL.H + LT::HS * i + RowVec::ACL;
+                    const StageLin SL = stage_lin();
+                    const double Ar[2][5] = {{1.0, 0.0, SL.a02, SL.a03, SL.a04}, {0.0, 1.0, SL.a12, SL.a13, SL.a14}};
+                    const double Br[2][2] = {{SL.b00, SL.b01}, {SL.b10, SL.b11}};
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        acl[0 * RowVec::RS + c] = Ar[0][c] + Br[0][0] * F.K0[c] + Br[0][1] * F.K1[c];
+                        acl[1 * RowVec::RS + c] = Ar[1][c] + Br[1][0] * F.K0[c] + Br[1][1] * F.K1[c];
+                        acl[2 * RowVec::RS + c] = (c == 2 ? 1.0 : (c == 4 ? dt : 0.0)) + h2 * F.K1[c];
+                        acl[3 * RowVec::RS + c] = (c == 3 ? 1.0 : 0.0) + dt * F.K0[c];
+                        acl[4 * RowVec::RS + c] = (c == 4 ? 1.0 : 0.0) + dt * F.K1[c];
+                    }
+                }
+            } else
+                systolic_factor(i, N, S, Hq, gloc[0] + cb[0], gloc[1] + cb[1], gxs, bbr, rhoPi != 0.0, F);
+        }
+        MPC_TICK(2);
+        if (ROWPAR) {
+            if (has_u) {        // c_t = r_b + B k
+                double *cc = RL.H + LT::HS * i + RowVec::ACL + 5;      // c[r] closes row r
+                const StageLin SL = stage_lin();
+                cc[0 * RowVec::RS] = bbr[0] + SL.b00 * F.k0 + SL.b01 * F.k1; cc[1 * RowVec::RS] = bbr[1] + SL.b10 * F.k0 + SL.b11 * F.k1;
+                cc[2 * RowVec::RS] = bbr[2] + h2 * F.k1; cc[3 * RowVec::RS] = bbr[3] + dt * F.k0; cc[4 * RowVec::RS] = bbr[4] + dt * F.k1;
+            }
+            if (i == 0) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = SLDS ? rhoPi * lds_raw[RowLdsC::CT + slot * 5 + c] : x_init[c];
+            }
+            wave_sync();
+            rowpar_vector_fast<true>(lane, N, RS, sweep_worker);
+            wave_sync();
+            if (act) {
+                const double *xx = RL.H + LT::HS * i + RowVec::X;
+                double u0 = F.k0, u1 = F.k1;
+#pragma unroll
+                for (int c = 0; c < 5; c++) { za[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }
+                za[0] = u0; za[1] = u1;
+            }
+        } else
+            systolic_rollout<true>(i, N, S, F, x_init, bbr, za);
+        MPC_TICK(3);
+
+        // ---- affine step: dt, dlam per row, step ratios, products dlam_aff * dt_aff ----
+        // The products dlam_aff * dt_aff of the rows are not carried from here to the combined step (18 doubles with 3 obstacles, 32 with 10: they would
+        // cross two sweeps in accumulation registers -- six register moves per double -- and with ten obstacles they are what no longer fits): the combined
+        // step recomputes them from the affine step za, which it keeps, and the corrector's right-hand side, linear in sigma * mu, is accumulated HERE
+        // as  gc = G1 - sigma mu G0  (so the corrector has no pass over the rows at all).
+        double G1[7] = {0, 0, 0, 0, 0, 0, 0}, G0[7] = {0, 0, 0, 0, 0, 0, 0};
+        double smu;
+        {
+#pragma unroll
+            for (int c = 0; c < 7; c++) OPAQUE(z[c]);
+#pragma unroll
+            for (int j = 0; j < NOBST; j++) { OPAQUE(l1[j]); OPAQUE(l2[j]); }
+            refresh_box_rcp();
+            reload_bounds();
+            double vals[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
+#pragma unroll
+            for (int k = 0; k < NB; k++) OPAQUE(vals[k]);
+            double rmax = 0.0, rmaxd = 0.0;      // largest -dt/t (primal) and -dlam/lam (dual) ratios
+            double rg = 0.0, rgd = 0.0;      // ... of one row group (see m_u, m_x, m_s), entered when the group is done
+            // complementarity after the affine step, sum over the rows of (lam + ad dlam)(t + a dt) = S0 + a S1 + ad S2 + a ad S3 with
+            // S0 = sum lam t, S1 = sum lam dt, S2 = sum dlam t, S3 = sum dlam dt per row group: four running sums instead of the rows' steps
+            // kept alive across the ratio reduction (24 + 4 NOBST doubles: the register peak of the whole iteration)
+            double S0 = 0.0, S1 = 0.0, S2 = 0.0, S3 = 0.0, T0 = 0.0, T1 = 0.0, T2 = 0.0, T3 = 0.0;      // S: the group in progress, T: this lane's totals
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                double rdl, rdh;
+                box_rd(k, vals, z, rdl, rdh);
+                const double dzk = za[zidx[k]];
+                const double dtl = dzk + rdl, dth = -dzk + rdh;
+                const double ltl = ll[k] * tl[k], lth = lh[k] * th[k];
+                const double dll = -(ltl + ll[k] * dtl) * rtl[k], dlh = -(lth + lh[k] * dth) * rth[k];
+                const double ppl = dll * dtl, pph = dlh * dth;
+                G1[zidx[k]] = MPC_MK(k) * (ppl * rtl[k] - pph * rth[k]); G0[zidx[k]] = MPC_MK(k) * (rtl[k] - rth[k]);
+                rg = fmax(rg, fmax(-dtl * rtl[k], -dth * rth[k]));
+                rgd = fmax(rgd, fmax(fma(dtl, rtl[k], 1.0), fma(dth, rth[k], 1.0)));      // -dlam/lam = 1 + dt/t when sigma = 0
+                S0 += ltl + lth; S1 = fma(ll[k], dtl, fma(lh[k], dth, S1)); S2 = fma(dll, tl[k], fma(dlh, th[k], S2)); S3 += ppl + pph;
+                if (k == 1 || k == NB - 1) {
+                    const double m = MPC_MK(k);
+                    rmax = fmax(rmax, m * rg); rmaxd = fmax(rmaxd, m * rgd);
+                    T0 = fma(m, S0, T0); T1 = fma(m, S1, T1); T2 = fma(m, S2, T2); T3 = fma(m, S3, T3);
+                    rg = rgd = 0.0; S0 = S1 = S2 = S3 = 0.0;
+                }
+            }
+            double cx1 = 0.0, cx0 = 0.0, cy1 = 0.0, cy0 = 0.0;      // the obstacle rows' part of G1, G0 (x and y entries)
+            const double pz = phase_zero();
+#pragma unroll
+            for (int j = 0; j < NOBST; j++) {
+                if (!ROW_OFF(j)) {
+                    const ObstView v = obst_view(j, pz);
+                    const SoftT o = soft_terms(j, v, z);
+                    const double y = v.ax * za[2] + v.ay * za[3];
+                    const double lt1 = l1[j] * t1[j];
+                    double e1, e0, dt1, dl1;       // d beta_c eliminated to the x, y entries: geff = e1 - sigma mu e0
+                    if (soft) {
+                        const double rsum = o.rs + o.be1 + o.be2;
+                        const double ds = -(rsum + o.w1 * y) * o.rD;
+                        dt1 = o.rd1 + (y * (zpen + o.w2) - rsum) * o.rD;     // y + ds without cancellation
+                        const double dt2 = o.rd2 + ds;
+                        const double lt2 = l2[j] * t2[j];
+                        const double dl2 = -(lt2 + l2[j] * dt2) * v.rt2;
+                        dl1 = -(lt1 + l1[j] * dt1) * v.rt1;
+                        const double pp2 = dl2 * dt2, pp1 = dl1 * dt1;
+                        const double q = (zpen + o.w2) * v.rt1, r = o.w1 * v.rt2;
+                        e1 = (pp1 * q - pp2 * r) * o.rD; e0 = (q - r) * o.rD;
+                        rg = fmax(rg, -dt2 * v.rt2); rgd = fmax(rgd, fma(dt2, v.rt2, 1.0));
+                        S0 += lt2; S1 = fma(l2[j], dt2, S1); S2 = fma(dl2, t2[j], S2); S3 += pp2 + pp1;
+                    } else {
+                        dt1 = o.rd1 + y;
+                        dl1 = -(lt1 + l1[j] * dt1) * v.rt1;
+                        e1 = dl1 * dt1 * v.rt1; e0 = v.rt1;
+                        S3 = fma(dl1, dt1, S3);
+                    }
+                    S0 += lt1; S1 = fma(l1[j], dt1, S1); S2 = fma(dl1, t1[j], S2);
+                    cx1 = fma(e1, v.ax, cx1); cx0 = fma(e0, v.ax, cx0); cy1 = fma(e1, v.ay, cy1); cy0 = fma(e0, v.ay, cy0);
+                    rg = fmax(rg, -dt1 * v.rt1); rgd = fmax(rgd, fma(dt1, v.rt1, 1.0));
+                }
+            }
+            G1[2] = fma(m_s, cx1, G1[2]); G0[2] = fma(m_s, cx0, G0[2]); G1[3] = fma(m_s, cy1, G1[3]); G0[3] = fma(m_s, cy0, G0[3]);
+            rmax = fmax(rmax, m_s * rg); rmaxd = fmax(rmaxd, m_s * rgd);
+            T0 = fma(m_s, S0, T0); T1 = fma(m_s, S1, T1); T2 = fma(m_s, S2, T2); T3 = fma(m_s, S3, T3);      // this lane's four sums over the rows that exist
+            seg_reduce2<G, false>(rmax, rmaxd, lane);
+            const double a_aff = rmax > 1.0 ? 1.0 / rmax : 1.0, a_affd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;      // (true divisions, as the oracle: a 1-ulp reciprocal here moves a sensitive instance past the parity tolerance)
+            double maff = fma(a_aff, fma(a_affd, T3, T1), fma(a_affd, T2, T0));
+            maff = seg_sum<G>(maff, lane) * inv_items;
+            double sigma = mu > 0 ? maff / mu : 0.0;
+            sigma = sigma * sigma;
+            if (sigma > 1.0) sigma = 1.0;
+            smu = sigma * mu;
+#ifndef MPC_PHASE_TIMING
+            if (p.trace && i == 0 && valid && running) {
+                double *tr = p.trace + ((size_t)inst * p.iter_max + it) * 4;
+                tr[0] = mu; tr[1] = sigma; tr[3] = cmax;
+            }
+#endif
+        }
+        MPC_TICK(4);
+
+        // ---- corrector: homogeneous system for the change of right-hand side, d beta_c = (dlam_aff dt_aff - sigma mu) / t ----
+        double dz[7] = {0, 0, 0, 0, 0, 0, 0};
+        {
+            double gc[7];
+#pragma unroll
+            for (int c = 0; c < 7; c++) gc[c] = fma(-smu, G0[c], G1[c]);
+            MPC_TICK(5);
+            if (ROWPAR) {
+                if (act) {      // c~_t = gc_x + K' gc_u  (K = 0 in the terminal lane)
+                    double *cc = RL.H + LT::HS * i + RowVec::CT;
+#pragma unroll
+                    for (int c = 0; c < 5; c++) cc[c] = gc[2 + c] + F.K0[c] * gc[0] + F.K1[c] * gc[1];
+                }
+                wave_sync();
+                rowpar_vector_fast<false>(lane, N, RS, sweep_worker);
+                wave_sync();
+                if (has_u) {    // feed-forward of the corrector right-hand side: k = -Muu^-1 (gc_u + B' p_{t+1})
+                    const double *pp = RL.H + LT::HS * (i + 1) + RowVec::P;
+                    const double pv[5] = {pp[0], pp[1], pp[2], pp[3], pp[4]};
+                    const StageLin SL = stage_lin();
+                    const double m0 = gc[0] + SL.dua(pv), m1 = gc[1] + SL.dual(pv);
+                    F.k1 = fma(F.l, m0, -m1) * F.i11;
+                    F.k0 = fma(-F.l, F.k1, -(m0 * F.i00));
+                }
+            } else
+                systolic_corrector(i, N, S, gc, F);
+        }
+        MPC_TICK(6);
+        if (ROWPAR) {
+            if (has_u) {        // homogeneous dynamics: c_t = B k
+                double *cc = RL.H + LT::HS * i + RowVec::ACL + 5;
+                const StageLin SL = stage_lin();
+                cc[0 * RowVec::RS] = SL.b00 * F.k0 + SL.b01 * F.k1; cc[1 * RowVec::RS] = SL.b10 * F.k0 + SL.b11 * F.k1;
+                cc[2 * RowVec::RS] = h2 * F.k1; cc[3 * RowVec::RS] = dt * F.k0; cc[4 * RowVec::RS] = dt * F.k1;
+            }
+            if (i == 0) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = 0.0;
+            }
+            wave_sync();
+            rowpar_vector_fast<true>(lane, N, RS, sweep_worker);
+            wave_sync();
+            if (act) {
+                const double *xx = RL.H + LT::HS * i + RowVec::X;
+                double u0 = F.k0, u1 = F.k1;
+#pragma unroll
+                for (int c = 0; c < 5; c++) { dz[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }
+                dz[0] = u0; dz[1] = u1;
+            }
+        } else
+            systolic_rollout<false>(i, N, S, F, x_init, bbr, dz);
+#pragma unroll
+        for (int c = 0; c < 7; c++) dz[c] += za[c];
+        MPC_TICK(7);
+
+        // ---- combined step: ratios, step length, update (instances that have stopped keep their state) ----
+        {
+#pragma unroll
+            for (int c = 0; c < 7; c++) { OPAQUE(z[c]); OPAQUE(za[c]); }      // (za: or the optimiser keeps the affine phase's products alive instead of recomputing them)
+#pragma unroll
+            for (int j = 0; j < NOBST; j++) { OPAQUE(l1[j]); OPAQUE(l2[j]); }
+            refresh_box_rcp();
+            reload_bounds();
+            double vals[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
+#pragma unroll
+            for (int k = 0; k < NB; k++) OPAQUE(vals[k]);
+            double rmax = 0.0, rmaxd = 0.0;
+            double rg = 0.0, rgd = 0.0;
+            double dtl_[NB], dth_[NB], dll_[NB], dlh_[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                double rdl, rdh;
+                box_rd(k, vals, z, rdl, rdh);
+                const double dzk = dz[zidx[k]];
+                dtl_[k] = dzk + rdl; dth_[k] = -dzk + rdh;
+                // (dlam_aff dt_aff of the row, exactly as the affine phase formed it: same state, same za)
+                const double dal = za[zidx[k]] + rdl, dah = -za[zidx[k]] + rdh;
+                const double ppl = -(ll[k] * tl[k] + ll[k] * dal) * rtl[k] * dal, pph = -(lh[k] * th[k] + lh[k] * dah) * rth[k] * dah;
+                dll_[k] = -(ll[k] * tl[k] - smu + ppl + ll[k] * dtl_[k]) * rtl[k];
+                dlh_[k] = -(lh[k] * th[k] - smu + pph + lh[k] * dth_[k]) * rth[k];
+                rg = fmax(rg, fmax(-dtl_[k] * rtl[k], -dth_[k] * rth[k]));
+                rgd = fmax(rgd, fmax(-dll_[k] * rcp_nr(ll[k]), -dlh_[k] * rcp_nr(lh[k])));
+                if (k == 1 || k == NB - 1) { rmax = fmax(rmax, MPC_MK(k) * rg); rmaxd = fmax(rmaxd, MPC_MK(k) * rgd); rg = rgd = 0.0; }
+            }
+            // the combined step of obstacle row pair j
+            struct ObstStep { double dt1, dl1, dt2, dl2, ds; };
+            auto obst_step = [&](int j, double pzero) {
+                ObstStep q; q.dt2 = q.dl2 = q.ds = 0.0;
+                const ObstView v = obst_view(j, pzero);
+                const SoftT o = soft_terms(j, v, z);
+                const double y = v.ax * dz[2] + v.ay * dz[3];
+                const double ya = v.ax * za[2] + v.ay * za[3];
+                double pp1;
+                if (soft) {
+                    const double rsa = o.rs + o.be1 + o.be2;
+                    const double da1 = o.rd1 + (ya * (zpen + o.w2) - rsa) * o.rD, da2 = o.rd2 - (rsa + o.w1 * ya) * o.rD;
+                    const double pp2 = -(l2[j] * t2[j] + l2[j] * da2) * v.rt2 * da2;
+                    pp1 = -(l1[j] * t1[j] + l1[j] * da1) * v.rt1 * da1;
+                    const double db1 = (pp1 - smu) * v.rt1, db2 = (pp2 - smu) * v.rt2;
+                    const double rsum = o.rs + (o.be1 + db1) + (o.be2 + db2);
+                    q.ds = -(rsum + o.w1 * y) * o.rD;
+                    q.dt1 = o.rd1 + (y * (zpen + o.w2) - rsum) * o.rD;
+                    q.dt2 = o.rd2 + q.ds;
+                    q.dl2 = -(l2[j] * t2[j] - smu + pp2 + l2[j] * q.dt2) * v.rt2;
+                    rg = fmax(rg, -q.dt2 * v.rt2); rgd = fmax(rgd, -q.dl2 * rcp_nr(l2[j]));
+                } else {
+                    const double da1 = o.rd1 + ya;
+                    pp1 = -(l1[j] * t1[j] + l1[j] * da1) * v.rt1 * da1;
+                    q.dt1 = o.rd1 + y;
+                }
+                q.dl1 = -(l1[j] * t1[j] - smu + pp1 + l1[j] * q.dt1) * v.rt1;
+                rg = fmax(rg, -q.dt1 * v.rt1); rgd = fmax(rgd, -q.dl1 * rcp_nr(l1[j]));
+                return q;
+            };
+            // TWOPASS (ten obstacles): the 50 step values of the obstacle rows are not kept across the ratio reduction -- they are the register peak of
+            // the iteration, 100 registers that end up in scratch memory -- but computed again behind it (+6 % instructions, no scratch)
+            constexpr bool TWOPASS = false;      // (tried with ten obstacles: +17 % instructions and the same scratch -- the peak is not here)
+            double dt1_[TWOPASS ? 1 : NOBST], dl1_[TWOPASS ? 1 : NOBST], dt2_[TWOPASS ? 1 : NOBST], dl2_[TWOPASS ? 1 : NOBST], ds_[TWOPASS ? 1 : NOBST];
+            {
+                const double pz = phase_zero();
+#pragma unroll
+                for (int j = 0; j < NOBST; j++) {
+                    if (ROW_OFF(j)) continue;
+                    const ObstStep q = obst_step(j, pz);
+                    if constexpr (!TWOPASS) { dt1_[j] = q.dt1; dl1_[j] = q.dl1; dt2_[j] = q.dt2; dl2_[j] = q.dl2; ds_[j] = q.ds; }
+                }
+            }
+            rmax = fmax(rmax, m_s * rg); rmaxd = fmax(rmaxd, m_s * rgd);
+            seg_reduce2<G, false>(rmax, rmaxd, lane);
+            const double amax = rmax > 1.0 ? 1.0 / rmax : 1.0, amaxd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;
+            const double alpha = (amax >= 1.0) ? 1.0 : kFracToBoundary * amax;        // primal step: z, s, t
+            const double alphad = (amaxd >= 1.0) ? 1.0 : kFracToBoundary * amaxd;     // dual step: lam
+#ifndef MPC_PHASE_TIMING
+            if (p.trace && i == 0 && valid && running) p.trace[((size_t)inst * p.iter_max + it) * 4 + 2] = alpha;
+#endif
+            if (running && (!(alpha > 1e-14) || !(alphad > 1e-14))) { status = 4; running = false; it_done = it; }
+            {   // An instance that has stopped keeps its step z (a select, not a step of length zero: what a converged instance computes while it idles
+                // beside a neighbour that still iterates is a Newton step from a state with slacks at their floor -- it may be Inf or NaN, and 0 * NaN
+                // is NaN).  Its row state is no longer read by anything and simply moves on, as do the rows that do not exist.
+                const double ae = alpha;
+                // rows that do not exist take no step (the 0 / 1 factors again): their dummy state stays at its benign initial value, so that everything
+                // computed from it is bounded whatever the instance does -- outside the ratio test they would otherwise run into their floors and
+                // overflow within a few iterations (lam grows by 1 / floor per step), and 0 * Inf would enter the shared sums as NaN
+                const double aeg[3] = {alpha * m_u, alpha * m_x, alpha * m_s}, adg[3] = {alphad * m_u, alphad * m_x, alphad * m_s};
+#pragma unroll
+                for (int c = 0; c < 7; c++) z[c] = running ? fma(ae, dz[c], z[c]) : z[c];
+#pragma unroll
+                for (int k = 0; k < NB; k++) {
+                    const int g = k < 2 ? 0 : 1;
+                    tl[k] = fmax(fma(aeg[g], dtl_[k], tl[k]), kTLMin); th[k] = fmax(fma(aeg[g], dth_[k], th[k]), kTLMin);
+                    ll[k] = fmax(fma(adg[g], dll_[k], ll[k]), kTLMin); lh[k] = fmax(fma(adg[g], dlh_[k], lh[k]), kTLMin);
+                    if constexpr (!LEAN) { rtl[k] = rcp_nr(tl[k]); rth[k] = rcp_nr(th[k]); }
+                }
+                const double pz2 = phase_zero();
+#pragma unroll
+                for (int j = 0; j < NOBST; j++) {
+                    if (ROW_OFF(j)) continue;
+                    ObstStep q;
+                    if constexpr (TWOPASS) q = obst_step(j, pz2);      // (its ratio outputs are dead here)
+                    else { q.dt1 = dt1_[j]; q.dl1 = dl1_[j]; q.dt2 = dt2_[j]; q.dl2 = dl2_[j]; q.ds = ds_[j]; }
+                    t1[j] = fmax(fma(aeg[2], q.dt1, t1[j]), kTLMin); l1[j] = fmax(fma(adg[2], q.dl1, l1[j]), kTLMin);
+                    if constexpr (!LEAN) rt1[j] = rcp_nr(t1[j]);
+                    if (soft) {
+                        sv[j] = fma(aeg[2], q.ds, sv[j]);
+                        t2[j] = fmax(fma(aeg[2], q.dt2, t2[j]), kTLMin); l2[j] = fmax(fma(adg[2], q.dl2, l2[j]), kTLMin);
+                        if constexpr (!LEAN) rt2[j] = rcp_nr(t2[j]);
+                    }
+                }
+                rhoPi *= (1.0 - ae);
+            }
+        }
+        MPC_TICK(8);
+    }
+    } else {
     for (it = 0;; it++) {
         // ---- complementarity measures ----
         double msum = 0.0, cmax = 0.0;
@@ -2006,6 +2591,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         for (int c = 0; c < 5; c++) { bbr[c] = rhoPi * bb[c]; x_init[c] = SLDS ? 0.0 : rhoPi * d0[c]; }
         {
             refresh_box_rcp();
+            reload_bounds();
             double vals[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
 #pragma unroll
             for (int k = 0; k < NB; k++) OPAQUE(vals[k]);
@@ -2015,6 +2601,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 // scalar copy first -- written as if / else on the argument arrays, the optimiser selects the ADDRESS and issues five
                 // per-lane global loads from the kernel-argument segment inside the iteration loop
                 double hs[7], ht[5], wg[6], we[4];
+#ifdef MPC_NO_RELOAD
 #pragma unroll
                 for (int c = 0; c < 7; c++) { hs[c] = p.Hd_stage[c]; asm volatile("" : "+s"(hs[c])); }
 #pragma unroll
@@ -2023,6 +2610,18 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 for (int c = 0; c < 6; c++) { wg[c] = p.Wg[c]; asm volatile("" : "+s"(wg[c])); }
 #pragma unroll
                 for (int c = 0; c < 4; c++) { we[c] = p.Weg[c]; asm volatile("" : "+s"(we[c])); }
+#else
+                KArg *pk = (KArg *)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(pk));
+#pragma unroll
+                for (int c = 0; c < 7; c++) hs[c] = pk->Hd_stage[c];
+#pragma unroll
+                for (int c = 0; c < 5; c++) ht[c] = pk->Hd_term[c];
+#pragma unroll
+                for (int c = 0; c < 6; c++) wg[c] = pk->Wg[c];
+#pragma unroll
+                for (int c = 0; c < 4; c++) we[c] = pk->Weg[c];
+#endif
                 Hd[0] = has_u ? hs[0] : 0.0; Hd[1] = has_u ? hs[1] : 0.0;
 #pragma unroll
                 for (int c = 0; c < 5; c++) Hd[2 + c] = has_u ? hs[2 + c] : ht[c];
@@ -2196,6 +2795,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #pragma unroll
             for (int j = 0; j < NOBST; j++) { OPAQUE(l1[j]); OPAQUE(l2[j]); }
             refresh_box_rcp();
+            reload_bounds();
             double vals[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
 #pragma unroll
             for (int k = 0; k < NB; k++) OPAQUE(vals[k]);
@@ -2348,6 +2948,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #pragma unroll
             for (int j = 0; j < NOBST; j++) { OPAQUE(l1[j]); OPAQUE(l2[j]); }
             refresh_box_rcp();
+            reload_bounds();
             double vals[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
 #pragma unroll
             for (int k = 0; k < NB; k++) OPAQUE(vals[k]);
@@ -2424,7 +3025,9 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         }
         MPC_TICK(8);
     }
+    }
 #undef OPAQUE
+#undef MPC_MK
 #ifdef MPC_PHASE_TIMING
     if (p.trace && i == 0 && valid) { for (int k = 0; k < 10; k++) p.trace[((size_t)inst * p.iter_max) * 4 + k] = (double)tacc_[k]; }
 #endif
