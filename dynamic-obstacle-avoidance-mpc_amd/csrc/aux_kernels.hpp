@@ -180,7 +180,8 @@ __global__ __launch_bounds__(64) void shift_kernel(int batch, int N, double *__r
 }
 
 // set_initial_guess, robot_ocp_problem.py:286-306: X[i] = [x0_x, x0_y, x0_psi, 0, 0], U = 0.
-__global__ void reset_guess_kernel(int batch, int N, const double *__restrict__ x0, double *__restrict__ X, double *__restrict__ U)
+// goal != null: the straight-line variant of the commented block :293-300 (interp_guess, rti_kernel.hpp).
+__global__ void reset_guess_kernel(int batch, int N, const double *__restrict__ x0, const double *__restrict__ goal, double *__restrict__ X, double *__restrict__ U)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= batch * (N + 1)) return;
@@ -188,6 +189,13 @@ __global__ void reset_guess_kernel(int batch, int N, const double *__restrict__ 
     const double *x = x0 + (size_t)inst * 5;
     double *Xi = X + (size_t)t * 5;
     Xi[0] = x[0]; Xi[1] = x[1]; Xi[2] = x[2]; Xi[3] = 0.0; Xi[4] = 0.0;
+    if (goal) {
+        const double xs[5] = {x[0], x[1], x[2], x[3], x[4]};
+        double xg[5];
+        interp_guess(xs, goal[(size_t)inst * 2 + 1], i, N, xg);
+#pragma unroll
+        for (int c = 0; c < 5; c++) Xi[c] = xg[c];
+    }
     if (i < N) { double *Ui = U + ((size_t)inst * N + i) * 2; Ui[0] = 0.0; Ui[1] = 0.0; }
 }
 

@@ -519,16 +519,27 @@ int mpc_shift_dev(mpc_handle *h, int batch, double *d_X, double *d_U, void *stre
     return MPC_OK;
 }
 
-int mpc_reset_guess_dev(mpc_handle *h, int batch, const double *d_x0, double *d_X, double *d_U, void *stream)
+static int reset_guess_launch(mpc_handle *h, int batch, const double *d_x0, const double *d_goal, double *d_X, double *d_U, void *stream)
 {
     int rc = check_batch(h, batch); if (rc) return rc;
     if (batch == 0) return MPC_OK;
     if (!d_x0 || !d_X || !d_U) return fail(MPC_ERR_ARG, "null device pointer");
     HIPCHK(hipSetDevice(h->device));
     const int count = batch * (h->cfg.N + 1);
-    hipLaunchKernelGGL(mpc::reset_guess_kernel, dim3((count + 255) / 256), dim3(256), 0, pick(h, stream), batch, h->cfg.N, d_x0, d_X, d_U);
+    hipLaunchKernelGGL(mpc::reset_guess_kernel, dim3((count + 255) / 256), dim3(256), 0, pick(h, stream), batch, h->cfg.N, d_x0, d_goal, d_X, d_U);
     HIPCHK(hipGetLastError());
     return MPC_OK;
+}
+
+int mpc_reset_guess_dev(mpc_handle *h, int batch, const double *d_x0, double *d_X, double *d_U, void *stream)
+{
+    return reset_guess_launch(h, batch, d_x0, nullptr, d_X, d_U, stream);
+}
+
+int mpc_reset_guess_interp_dev(mpc_handle *h, int batch, const double *d_x0, const double *d_goal, double *d_X, double *d_U, void *stream)
+{
+    if (!d_goal) return fail(MPC_ERR_ARG, "null device pointer");
+    return reset_guess_launch(h, batch, d_x0, d_goal, d_X, d_U, stream);
 }
 
 int mpc_plant_step_dev(mpc_handle *h, int batch, const double *d_x, const double *d_u, double *d_xnext, void *stream)
@@ -618,6 +629,18 @@ int mpc_reset_guess(mpc_handle *h, int batch, const double *x0)
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpyAsync(h->d_x0, x0, (size_t)batch * 5 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     rc = mpc_reset_guess_dev(h, batch, h->d_x0, h->dX, h->dU, nullptr); if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPC_OK;
+}
+
+int mpc_reset_guess_interp(mpc_handle *h, int batch, const double *x0, const double *goal)
+{
+    int rc = check_batch(h, batch); if (rc) return rc;
+    if (!x0 || !goal) return fail(MPC_ERR_ARG, "null pointer");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->d_x0, x0, (size_t)batch * 5 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_goal, goal, (size_t)batch * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    rc = mpc_reset_guess_interp_dev(h, batch, h->d_x0, h->d_goal, h->dX, h->dU, nullptr); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     return MPC_OK;
 }

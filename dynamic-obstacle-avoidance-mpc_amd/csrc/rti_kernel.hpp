@@ -53,7 +53,8 @@ enum : int {
     kFuseObstacles = 4,    // obstacle states advance one step, optional velocity noise (visualization.py:20-33)
     kFuseResetOnFail = 8,  // status 4 -> set_initial_guess() before the plant step (:203-205)
     kFuseAliasBug = 16,    // ... which in the reference also zeroes the plant's v, omega (defect D2, :301-302)
-    kFuseMetrics = 32      // episode bookkeeping of RobotOcpProblem.step (:213-250)
+    kFuseMetrics = 32,     // episode bookkeeping of RobotOcpProblem.step (:213-250)
+    kFuseInterpGuess = 64  // ... and that set_initial_guess() is the straight-line variant the reference keeps commented out (:293-300, interp_guess below)
 };
 
 struct KParams {
@@ -166,6 +167,23 @@ __device__ __forceinline__ void obstacle_advance(const World w, double dt, doubl
     coord_advance(w.xmin, w.xmax, dt, x, vx);
     coord_advance(w.ymin, w.ymax, dt, y, vy);
 }
+// The reference's OTHER initial guess (robot_ocp_problem.py:293-300, a commented block -- the code that recorded the two `interpolate_init` tables of
+// src/simulation/test_data): stage i of N starts at
+//     x = x0_x + i / N * (x0_x - x0_x) = x0_x      (sic: the x coordinate does not move),   y = x0_y + i / N * (goal_y - x0_y),
+//     psi = arctan2(goal_y - x0_y, goal_x - goal_x) = arctan2(dy, 0) = +-pi/2 (0 when dy = 0),   v = omega = 0,   u = 0,
+// defects included.  Plain IEEE operations in the reference's order (no contraction), so that the guess is bit for bit numpy's.
+__device__ __forceinline__ void interp_guess(const double x0[5], double goal_y, int i, int N, double xg[5])
+{
+#pragma clang fp contract(off)
+    const double dy = goal_y - x0[1];
+    const double f = (double)i / (double)N;
+    const double step = f * dy;
+    xg[0] = x0[0] + f * (x0[0] - x0[0]);
+    xg[1] = x0[1] + step;
+    xg[2] = atan2(dy, 0.0);
+    xg[3] = 0.0; xg[4] = 0.0;
+}
+
 // velocity noise of Obstacle.step(), visualization.py:28-33
 __device__ __forceinline__ void obstacle_noise(double randomness, double vmax, double nx, double ny, double &vx, double &vy)
 {
@@ -3053,6 +3071,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     const double u_apply[2] = {lane_value_seg<G>(ui[0], lane), lane_value_seg<G>(ui[1], lane)};   // u* = U[0] of this instance
     if ((p.fused & kFuseResetOnFail) && status == 4) {      // set_initial_guess(), robot_ocp_problem.py:203-205,286-306
         xi[0] = x0v[0]; xi[1] = x0v[1]; xi[2] = x0v[2]; xi[3] = 0.0; xi[4] = 0.0; ui[0] = ui[1] = 0.0;
+        if (p.fused & kFuseInterpGuess) interp_guess(x0v, gl[1], i <= N ? i : N, N, xi);
     }
     if (store && (status != 4 || (p.fused & (kFuseResetOnFail | kFuseShift)))) {
         if (p.fused & kFuseShift) {                          // X[j] <- X[j+1], U[j] <- U[j+1], U[N-1] <- 0, X[N] kept (:253-258)

@@ -732,6 +732,7 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
     const double u_apply[2] = {lane_value(ui[0], 0), lane_value(ui[1], 0)};   // u* = U[0]
     if ((p.fused & kFuseResetOnFail) && status == 4) {      // set_initial_guess(), robot_ocp_problem.py:203-205,286-306
         xi[0] = x0v[0]; xi[1] = x0v[1]; xi[2] = x0v[2]; xi[3] = 0.0; xi[4] = 0.0; ui[0] = ui[1] = 0.0;
+        if (p.fused & kFuseInterpGuess) interp_guess(x0v, gl[1], i <= N ? i : N, N, xi);
     }
     if (store && own && (status != 4 || (p.fused & (kFuseResetOnFail | kFuseShift)))) {
         if (p.fused & kFuseShift) {                          // X[j] <- X[j+1], U[j] <- U[j+1], U[N-1] <- 0, X[N] kept (:253-258)

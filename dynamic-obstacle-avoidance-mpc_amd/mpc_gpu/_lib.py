@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("MPC_GPU_LIB") or os.path.join(PKG_ROOT, "libmpcgpu.so
 REPO_ROOT = os.path.dirname(PKG_ROOT)
 
 MPC_OK, MPC_ERR_ARG, MPC_ERR_HIP, MPC_ERR_NODEVICE = 0, -1, -2, -3
-STEP_SHIFT, STEP_PLANT, STEP_OBSTACLES, STEP_RESET_ON_FAIL, STEP_ALIAS_BUG, STEP_METRICS = 1, 2, 4, 8, 16, 32
+STEP_SHIFT, STEP_PLANT, STEP_OBSTACLES, STEP_RESET_ON_FAIL, STEP_ALIAS_BUG, STEP_METRICS, STEP_INTERP_GUESS = 1, 2, 4, 8, 16, 32, 64
 
 _d = C.c_double
 _i32 = C.c_int32
@@ -48,6 +48,7 @@ SYMBOLS = {
     "mpc_set_warmstart": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "mpc_get_traj": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "mpc_reset_guess": (C.c_int, [_vp, C.c_int, _vp]),
+    "mpc_reset_guess_interp": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "mpc_shift": (C.c_int, [_vp, C.c_int]),
     "mpc_solve": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mpc_solve_obst": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -60,6 +61,7 @@ SYMBOLS = {
     "mpc_predict_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "mpc_shift_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "mpc_reset_guess_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "mpc_reset_guess_interp_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "mpc_plant_step_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     "mpc_obstacle_step_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _d, _d, _vp]),
     "mpc_linearize_dev": (C.c_int, [_vp, C.c_int] + [_vp] * 12),

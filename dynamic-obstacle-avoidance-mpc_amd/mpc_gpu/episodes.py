@@ -17,13 +17,18 @@ from .solver import BatchedMpc
 
 
 def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, init_guess_when_error=True,
-                 bug_compat_alias=True, seed=0, device=0, solver=None, n_obst=5, first_seed=0, record=False, noise=None, **cfg):
+                 bug_compat_alias=True, seed=0, device=0, solver=None, n_obst=5, first_seed=0, record=False, noise=None,
+                 interpolate_init=False, status_log=False, **cfg):
     """x0 (B,5), goal (B,2), obst (B,n_obst,4) -- or a scenario name ("RANDOM" | "CENTER" | "EDGE"): instance s then starts
     from the reference generator's draw for np.random.seed(first_seed + s), produced on the device (experiments.py:26-29).
     record=True also returns simX (steps+1,B,5), obst_traj (steps+1,B,n_obst,4) and pred (steps,B,N+1,5): what the reference keeps
     for its visualisation (robot_ocp_problem.py:232-240,270-276).
     noise: None -> standard normals from torch's generator (`seed`); an array (steps, B, n_obst, 2) -> exactly these normals, control step
     k using noise[k] (world.reference_streams gives the sequences the reference's own runs consumed, per seed).
+    interpolate_init: set_initial_guess() is the straight-line variant the reference keeps commented out (robot_ocp_problem.py:293-300; spec key
+    `interpolate_init` of two recorded tables) -- at the start and on every status-4 reset.
+    status_log: also return, per episode, how many of its solves ended with status 2 / status 4 and the first control step with a status != 0
+    (-1: none) -- `status2`, `status4`, `first_bad`.
     Returns dict(table (B,6), x_last (B,5), steps_run, solves)."""
     import torch
     x0 = np.ascontiguousarray(x0, dtype=np.float64); B = x0.shape[0]
@@ -45,10 +50,16 @@ def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, i
         margin = torch.full((B,), float("inf"), dtype=torch.float64, device=dev)
         flags = torch.zeros(B, dtype=torch.int32, device=dev); steps = torch.zeros(B, dtype=torch.int32, device=dev)
         s = stream.cuda_stream
-        m.reset_guess_dev(B, dx0, X, U, stream=s)            # set_initial_guess() at the start of step(), :180
+        if interpolate_init:
+            m.reset_guess_interp_dev(B, dx0, dgoal, X, U, stream=s)
+        else:
+            m.reset_guess_dev(B, dx0, X, U, stream=s)        # set_initial_guess() at the start of step(), :180
         fl = _lib.STEP_SHIFT | _lib.STEP_PLANT | _lib.STEP_OBSTACLES | _lib.STEP_METRICS
         if init_guess_when_error:
-            fl |= _lib.STEP_RESET_ON_FAIL | (_lib.STEP_ALIAS_BUG if bug_compat_alias else 0)
+            fl |= _lib.STEP_RESET_ON_FAIL | (_lib.STEP_ALIAS_BUG if bug_compat_alias else 0) | (_lib.STEP_INTERP_GUESS if interpolate_init else 0)
+        if status_log:
+            n2 = torch.zeros(B, dtype=torch.int32, device=dev); n4 = torch.zeros(B, dtype=torch.int32, device=dev)
+            first_bad = torch.full((B,), -1, dtype=torch.int32, device=dev)
         gen = torch.Generator(device=dev); gen.manual_seed(seed)
         dnoise = None
         if noise is not None and random_move:
@@ -67,6 +78,10 @@ def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, i
                 nz = torch.randn(B, n_obst, 2, dtype=torch.float64, device=dev, generator=gen)
             m.closed_loop_step_dev(B, dx0, dobst, dgoal, X, U, None, None, status, iters, nz, flags=fl,
                                    min_margin=margin, ep_flags=flags, ep_steps=steps, stream=s)
+            if status_log:      # (an episode that has reached its goal idles: its status word keeps the last solve's value and is not counted again)
+                live = (steps + (flags & 1)) > k
+                n2 += (live & (status == 2)).int(); n4 += (live & (status == 4)).int()
+                first_bad = torch.where(live & (status != 0) & (first_bad < 0), torch.full_like(first_bad, k), first_bad)
             k += 1
             if record:      # X holds the shifted prediction: stage j of the solve is X[j - 1], stage N is kept (:253-258)
                 rec_x.append(dx0.clone()); rec_o.append(dobst.clone()); rec_p.append(X.clone())
@@ -79,6 +94,8 @@ def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, i
         extra = {}
         if record:
             extra = dict(simX=torch.stack(rec_x).cpu().numpy(), obst_traj=torch.stack(rec_o).cpu().numpy(), pred=torch.stack(rec_p).cpu().numpy())
+        if status_log:
+            extra.update(status2=n2.cpu().numpy(), status4=n4.cpu().numpy(), first_bad=first_bad.cpu().numpy())
     if solver is None:
         m.close()
     return dict(table=table, x_last=xl, steps_run=k, solves=int(steps.sum().item()) + int((fl_h & 1).sum()), **extra)

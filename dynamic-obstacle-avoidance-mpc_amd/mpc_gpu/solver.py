@@ -74,6 +74,11 @@ class BatchedMpc:
         x0 = _f64(np.atleast_2d(x0))
         _lib.check(_lib.lib().mpc_reset_guess(self._h, x0.shape[0], _ptr(x0)))
 
+    def reset_guess_interp(self, x0, goal):
+        """set_initial_guess() of the commented block :293-300 (the `interpolate_init` tables): straight line in y towards the goal."""
+        x0 = _f64(np.atleast_2d(x0)); goal = _f64(np.atleast_2d(goal), (x0.shape[0], 2))
+        _lib.check(_lib.lib().mpc_reset_guess_interp(self._h, x0.shape[0], _ptr(x0), _ptr(goal)))
+
     def set_warmstart(self, X, U):
         X, U = _f64(X), _f64(U)
         B = X.shape[0]
@@ -187,6 +192,9 @@ class BatchedMpc:
 
     def reset_guess_dev(self, batch, x0, X, U, stream=None):
         _lib.check(_lib.lib().mpc_reset_guess_dev(self._h, batch, _ptr(x0), _ptr(X), _ptr(U), _ptr(stream)))
+
+    def reset_guess_interp_dev(self, batch, x0, goal, X, U, stream=None):
+        _lib.check(_lib.lib().mpc_reset_guess_interp_dev(self._h, batch, _ptr(x0), _ptr(goal), _ptr(X), _ptr(U), _ptr(stream)))
 
     def plant_step_dev(self, batch, x, u, xn, stream=None):
         _lib.check(_lib.lib().mpc_plant_step_dev(self._h, batch, _ptr(x), _ptr(u), _ptr(xn), _ptr(stream)))

@@ -93,6 +93,10 @@ int mpc_set_warmstart(mpc_handle *h, int batch, const double *X, const double *U
 int mpc_get_traj(mpc_handle *h, int batch, double *X, double *U);
 /* set_initial_guess(): reset(), X[i] = [x0_x, x0_y, x0_psi, 0, 0], U = 0, robot_ocp_problem.py:286-306 */
 int mpc_reset_guess(mpc_handle *h, int batch, const double *x0);
+/* set_initial_guess() as the commented block robot_ocp_problem.py:293-300 computes it -- the variant that recorded the two `interpolate_init`
+ * tables of src/simulation/test_data (20221031_225145, _225445): stage i starts at (x0_x, x0_y + i/N (goal_y - x0_y), arctan2(goal_y - x0_y, 0), 0, 0),
+ * U = 0; the reference's slips (`x0[0] - x0[0]`, `subgoal[0] - subgoal[0]`) included, bit for bit numpy's arithmetic. */
+int mpc_reset_guess_interp(mpc_handle *h, int batch, const double *x0, const double *goal);
 /* warm-start shift, robot_ocp_problem.py:253-258 */
 int mpc_shift(mpc_handle *h, int batch);
 
@@ -139,12 +143,14 @@ int mpc_predict_dev(mpc_handle *h, int batch, const double *d_obst, double *d_P,
 #define MPC_STEP_RESET_ON_FAIL 8
 #define MPC_STEP_ALIAS_BUG 16
 #define MPC_STEP_METRICS 32
+#define MPC_STEP_INTERP_GUESS 64   /* with MPC_STEP_RESET_ON_FAIL: the reset writes the straight-line guess of mpc_reset_guess_interp */
 int mpc_closed_loop_step_dev(mpc_handle *h, int batch, double *d_x0, double *d_obst, const double *d_goal, double *d_X, double *d_U,
                              double *d_u0, double *d_cost, int32_t *d_status, int32_t *d_iters, const double *d_noise,
                              double randomness, double vmax, int flags, double *d_min_margin, int32_t *d_ep_flags,
                              int32_t *d_ep_steps, void *stream);
 int mpc_shift_dev(mpc_handle *h, int batch, double *d_X, double *d_U, void *stream);
 int mpc_reset_guess_dev(mpc_handle *h, int batch, const double *d_x0, double *d_X, double *d_U, void *stream);
+int mpc_reset_guess_interp_dev(mpc_handle *h, int batch, const double *d_x0, const double *d_goal, double *d_X, double *d_U, void *stream);
 int mpc_plant_step_dev(mpc_handle *h, int batch, const double *d_x, const double *d_u, double *d_xnext, void *stream);
 /* Obstacle.step() ground-truth motion (visualization.py:20-33); d_noise[B*n_obst][2] standard normals or NULL */
 int mpc_obstacle_step_dev(mpc_handle *h, int count, double *d_obst, const double *d_noise,

@@ -284,6 +284,20 @@ void orc_initial_guess(const orc_config *c, const double *x0, double *X, double 
     for (int i = 0; i < c->N * 2; i++) U[i] = 0;
 }
 
+/* robot_ocp_problem.py:293-300, the commented "straight line guess" -- the code behind the two interpolate_init tables of
+ * src/simulation/test_data: x_guess = x0_x + i/N (x0_x - x0_x), y_guess = x0_y + i/N (goal_y - x0_y), psi_guess = arctan2(goal_y - x0_y,
+ * goal_x - goal_x), v = omega = 0, u = 0 (the two self-differences are the reference's) */
+void orc_initial_guess_interp(const orc_config *c, const double *x0, const double *goal, double *X, double *U)
+{
+    const double dy = goal[1] - x0[1];
+    const double psi = atan2(dy, goal[0] - goal[0]);
+    for (int i = 0; i <= c->N; i++) {
+        const double f = (double)i / (double)c->N;
+        X[i * 5] = x0[0] + f * (x0[0] - x0[0]); X[i * 5 + 1] = x0[1] + f * dy; X[i * 5 + 2] = psi; X[i * 5 + 3] = 0; X[i * 5 + 4] = 0;
+    }
+    for (int i = 0; i < c->N * 2; i++) U[i] = 0;
+}
+
 /* robot_ocp_problem.py:253-258 */
 void orc_shift(const orc_config *c, double *X, double *U)
 {

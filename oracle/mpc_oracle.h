@@ -90,6 +90,7 @@ void orc_slack_alpha(const orc_config *c, const double *x0, const double *goal, 
 
 /* a13 / a12 */
 void orc_initial_guess(const orc_config *c, const double *x0, double *X, double *U);
+void orc_initial_guess_interp(const orc_config *c, const double *x0, const double *goal, double *X, double *U);   /* :293-300 (commented variant) */
 void orc_shift(const orc_config *c, double *X, double *U);
 
 /* linearisation products, for parity tests of the linearise stage:

@@ -82,6 +82,7 @@ def lib():
         L.orc_predict_params.argtypes = [cp, _dp, _dp]
         L.orc_slack_alpha.argtypes = [cp, _dp, _dp, _dp]
         L.orc_initial_guess.argtypes = [cp, _dp, _dp, _dp]
+        L.orc_initial_guess_interp.argtypes = [cp, _dp, _dp, _dp, _dp]
         L.orc_shift.argtypes = [cp, _dp, _dp]
         L.orc_linearize.argtypes = [cp] + [_dp] * 11
         L.orc_cost.argtypes = [cp] + [_dp] * 5
@@ -153,6 +154,13 @@ def slack_alpha(cfg, x0, goal):
 def initial_guess(cfg, x0):
     X, U = np.zeros((cfg.N + 1, 5)), np.zeros((cfg.N, 2))
     lib().orc_initial_guess(C.byref(cfg), _a(x0), X, U)
+    return X, U
+
+
+def initial_guess_interp(cfg, x0, goal):
+    """the commented straight-line guess of robot_ocp_problem.py:293-300 (interpolate_init tables)"""
+    X, U = np.zeros((cfg.N + 1, 5)), np.zeros((cfg.N, 2))
+    lib().orc_initial_guess_interp(C.byref(cfg), _a(x0), _a(goal), X, U)
     return X, U
 
 

@@ -1,0 +1,111 @@
+"""Which recorded rows does the replay NOT land on, and why?  
+
+For all ten recorded tables of the reference (src/simulation/test_data/20221031_*_experiment_data.csv -> tests/golden/reference_tables.json; the two
+`interpolate_init` tables with the straight-line initial guess of robot_ocp_problem.py:293-300) x 100 seeds, the GPU episode harness replays
+experiments.py:20-36 with the reference's own numpy streams and logs per episode: number of solves that ended with status 2 (QP at its iteration
+cap) and status 4 (QP failed -> set_initial_guess()), the first control step with a status != 0, and whether the row is reproduced (control-step
+count exact, flags equal, min_margin and dist_to_goal to 1e-3).  A seed that is NOT reproduced although every one of its solves converged on the
+GPU is then replayed on the CPU oracle: if the oracle's episode is clean as well and still misses the row, it is a parity defect of the
+specification (both sides agree with each other, not with acados); otherwise the difference lies in what happens after a non-converged QP, where
+nothing reference-held says what acados / HPIPM returned.
+
+usage (GPU box): python scripts/unmatched_rows.py        -> gpurun_out/r03_unmatched_rows.json (copy to profiles/)
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "dynamic-obstacle-avoidance-mpc_amd"), os.path.join(ROOT, "tests")]
+import numpy as np
+import mpc_gpu
+from mpc_gpu.world import reference_streams
+
+
+def matches(tb, rows):
+    di = np.abs(tb[:, 4] - rows[:, 4]); dm = np.abs(tb[:, 2] - rows[:, 2]); dd = np.abs(tb[:, 3] - rows[:, 3])
+    fl = (tb[:, 0] == rows[:, 0]) & (tb[:, 1] == rows[:, 1]) & (tb[:, 5] == rows[:, 5])
+    return (di == 0) & (dm <= 1e-3) & (dd <= 1e-3) & fl, (di == 0) & (dm <= 1e-6) & (dd <= 1e-6) & fl
+
+
+def oracle_episode(sp, seed, obst, noise, interp, alias):
+    from oracle import oracle as orc
+    from helpers import OracleLoop
+    cfg = orc.config(sp["N_SOLV"], 5, float(sp["TF"]), qp_tol=1e-8, qp_iter_max=sp["QP_ITER"])
+    lp = OracleLoop(orc, cfg, [-7.0, -7.0, np.pi / 4, 0, 0], [7.0, 7.0], obst[seed], reset_on_fail=True, alias=alias, interp=interp)
+    n2 = n4 = 0
+    for k in range(400):
+        r = lp.step(noise[k, seed])
+        if r is None:
+            break
+        n2 += r["status"] == 2; n4 += r["status"] == 4
+    return lp.row(), int(n2), int(n4)
+
+
+def main():
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_tables.json")))["tables"]
+    x0 = np.tile([-7.0, -7.0, np.pi / 4, 0, 0], (100, 1)); goal = np.tile([7.0, 7.0], (100, 1))
+    streams = {s: reference_streams(s, range(100), 5, 400) for s in ("RANDOM", "EDGE")}
+    out = {"protocol": "experiments.py:20-36 replayed per seed with the reference's numpy streams; match = control steps exact, flags equal, min_margin and "
+                       "dist_to_goal to 1e-3", "tables": {}}
+    tot = dict(rows=0, matched=0, matched_1e6=0, unmatched=0, unmatched_with_nonconverged_qp=0, unmatched_clean_on_gpu=0, unmatched_clean_on_both=0)
+    for stem, t in ref.items():
+        sp = t["spec"]; scen = sp["scenario"]; interp = bool(sp.get("interpolate_init"))
+        obst, noise = streams[scen]
+        rows = np.array(t["rows"])
+        best = None
+        for alias in ((True, False) if interp else (True,)):       # the straight-line block builds its guess afresh: whether the aliasing defect D2 was live then is not recorded
+            r = mpc_gpu.run_episodes(x0, goal, obst, N=sp["N_SOLV"], Tf=float(sp["TF"]), max_iter=400, random_move=True, init_guess_when_error=True,
+                                     noise=noise, qp_iter_max=sp["QP_ITER"], bug_compat_alias=alias, interpolate_init=interp, status_log=True)
+            m3, m6 = matches(r["table"], rows)
+            if best is None or m3.sum() > best[1].sum():
+                best = (alias, m3, m6, r)
+        alias, m3, m6, r = best
+        n2, n4, fb = r["status2"], r["status4"], r["first_bad"]
+        clean = (n2 == 0) & (n4 == 0)
+        rec = dict(spec=sp, bug_compat_alias=alias, matched=int(m3.sum()), matched_1e6=int(m6.sum()), matched_seeds=[int(s) for s in np.nonzero(m3)[0]],
+                   episodes_all_converged=int(clean.sum()), matched_and_all_converged=int((m3 & clean).sum()),
+                   matched_despite_nonconverged_qp=int((m3 & ~clean).sum()),
+                   unmatched=[dict(seed=int(s), status2=int(n2[s]), status4=int(n4[s]), first_bad_step=int(fb[s]), steps=int(r["table"][s, 4]),
+                                   recorded_steps=int(rows[s, 4])) for s in np.nonzero(~m3)[0]],
+                   statistics=dict(hit=float(r["table"][:, 0].mean()), reached=float(r["table"][:, 1].mean()), mean_iters=float(r["table"][:, 4].mean()),
+                                   oob=float(r["table"][:, 5].mean()), recorded={k: t[k] for k in ("hit", "reached", "mean_iters", "oob")}))
+        suspects = [int(s) for s in np.nonzero(~m3 & clean)[0]]
+        rec["unmatched_clean_on_gpu"] = suspects
+        both = []
+        for s in suspects:
+            row, o2, o4 = oracle_episode(sp, s, obst, noise, interp, alias)
+            same = abs(row[4] - r["table"][s, 4]) == 0 and abs(row[2] - r["table"][s, 2]) <= 1e-3
+            both.append(dict(seed=s, oracle_status2=o2, oracle_status4=o4, oracle_equals_gpu=bool(same), oracle_steps=int(row[4]), gpu_steps=int(r["table"][s, 4]),
+                             recorded_steps=int(rows[s, 4]), recorded_margin=float(rows[s, 2]), gpu_margin=float(r["table"][s, 2])))
+        rec["unmatched_clean_cross_check"] = both
+        out["tables"][stem] = rec
+        tot["rows"] += 100; tot["matched"] += int(m3.sum()); tot["matched_1e6"] += int(m6.sum()); tot["unmatched"] += int((~m3).sum())
+        tot["unmatched_with_nonconverged_qp"] += int((~m3 & ~clean).sum()); tot["unmatched_clean_on_gpu"] += len(suspects)
+        tot["unmatched_clean_on_both"] += sum(1 for b in both if b["oracle_status2"] == 0 and b["oracle_status4"] == 0)
+        print(stem, scen, "interp" if interp else "", f"alias={alias} matched {m3.sum()} (1e-6: {m6.sum()}), clean episodes {clean.sum()}, unmatched with a non-converged QP "
+              f"{(~m3 & ~clean).sum()}, unmatched although clean {len(suspects)}", flush=True)
+    out["total"] = tot
+    # What the recorded tables themselves say about acados' QPs: a seed whose rows AGREE between the runs recorded with QP_ITER 100, 50 (and 25) never ran
+    # into those caps -- acados' QP converged at every step of it; a seed whose rows differ between caps ran into one.  Replay matches per class:
+    T = {k: np.array(v["rows"]) for k, v in ref.items()}
+
+    def agree(a, b, tol):
+        return (T[a][:, 4] == T[b][:, 4]) & (np.abs(T[a][:, 2] - T[b][:, 2]) < tol) & (np.abs(T[a][:, 3] - T[b][:, 3]) < tol) & np.all(T[a][:, [0, 1, 5]] == T[b][:, [0, 1, 5]], axis=1)
+    out["recorded_rows_by_cap_agreement"] = {}
+    for scen, (a, b, c) in {"RANDOM": ("20221031_215846", "20221031_220735", "20221031_221343"), "EDGE": ("20221031_220136", "20221031_220939", "20221031_221613")}.items():
+        m = {k: np.isin(np.arange(100), out["tables"][k]["matched_seeds"]) for k in (a, b, c)}
+        for tol in (1e-3, 1e-6):
+            ab = agree(a, b, tol); abc = ab & agree(a, c, tol)
+            out["recorded_rows_by_cap_agreement"][f"{scen}_tol{tol:g}"] = dict(
+                agree_at_caps_100_50_25=int(abc.sum()), replay_matches_of_those=[int((m[k] & abc).sum()) for k in (a, b, c)],
+                agree_at_caps_100_50=int(ab.sum()), replay_matches_of_those_cap100_cap50=[int((m[a] & ab).sum()), int((m[b] & ab).sum())],
+                disagree_between_caps_100_50=int((~ab).sum()), replay_matches_of_those_cap100_cap50_=[int((m[a] & ~ab).sum()), int((m[b] & ~ab).sum())],
+                agree_100_50_but_replay_misses=[int(s_) for s_ in np.nonzero(ab & ~m[a])[0]])
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r03_unmatched_rows.json"), "w"), indent=1)
+    print(tot)
+
+
+if __name__ == "__main__":
+    main()

@@ -52,16 +52,20 @@ class OracleLoop:
     oracle's functions -- look-ahead, RTI solve, status-4 reset (with the aliasing defect D2 when alias=True), plant step, noisy
     obstacle motion, margin / arena / goal bookkeeping, warm-start shift.  Test infrastructure (checker for the fused GPU step)."""
 
-    def __init__(self, orc, cfg, x0, goal, obst, reset_on_fail=True, alias=True, randomness=0.1, vmax=2.0):
+    def __init__(self, orc, cfg, x0, goal, obst, reset_on_fail=True, alias=True, randomness=0.1, vmax=2.0, interp=False):
         self.orc, self.cfg = orc, cfg
         self.x = np.array(x0, dtype=np.float64); self.goal = np.array(goal, dtype=np.float64)
         self.obst = np.array(obst, dtype=np.float64)
         self.reset_on_fail, self.alias, self.randomness, self.vmax = reset_on_fail, alias, randomness, vmax
+        self.interp = interp                      # set_initial_guess() = the commented straight-line variant (:293-300)
         if alias:
             self.x[3:] = 0.0                      # set_initial_guess() at the start of step() zeroes v, omega through the alias (:301-302)
-        self.X, self.U = orc.initial_guess(cfg, self.x)
+        self.X, self.U = self.guess()
         self.min_margin, self.flags, self.steps = np.inf, 0, 0
         self.last = None
+
+    def guess(self):
+        return self.orc.initial_guess_interp(self.cfg, self.x, self.goal) if self.interp else self.orc.initial_guess(self.cfg, self.x)
 
     def step(self, noise=None):
         """one control step; returns the oracle's solve result"""
@@ -76,7 +80,7 @@ class OracleLoop:
         if r["status"] == 4 and self.reset_on_fail:
             if self.alias:
                 self.x[3:] = 0.0
-            self.X, self.U = orc.initial_guess(cfg, self.x)
+            self.X, self.U = self.guess()
         self.x = orc.dynamics(self.x, u, dt)[0]
         for j in range(cfg.n_obst):
             self.obst[j] = orc.obstacle_step(cfg, self.obst[j], dt, None if noise is None else noise[j], self.randomness, self.vmax)

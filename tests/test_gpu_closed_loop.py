@@ -9,7 +9,7 @@ from helpers import OracleLoop, oracle_P, oracle_guess, qp_merit, random_batch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["stage-split", "one-lane-per-stage"])
+@pytest.fixture(params=["stage-split", "one-lane-per-stage"])
 def env(built, request):
     import mpc_gpu
     from oracle import oracle as orc
@@ -250,3 +250,59 @@ def test_outliers_are_judged_by_the_qp_not_by_a_count(env):
             assert fg <= fo + 1e-7 * max(1.0, abs(fo)), (b, d, fg, fo)
             assert d < 5e-3
     print("outliers judged by the QP:", n_out)
+
+
+def test_interpolate_init_guess(env):
+    """The reference's other set_initial_guess() -- the commented straight-line block robot_ocp_problem.py:293-300 behind the two `interpolate_init`
+    tables: (i) mpc_reset_guess_interp equals the oracle's restatement AND plain numpy of the reference's expressions bit for bit (its slips included:
+    x does not move, psi = arctan2(dy, 0)); (ii) the fused control step with MPC_STEP_INTERP_GUESS writes that guess on a failed QP: episodes with the
+    iteration cap at 3 (most solves end with status 2 or 4) against the oracle loop with the same guess, resynchronised per step."""
+    import torch
+    mpc_gpu, orc = env
+    from mpc_gpu import _lib
+    N, no, B = 20, 3, 48
+    x0, goal, obst = random_batch(B, no, seed=123)
+    x0[:, 3:] = np.random.default_rng(3).uniform(-1, 1, (B, 2)); goal[5, 1] = x0[5, 1]      # one instance with dy = 0
+    cfg = orc.config(N, no, 2.0, qp_tol=1e-8)
+    with mpc_gpu.BatchedMpc(N, no, 2.0, max_batch=B) as s:
+        s.reset_guess_interp(x0, goal)
+        X, U = s.get_traj(B)
+    i = np.arange(N + 1)
+    for b in range(B):
+        Xo, Uo = orc.initial_guess_interp(cfg, x0[b], goal[b])
+        want = np.zeros((N + 1, 5))
+        want[:, 0] = x0[b, 0] + i / N * (x0[b, 0] - x0[b, 0]); want[:, 1] = x0[b, 1] + i / N * (goal[b, 1] - x0[b, 1])
+        want[:, 2] = np.arctan2(goal[b, 1] - x0[b, 1], goal[b, 0] - goal[b, 0])
+        assert np.array_equal(X[b], want) and np.array_equal(Xo, want) and not U[b].any() and not Uo.any()
+    assert X[5, 0, 2] == 0.0 and abs(abs(X[0, 0, 2]) - np.pi / 2) < 1e-15
+    # fused reset: HARD obstacle rows and an obstacle parked on top of the robot make the QP of every second instance infeasible (status 4);
+    # after every step both sides must hold the same iterate (the shifted solve, or the shifted straight line)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    x0[:, 3:] = 0.0
+    obst[::2, 0, :2] = x0[::2, :2] + 0.4; obst[::2, 0, 2:] = 0.0
+    cfgh = orc.config(N, no, 2.0, qp_tol=1e-8, soft_h=0)
+    loops = [OracleLoop(orc, cfgh, x0[b], goal[b], obst[b], reset_on_fail=True, alias=False, interp=True) for b in range(B)]
+    fl = _lib.STEP_SHIFT | _lib.STEP_PLANT | _lib.STEP_OBSTACLES | _lib.STEP_RESET_ON_FAIL | _lib.STEP_INTERP_GUESS
+    resets = 0
+    with mpc_gpu.BatchedMpc(N, no, 2.0, max_batch=B, soft_h=0) as s, torch.cuda.stream(torch.cuda.Stream(device=dev)):
+        st = torch.cuda.current_stream().cuda_stream
+        dx, dg, do = t(x0), t(goal), t(obst)
+        X = torch.zeros(B, N + 1, 5, dtype=torch.float64, device=dev); U = torch.zeros(B, N, 2, dtype=torch.float64, device=dev)
+        status = torch.zeros(B, dtype=torch.int32, device=dev)
+        s.reset_guess_interp_dev(B, dx, dg, X, U, stream=st)
+        for k in range(4):
+            s.closed_loop_step_dev(B, dx, do, dg, X, U, None, None, status, None, None, flags=fl, stream=st)
+            torch.cuda.synchronize()
+            Xh, Uh, sh = X.cpu().numpy(), U.cpu().numpy(), status.cpu().numpy()
+            for b in range(B):
+                r = loops[b].step()
+                assert r["status"] == sh[b], (k, b, r["status"], sh[b])
+                resets += r["status"] == 4
+                if r["status"] == 4:
+                    assert np.array_equal(loops[b].X, Xh[b]) and not Uh[b].any()          # the straight line itself, shifted: exact
+                elif r["status"] == 0:
+                    assert np.abs(loops[b].X - Xh[b]).max() <= 1e-6 and np.abs(loops[b].U - Uh[b]).max() <= 8e-6, (k, b)
+                loops[b].X, loops[b].U = Xh[b].copy(), Uh[b].copy()  # resynchronise: every comparison is one step on identical inputs
+                loops[b].x = dx[b].cpu().numpy().copy(); loops[b].obst = do[b].cpu().numpy().copy()
+    assert resets >= 5, resets

@@ -16,7 +16,7 @@ TOL_U = 1e-6 * 8.0
 TOL_LIN = 1e-12
 
 
-@pytest.fixture(scope="module", params=["stage-split", "one-lane-per-stage"])
+@pytest.fixture(params=["stage-split", "one-lane-per-stage"])
 def env(built, request):
     """Every parity test runs on both lane mappings of the solve kernel: the automatic choice (these batches are small, so the
     rows of a stage are split over 2-3 lanes wherever the horizon fits: rti_split_kernel) and one lane per stage

@@ -4,13 +4,16 @@ cannot run here.  Protocol: experiments.py:20-36 -- np.random.seed(i), scenario 
 obstacles, init_guess_when_error, at most 400 control steps; the obstacle noise is the reference's own numpy stream
 (mpc_gpu.world.reference_streams, plain numpy).  Columns: [hit, reached, min_margin, dist_to_goal, iters, out_of_bounds].
 
-What is asserted, and why these numbers (profiles/r02_seed_replay.json has the full scan over the 16 switch combinations):
-  * the seeds SURVEY.md section 4 lists as bit-stable across the recorded QP_ITER caps (acados' QP always converged, so the closed loop is
-    a function of the mathematical problem alone) reproduce the recorded row: control-step count EXACTLY, min_margin to 1e-4
-    (measured: <= 2e-8 RANDOM, <= 2.7e-6 EDGE after 100+ closed-loop steps), dist_to_goal to 1e-3 (measured <= 3.2e-4), all three flags;
-  * over all 100 seeds at least 40 rows are reproduced to 1e-3 with exact step counts (measured 48 / 55): the remainder contains an
-    acados QP that hit its cap or failed, where the recorded tables themselves disagree between caps (57 / 63 rows keep their step count
-    from QP_ITER 100 to 50);
+What is asserted, and why these numbers (profiles/r03_unmatched_rows.json: per table, per seed; profiles/r02_seed_replay.json: the scan over the 16
+switch combinations that selected the defaults):
+  * WHICH rows a converged solver can reproduce is read off the recorded tables themselves: a seed whose recorded rows agree between the runs taken
+    with QP_ITER 100, 50 and 25 never ran into those caps -- acados' QP converged at every one of its steps, so its closed loop is a function of the
+    mathematical problem alone.  Every such seed is reproduced (RANDOM 21 of 21, EDGE 20 of 20): control-step count EXACTLY, all three flags, min_margin
+    to 1e-4 (measured <= 2e-8 RANDOM, <= 2.7e-6 EDGE after 100+ closed-loop steps), dist_to_goal to 1e-3.  Of the seeds whose rows agree at caps 100 and
+    50, 41 of 48 (RANDOM) and 43 of 48 (EDGE) are reproduced -- at an agreement of 1e-6, EDGE 37 of 37; of the seeds whose recorded rows DIFFER between the
+    caps (acados truncated a QP: what it returned then is not reproducible by any converged solver) 7 and 12 of 52;
+  * per table, the number of reproduced rows is at least the measured number minus 2 (all ten tables, both lane mappings; the two `interpolate_init`
+    tables with the straight-line initial guess of robot_ocp_problem.py:293-300);
   * any other setting of the unverifiable acados-semantics switches reproduces NO row (checked for lm_scaled = 0 here).
 """
 import json
@@ -41,34 +44,59 @@ def row_match(tb, rows, tol):
     return flags & (tb[:, 4] == rows[:, 4]) & (np.abs(tb[:, 2] - rows[:, 2]) <= tol) & (np.abs(tb[:, 3] - rows[:, 3]) <= tol)
 
 
-@pytest.fixture(scope="module", params=["stage-split", "one-lane-per-stage"])
+@pytest.fixture(params=["stage-split", "one-lane-per-stage"])
 def mapping(built, request):
+    """function-scoped: the class attribute is restored behind every test, nothing leaks into other modules"""
     import mpc_gpu
     mpc_gpu.BatchedMpc.default_lanes_per_stage = 0 if request.param == "stage-split" else 1
     yield mpc_gpu
     mpc_gpu.BatchedMpc.default_lanes_per_stage = 0
 
 
-@pytest.mark.parametrize("stem", ["20221031_215846", "20221031_220136"])       # RANDOM / EDGE, TF = 2, N = 20, QP_ITER = 100
-def test_recorded_rows_are_reproduced_per_seed(mapping, stem):
-    tb, rows, scen = replay(mapping, stem)
-    st = STABLE[scen]
+def agree_between_caps(a, b, tol):
+    """seeds whose RECORDED rows agree between two tables taken with different QP_ITER caps"""
+    A, B = np.array(TABLES[a]["rows"]), np.array(TABLES[b]["rows"])
+    return (A[:, 4] == B[:, 4]) & (np.abs(A[:, 2] - B[:, 2]) < tol) & (np.abs(A[:, 3] - B[:, 3]) < tol) & np.all(A[:, [0, 1, 5]] == B[:, [0, 1, 5]], axis=1)
+
+
+CAPS = {"RANDOM": ("20221031_215846", "20221031_220735", "20221031_221343"), "EDGE": ("20221031_220136", "20221031_220939", "20221031_221613")}
+# rows reproduced to (1e-3, 1e-6) per table, the smaller of the two lane mappings (scripts/replay_counts.py on MI355X); asserted: these minus 2
+MEASURED = {"20221031_215846": (47, 35), "20221031_220136": (54, 30), "20221031_220735": (44, 35), "20221031_220939": (45, 28), "20221031_221343": (21, 14),
+            "20221031_221613": (20, 14), "20221031_224515": (54, 49), "20221031_224642": (54, 38), "20221031_225145": (30, 26), "20221031_225445": (37, 28)}
+
+
+@pytest.mark.parametrize("scen", ["RANDOM", "EDGE"])
+def test_recorded_rows_are_reproduced_per_seed(mapping, scen):
+    """TF = 2, N = 20, QP_ITER = 100: the seeds on which acados' QP provably converged (read off the recorded tables) come back exactly"""
+    c100, c50, c25 = CAPS[scen]
+    tb, rows, _ = replay(mapping, c100)
+    conv25 = agree_between_caps(c100, c50, 1e-3) & agree_between_caps(c100, c25, 1e-3)       # never ran into cap 25, 50 or 100
+    assert conv25.sum() >= 20 and set(STABLE[scen]) <= set(np.nonzero(conv25)[0].tolist())      # (SURVEY section 4's bit-stable seeds are among them)
+    st = np.nonzero(conv25)[0]
     assert np.array_equal(tb[st, 4], rows[st, 4]), (tb[st, 4], rows[st, 4])                 # control-step counts, exactly
     assert np.array_equal(tb[st][:, [0, 1, 5]], rows[st][:, [0, 1, 5]])                     # hit / reached / out of bounds
     assert np.abs(tb[st, 2] - rows[st, 2]).max() <= 1e-4 and np.abs(tb[st, 3] - rows[st, 3]).max() <= 1e-3      # measured 2.4e-6 / 3.2e-4
-    assert row_match(tb, rows, 1e-3).sum() >= 40
-    assert row_match(tb, rows, 1e-6).sum() >= 25
-    # statistics of the whole table stay in the recorded band (the unmatched rows are chaotic, not wrong)
-    assert abs(tb[:, 0].mean() - rows[:, 0].mean()) <= 0.12 and abs(tb[:, 1].mean() - rows[:, 1].mean()) <= 0.12
-    assert abs(tb[:, 4].mean() - rows[:, 4].mean()) <= 0.15 * rows[:, 4].mean()
+    m3 = row_match(tb, rows, 1e-3)
+    conv50 = agree_between_caps(c100, c50, 1e-3)
+    assert (m3 & conv50).sum() >= {"RANDOM": 41, "EDGE": 43}[scen] - 2                        # of 48: converged within 50 iterations everywhere
+    assert (m3 & ~conv50).sum() <= 20                                                         # of 52: a truncated QP somewhere (measured 7 / 12)
+    if scen == "EDGE":
+        strict = agree_between_caps(c100, c50, 1e-6)
+        assert strict.sum() == 37 and (m3 & strict).sum() >= 36                               # measured 37 of 37
+    # statistics of the whole table against the recorded ones (the unmatched rows are chaotic, not wrong): measured differences hit 0.04 / 0.05, reached
+    # 0.05 / 0.03, mean control steps 9 % / 4 % -- this interior point gives up on a hard QP more often than HPIPM did, which costs RANDOM 5 goals in 100
+    assert abs(tb[:, 0].mean() - rows[:, 0].mean()) <= 0.07 and abs(tb[:, 1].mean() - rows[:, 1].mean()) <= 0.07
+    assert abs(tb[:, 4].mean() - rows[:, 4].mean()) <= 0.12 * rows[:, 4].mean()
 
 
-def test_short_horizon_table_and_iteration_cap(mapping):
-    """TF = 1 / N = 10 / QP_ITER = 50 (20221031_224515) and the QP_ITER = 25 table of the long horizon (20221031_221343)"""
-    tb, rows, _ = replay(mapping, "20221031_224515")
-    assert row_match(tb, rows, 1e-3).sum() >= 45 and row_match(tb, rows, 1e-6).sum() >= 40           # measured 54 / 49
-    tb, rows, _ = replay(mapping, "20221031_221343")
-    assert row_match(tb, rows, 1e-3).sum() >= 15                                                      # measured 21 (cap 25 truncates often)
+@pytest.mark.parametrize("stem", sorted(MEASURED))
+def test_every_recorded_table(mapping, stem):
+    """all ten tables: TF 2 / N 20 at caps 100, 50, 25; TF 1 / N 10; and the two interpolate_init tables with the reference's straight-line guess
+    (robot_ocp_problem.py:293-300; that block builds the guess afresh, so the aliasing defect D2 of the committed code is off)"""
+    interp = bool(TABLES[stem]["spec"].get("interpolate_init"))
+    tb, rows, _ = replay(mapping, stem, **(dict(interpolate_init=True, bug_compat_alias=False) if interp else {}))
+    want3, want6 = MEASURED[stem]
+    assert row_match(tb, rows, 1e-3).sum() >= want3 - 2 and row_match(tb, rows, 1e-6).sum() >= want6 - 2
 
 
 def test_the_other_lm_semantics_reproduces_nothing(built):
