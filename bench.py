@@ -274,7 +274,7 @@ def cpu_baseline(N, n_obst, x0, goal, obst, budget_s=24.0):
     while time.perf_counter() - t0 < budget_s / 8 and n_py < 4 * EPISODE:
         loop.control_step(st); loop.shift_warm_start(); n_py += 1
     py_rate = n_py / (time.perf_counter() - t0)
-    return {"value": rates[best][0], "unit": "solves/s", "cores": best, "kind": "port",
+    return {"value": rates[best][0], "unit": "solves/s", "cores": best, "kind": "port", "host_cpu": orc._cpu_model(), "host_threads": ncpu,
             "one_thread": one, "python_call_pattern_one_thread": py_rate,
             "threads": {str(n): r[0] for n, r in rates.items()},
             "sample": f"first {S_all} scenarios x {rates[best][1]} closed-loop control steps (after 5 untimed) of the same workload, oracle "
@@ -322,12 +322,18 @@ def measure(torch, dist, loop, world, exch, steps, warmup, dev):
     kern_ms, launches = loop.m.profile_read()
     loop.m.profile_enable(False)
     loop.m.set_accumulators(None, None)
+    # what an event pair measures with NOTHING between its records, on the same stream (the figure a timed launch carries on top of its own duration)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+    for a, b in evs:
+        a.record(); b.record()
+    torch.cuda.synchronize()
+    pair_ms = sorted(a.elapsed_time(b) for a, b in evs)[len(evs) // 2]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     n = loop.B * steps * EPISODE
-    return dict(elapsed=elapsed, kern_ms=kern_ms, launches=launches, mean_iters=float(it_acc.double().sum().item()) / n,
+    return dict(elapsed=elapsed, kern_ms=kern_ms, launches=launches, pair_ms=pair_ms, steps=steps, mean_iters=float(it_acc.double().sum().item()) / n,
                 fail=float((st_acc % 65536).double().sum().item()) / n, cap=float((st_acc // 65536).double().sum().item()) / n)
 
 
@@ -336,7 +342,9 @@ def roofline(loop, N, no, r):
     Everything from THIS run: kernel time from HIP events on the launch stream, flops from the measured mean iteration count."""
     batch = loop.B
     kname = loop.m.kernel_name(batch)
-    avg_s = r["kern_ms"] / max(1, r["launches"]) * 1e-3
+    raw_s = r["kern_ms"] / max(1, r["launches"]) * 1e-3
+    avg_s = max(raw_s - r["pair_ms"] * 1e-3, 1e-9)          # event-bracketed duration minus what an empty bracket measures
+    wall_per_launch = r["elapsed"] / (r["steps"] * EPISODE)
     flops = algorithmic_flops_per_solve(N, no, r["mean_iters"]) * batch
     abytes = algorithmic_bytes_per_solve(N, no) * batch
     tr = measured_traffic(kname, batch)
@@ -345,8 +353,11 @@ def roofline(loop, N, no, r):
             "traffic": tr[0] if tr else None,
             "traffic_source": (f"HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE passes of this command, profiles/{tr[1]} "
                                "(FETCH_SIZE uncorrected: 8-byte-per-lane loads)") if tr else None,
-            "kernel": kname, "avg_launch_us": avg_s * 1e6, "launches_timed": r["launches"],
-            "launch_timing": f"HIP events on the launch stream around every {EVENT_EVERY}th launch of the timed region",
+            "kernel": kname, "avg_launch_us": avg_s * 1e6, "avg_launch_us_raw": raw_s * 1e6, "event_pair_overhead_us": r["pair_ms"] * 1e3,
+            "kernel_time_over_wall": avg_s / wall_per_launch, "launches_timed": r["launches"],
+            "launch_timing": (f"HIP events on the launch stream around every {EVENT_EVERY}th launch of the timed region, minus the duration an empty event pair "
+                              "measures on the same stream (median of 64); kernel_time_over_wall = that per-launch time / wall time per control step (one launch "
+                              "each): <= 1, the rest is launch gaps and the episode resets"),
             "algorithmic_flops_per_launch": flops, "mean_ipm_iters": r["mean_iters"],
             "flop_model": "SURVEY.md 8(d): N*200 + K*[N*(7/3 nx^3 + 4 nx^2 nu + 2 nx nu^2 + nu^3/3) + N*(2 (nx+nu)^2 + 6 n_ineq)], K = mean_ipm_iters of this run",
             "hbm": {"achieved": abytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / avg_s / 1e9 / HBM_PEAK_GBS,
@@ -434,11 +445,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20, help="timed episodes (100 control steps each)")
     ap.add_argument("--warmup", type=int, default=3, help="untimed episodes")
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c2 on one GPU (BASELINE configs[1], the configuration the metric is quoted on); with --gpus N > 1 the sharded "
+                         "global batch c4 (configs[3]: 262144 scenarios over the ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the supplementary C3, C5 and C1 measurements")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the multi-rank plumbing (gloo), no kernels")
     args = ap.parse_args()
+    if args.workload is None:
+        args.workload = "c4" if max(args.gpus, int(os.environ.get("WORLD_SIZE", "1"))) > 1 else "c2"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args, sys.argv[1:])
@@ -511,6 +526,8 @@ def main():
         out["extra"] = {"workload": d3, "value": G3 * EPISODE * 3 / r3["elapsed"], "unit": "solves/s", "steps": 3, "warmup": 1,
                         "ms_per_step": r3["elapsed"] / 3 * 1e3, "ms_per_control_step": r3["elapsed"] / (3 * EPISODE) * 1e3,
                         "mean_ipm_iters": r3["mean_iters"], "qp_failure_frac": r3["fail"], "roofline": roofline(l3, N, no, r3)}
+        out["value_throughput"] = out["extra"]["value"]
+        out["value_throughput_config"] = "C3 (BASELINE configs[2]): 65536 randomized scenarios on this GPU -- `value` is the latency-shaped C2 (1024 scenarios = one wavefront per SIMD); `extra` has the details"
         del l3
         # ... and the long-horizon configuration (configs[4]: N = 50, 10 obstacles, 32768 scenarios) on this one GPU, two episodes
         N5, no5 = WORKLOADS["c5"][:2]

@@ -192,6 +192,19 @@ def rti_solve(cfg, x0, P, goal, X, U, alpha=None):
     return dict(X=X, U=U, u0=u0, cost=float(cst[0]), status=int(st), iters=int(it[0]), kkt=kkt)
 
 
+def rti_solve_trace(cfg, x0, P, goal, X, U, alpha=None):
+    """rti_solve plus the per-iteration record (mu, sigma, alpha, largest complementarity product) of the interior point: (iters, 4)"""
+    buf = np.zeros((cfg.qp_iter_max + 2, 4))
+    lib().orc_set_trace.argtypes = [C.c_void_p, C.c_int]
+    lib().orc_set_trace(buf.ctypes.data, buf.shape[0])
+    try:
+        r = rti_solve(cfg, x0, P, goal, X, U, alpha=alpha)
+    finally:
+        lib().orc_set_trace(None, 0)
+    r["trace"] = buf[:max(r["iters"], 1)]
+    return r
+
+
 def rti_solve_batch(cfg, x0, P, goal, X, U, nthreads=0):
     B = x0.shape[0]
     X, U = _a(X).copy(), _a(U).copy()

@@ -47,6 +47,53 @@ def qp_merit(orc, cfg, x0, P, goal, X, U, Xn, Un):
     return float(f), eq, bnd
 
 
+def judge_against_oracle(orc, cfg, x0, P, goal, X0, U0, g, Xg, Ug, o, tol_x=1e-6, tol_u=8e-6, alpha=None):
+    """GPU result (g, Xg, Ug) against the oracle's (o) for one RTI step of a batch from the iterate (X0, U0), instance by instance -- no "at most k
+    instances may differ" clauses.  Per instance:
+      * the statuses are equal, or the difference is an at-the-cap borderline: both sides ran to the iteration cap or one short of it (one meets the
+        tolerance at iteration cap where the other is a rounding error above it; or the at-the-cap rule separates 2 from 4);
+      * status 4 leaves the iterate untouched;
+      * a converged instance (status 0 on both sides) is within the tolerance of the oracle -- or, where the QP is ill-conditioned at the float64 floor of an
+        interior point, it is judged by the QP itself (qp_merit): the GPU's step satisfies the linearised dynamics and the boxes to 1e-7 and its QP objective
+        does not exceed the oracle's;
+      * the iteration counts are equal, or they differ by at most 2 AND the oracle's own record shows the end-game: where the earlier side stopped, the
+        oracle's largest complementarity product was already within four decades of the tolerance (the last, superlinear iterations, where a rounding
+        difference decides whether the tolerance is met one iteration sooner).
+    Returns the numbers of instances that took each escape, for the caller to bound or report."""
+    B = x0.shape[0]
+    cap, tol = cfg.qp_iter_max, cfg.qp_tol
+    n = dict(status_borderline=0, judged_by_qp=0, iter_borderline=0, converged=0)
+    for b in range(B):
+        sg, so, ig, io = int(g["status"][b]), int(o["status"][b]), int(g["iters"][b]), int(o["iters"][b])
+        if sg != so:
+            assert min(ig, io) >= cap - 1, f"instance {b}: status {sg} (GPU, {ig} iterations) vs {so} (oracle, {io}) away from the iteration cap {cap}"
+            n["status_borderline"] += 1
+            continue
+        if so == 4:
+            assert np.array_equal(Xg[b], X0[b]) and np.array_equal(Ug[b], U0[b]), f"instance {b}: a failed QP must leave the iterate untouched"
+        if so != 0:
+            continue
+        n["converged"] += 1
+        dx, du = np.abs(Xg[b] - o["X"][b]).max(), np.abs(Ug[b] - o["U"][b]).max()
+        if dx > tol_x or du > tol_u:
+            al = None if alpha is None else alpha[b]
+            fg, eqg, bg = qp_merit(orc, cfg, x0[b], P[b], goal[b], X0[b], U0[b], Xg[b], Ug[b]) if al is None else (None, None, None)
+            assert al is None, f"instance {b}: |dX| {dx:.2e} beyond the tolerance with an explicit slack schedule (no QP export for it)"
+            fo, _, _ = qp_merit(orc, cfg, x0[b], P[b], goal[b], X0[b], U0[b], o["X"][b], o["U"][b])
+            assert eqg <= 1e-7 and bg <= 1e-7 and fg <= fo + 1e-7 * max(1.0, abs(fo)), f"instance {b}: |dX| {dx:.2e}, QP objective {fg} vs oracle {fo}, eq {eqg:.1e}, box {bg:.1e}"
+            n["judged_by_qp"] += 1
+        else:
+            assert abs(g["cost"][b] - o["cost"][b]) <= 1e-8 * max(1.0, abs(o["cost"][b])), (b, g["cost"][b], o["cost"][b])
+            assert np.abs(g["u0"][b] - o["u0"][b]).max() <= tol_u
+        if ig != io:
+            assert abs(ig - io) <= 2, f"instance {b}: {ig} (GPU) vs {io} (oracle) interior-point iterations"
+            tr = orc.rti_solve_trace(cfg, x0[b], P[b], goal[b], X0[b], U0[b], alpha=None if alpha is None else alpha[b])["trace"]
+            m = min(ig, io)
+            assert m >= 1 and tr[min(m, len(tr) - 1), 3] <= 1e4 * tol, f"instance {b}: iteration counts {ig} / {io} differ away from the end-game (oracle cmax {tr[min(m, len(tr) - 1), 3]:.2e} at iteration {m})"
+            n["iter_borderline"] += 1
+    return n
+
+
 class OracleLoop:
     """Oracle-side closed loop of ONE instance: the body of RobotOcpProblem.step (robot_ocp_problem.py:184-260) spelled out on the
     oracle's functions -- look-ahead, RTI solve, status-4 reset (with the aliasing defect D2 when alias=True), plant step, noisy

@@ -259,6 +259,32 @@ def test_visualisation_inputs_match_the_shim_loop(env):
 
 
 @pytest.mark.gpu
+def test_visualisation_inputs_against_the_oracle_loop(env):
+    """the same arrays against an INDEPENDENT closed loop: OracleLoop (tests/helpers.py, the body of RobotOcpProblem.step on the CPU oracle's functions) records
+    the plant trajectory, every solved horizon and the obstacle tracks of a noise-free scenario; what visualisation_inputs() re-assembles from the GPU's recorded
+    batch must equal them to the closed-loop parity tolerance (the shim-driven loop of the test above runs on the same HIP kernels as the harness)"""
+    from helpers import OracleLoop
+    mpc_gpu, orc = env
+    x0 = np.array([-6.0, -6.0, np.pi / 4, 0, 0]); goal = np.array([6.0, 6.0])
+    obst = np.array([[0.5, 0.5, 0.4, -0.3], [-3.0, 2.0, 0.5, 0.5], [3.0, -2.0, -0.6, 0.2]])
+    steps = 40
+    rec = mpc_gpu.run_episodes(x0[None], goal[None], obst[None], N=20, Tf=2.0, max_iter=steps, random_move=False, record=True)
+    vis = mpc_gpu.visualisation_inputs(rec, 0, steps=steps)
+    cfg = orc.config(20, 3, 2.0, qp_tol=1e-8)
+    lp = OracleLoop(orc, cfg, x0, goal, obst, reset_on_fail=True, alias=True)
+    traj, horizons, tracks = [lp.x[:2].copy()], [np.zeros((21, 2))], [lp.obst[:, :2].copy()]
+    for k in range(steps):
+        r = lp.step()
+        assert r["status"] == 0
+        traj.append(lp.x[:2].copy()); horizons.append(r["X"][:, :2].copy()); tracks.append(lp.obst[:, :2].copy())
+    assert vis["trajectory"].shape == (2, steps + 1) and vis["pred"].shape == (steps + 1, 21, 2)
+    assert np.abs(vis["trajectory"] - np.array(traj).T).max() < 1e-6
+    assert np.abs(vis["pred"] - np.array(horizons)).max() < 2e-6
+    for j in range(3):
+        assert np.abs(vis["obstacles"][j] - np.array(tracks)[:, j].T).max() < 1e-12
+
+
+@pytest.mark.gpu
 def test_packed_small_batch_transfer_equals_the_general_host_path(env):
     """Host-pointer solves of up to 64 instances travel as one pinned block each way with the look-ahead computed in the solve kernel
     (mpc_api.hip::solve_common); larger batches take separate copies.  Same instances, same kernel -> bit-identical outputs, for obstacle
