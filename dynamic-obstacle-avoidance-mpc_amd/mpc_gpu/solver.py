@@ -34,6 +34,7 @@ class BatchedMpc:
     default_lanes_per_stage = int(os.environ.get("MPC_LANES_PER_STAGE", "0"))
     default_waves_per_simd = int(os.environ.get("MPC_WAVES_PER_SIMD", "0"))
     default_lanes_per_instance = int(os.environ.get("MPC_LANES_PER_INSTANCE", "0"))
+    default_matrix_cores = int(os.environ.get("MPC_MATRIX_CORES", "0"))      # 1: the v_mfma_f64_16x16x4 Riccati sweep (evidence path, one instance per wavefront)
 
     def __init__(self, N=20, n_obst=3, Tf=2.0, max_batch=1, device=0, **cfg_overrides):
         self.cfg = _lib.default_config(N, n_obst, Tf, **cfg_overrides)
@@ -49,6 +50,10 @@ class BatchedMpc:
             _lib.check(_lib.lib().mpc_set_waves_per_simd(self._h, int(BatchedMpc.default_waves_per_simd)))
         if BatchedMpc.default_lanes_per_instance:
             _lib.check(_lib.lib().mpc_set_lanes_per_instance(self._h, int(BatchedMpc.default_lanes_per_instance)))
+        if BatchedMpc.default_matrix_cores:
+            _lib.check(_lib.lib().mpc_set_lanes_per_stage(self._h, 1))
+            _lib.check(_lib.lib().mpc_set_lanes_per_instance(self._h, 64))
+            _lib.check(_lib.lib().mpc_set_matrix_cores(self._h, 1))
 
     # ------------------------------------------------------------------ lifetime
     def close(self):

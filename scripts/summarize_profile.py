@@ -38,6 +38,20 @@ if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CYCLES" in c and "SQ_WAVE_CYCLES" in 
     d["valu_active_fraction_of_wave_cycles"] = c["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / c["SQ_WAVE_CYCLES"]["mean_per_launch"]
 if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c:
     d["valu_instructions_per_wave"] = c["SQ_INSTS_VALU"]["mean_per_launch"] / c["SQ_WAVES"]["mean_per_launch"]
+if "SQ_VALU_MFMA_BUSY_CYCLES" in c and summary.get("kernel_stats"):
+    # SQ_VALU_MFMA_BUSY_CYCLES counts cycles (MI355X_MICROARCH.md: 64 per v_mfma_f64_16x16x4, 16 per v_mfma_f64_4x4x4_4b -- checked against SQ_INSTS_MFMA),
+    # summed over the SIMDs the launch ran on; utilisation = that / (SIMDs x kernel duration in cycles at the 2.4 GHz nominal clock)
+    simds = 1024
+    d["mfma_busy_cycles_per_simd"] = c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / simds
+    d["mfma_busy_fraction_of_kernel_time"] = d["mfma_busy_cycles_per_simd"] / (summary["kernel_stats"]["avg_ns"] * 2.4)
+    if "SQ_INSTS_MFMA" in c and c["SQ_INSTS_MFMA"]["mean_per_launch"]:
+        d["mfma_busy_cycles_per_mfma_instruction"] = c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / c["SQ_INSTS_MFMA"]["mean_per_launch"]
+if "SQ_INSTS_VALU_MFMA_MOPS_F64" in c and summary.get("kernel_stats"):
+    # one MOPS count = 512 floating-point operations (rocprofv3 counter definition); rate against the FP64 matrix peak of 78.6 TFLOP/s
+    flops = 512.0 * c["SQ_INSTS_VALU_MFMA_MOPS_F64"]["mean_per_launch"]
+    d["mfma_f64_flops_per_launch"] = flops
+    d["mfma_f64_tflops"] = flops / summary["kernel_stats"]["avg_ns"] * 1e-3
+    d["mfma_f64_fraction_of_peak_78.6"] = d["mfma_f64_tflops"] / 78.6
 summary["derived"] = d
 json.dump(summary, open(os.path.join(root, f"{tag}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps({"kernel": summary["kernel"], "stats": summary["kernel_stats"], "derived": d, "counters": sorted(c)}, indent=1))
