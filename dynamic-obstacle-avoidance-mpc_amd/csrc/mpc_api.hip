@@ -41,6 +41,7 @@ struct mpc_handle {
     int lanes_override;
     int use_mfma;                     // matrix-core Riccati factorisation when one instance per wavefront is chosen
     int row_parallel;                 // row-parallel (64-bit DPP) Riccati factorisation instead of the one-lane systolic sweep
+    int block2;                       // stage recursions on pairs of stages where the mapping has them (mpc_set_block_riccati; default off)
     int split_override;               // lanes per horizon stage: 0 automatic, 1 one lane per stage, 2 / 3 split kernel (mpc_set_lanes_per_stage)
     int waves_override;               // wavefronts per SIMD of the split kernel: 0 automatic, 1, 2 (mpc_set_waves_per_simd)
     int simd_count;                   // SIMDs of the device (4 per compute unit)
@@ -184,13 +185,19 @@ int grant_lds(K kernel, int (&granted)[kMaxDevices], int device, size_t lds)
     return MPC_OK;
 }
 
-template <int NO, int LPS, bool W2, bool MASKED = false>
+// Block-2 (partially condensed) stage recursions: the stage-split mapping on dense blocks, even horizons, all rows of the kernel's capacity in use
+bool use_block2(const mpc_handle *h, bool w2, bool masked) { return h->block2 && !w2 && !masked && (h->cfg.N % 2 == 0) && h->cfg.N >= 4; }
+
+template <int NO, int LPS, bool W2, bool MASKED = false, bool BLK2 = false>
 int launch_split_w(mpc_handle *h, const mpc::KParams &p, hipStream_t s)
 {
+    if constexpr (!BLK2 && !W2 && !MASKED) {
+        if (use_block2(h, W2, MASKED)) return launch_split_w<NO, LPS, W2, MASKED, true>(h, p, s);
+    }
     static int granted[kMaxDevices] = {};
-    const size_t lds = (size_t)mpc::SplitLds<LPS, NO, W2>::total(p.N, p.obst != nullptr) * sizeof(double);
-    int rc = grant_lds(&mpc::rti_split_kernel<NO, LPS, W2, MASKED>, granted, h->device, lds); if (rc) return rc;
-    hipLaunchKernelGGL((mpc::rti_split_kernel<NO, LPS, W2, MASKED>), dim3(p.batch), dim3(64), lds, s, p);
+    const size_t lds = (size_t)mpc::SplitLds<LPS, NO, W2, BLK2>::total(p.N, p.obst != nullptr) * sizeof(double);
+    int rc = grant_lds(&mpc::rti_split_kernel<NO, LPS, W2, MASKED, BLK2>, granted, h->device, lds); if (rc) return rc;
+    hipLaunchKernelGGL((mpc::rti_split_kernel<NO, LPS, W2, MASKED, BLK2>), dim3(p.batch), dim3(64), lds, s, p);
     return MPC_OK;
 }
 
@@ -423,7 +430,7 @@ int mpc_create(const mpc_config *cfg, int device, int max_batch, mpc_handle **ou
     HIPCHK(hipSetDevice(device));
     mpc_handle *h = new mpc_handle();     // value-initialised: every pointer null, so mpc_destroy can release a half-built handle
     h->cfg = *cfg; h->device = device; h->max_batch = max_batch;
-    h->row_parallel = 1; h->scheduling = 1;
+    h->row_parallel = 1; h->scheduling = 1; h->block2 = 0;      // block-2 recursions: built, parity-tested, measured 5 % slower at C2 -> opt-in
     int rc = create_resources(h);
     if (rc) { mpc_destroy(h); return rc; }     // (mpc_destroy leaves g_err alone when nothing fails inside it)
     *out = h;
@@ -863,6 +870,13 @@ int mpc_set_row_parallel(mpc_handle *h, int on)
     return MPC_OK;
 }
 
+int mpc_set_block_riccati(mpc_handle *h, int on)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    h->block2 = on ? 1 : 0;
+    return MPC_OK;
+}
+
 int mpc_get_lanes_per_instance(mpc_handle *h, int batch)
 {
     if (!h) return fail(MPC_ERR_ARG, "null handle");
@@ -910,7 +924,10 @@ int mpc_get_kernel_name(mpc_handle *h, int batch, int lookahead, char *buf, int 
     const SolvePlan q = plan_solve(h, batch, lookahead != 0);
     const int cap = row_capacity(h->cfg.n_obst);
     const char *masked = partial_rows(h) ? "true" : "false";      // (all template arguments, as rocprofv3 prints the instantiation)
-    if (q.lps > 1) snprintf(buf, (size_t)len, "rti_split_kernel<%d, %d, %s, %s>", cap, q.lps, (q.waves == 2 && !partial_rows(h)) ? "true" : "false", masked);
+    if (q.lps > 1) {
+        const bool w2 = q.waves == 2 && !partial_rows(h);
+        snprintf(buf, (size_t)len, "rti_split_kernel<%d, %d, %s, %s, %s>", cap, q.lps, w2 ? "true" : "false", masked, use_block2(h, w2, partial_rows(h)) ? "true" : "false");
+    }
     else snprintf(buf, (size_t)len, "rti_solve_kernel<%d, %d, %d, %s>", cap, q.G, q.fact, masked);
     return MPC_OK;
 }

@@ -730,6 +730,216 @@ __device__ __forceinline__ void rowpar_factor(int lane, int N, const LT L, bool 
     if (t == 0) { stepT(Wa, Pb, T); stepM(0, Wa, Ha, T, Pa); }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// BLOCK-2 (PARTIALLY CONDENSED) RICCATI FACTORISATION.  The stage recursions are sequential in the stage index and a lone wavefront is bound by the
+// length of its instruction stream, so the horizon is solved in PAIRS of stages: block m = stages a = 2m and b = 2m + 1, state x_a, inputs (u_a, u_b);
+// x_b = A_a x_a + B_a u_a + b_a is eliminated (HPIPM's own partial condensing is this idea):
+//     dynamics   x_{a+2} = A^ x_a + B^ (u_a, u_b) + b^,    A^ = A_b A_a,  B^ = [A_b B_a, B_b],  b^ = A_b b_a + b_b
+//     cost       H^ = H~_a (embedded) + V' H~_b V,         V = [A_a b_a B_a 0; 0 1 0 0; 0 0 0 I]   (assembled lane-parallel by the lanes that own the odd stages)
+// in homogeneous coordinates z^ = (x[5], 1, u_a[2], u_b[2]): 10 columns in lanes 0..9 of a 16-lane DPP row.  Same chain per block as rowpar_factor per stage --
+// T = P~ W^ (30 DPP FMAs), M~ = H^ + W^' T (32), Muu 4 x 4 -> L D L' in every lane, K^ = -Muu^-1 M~[u, :] by substitution, P~+ = M~xx + M~xu K^ (24) --
+// ~170 vector instructions for two stages instead of 2 x 112, 15 LDS instructions instead of 26, and the three vector recursions run over N / 2 blocks.
+// Pivot order u_b, u_a (what the stage-by-stage recursion does implicitly: the later input first).
+// ------------------------------------------------------------------------------------------------------------------
+struct Blk2Lds {
+    static constexpr int WS = 51, HS = 101;          // W^ rows 0..4 x 10 columns; H^ 10 x 10 row-major (symmetric: lane j reads ROW j as its column), odd strides
+    static constexpr int RS = RowLds::HS;            // result blocks: the layout and stride of the dense stage blocks, so that the vector sweeps are the same code
+    static constexpr int KROW = 8;                   // K^[u][j] at [u * 8 + j] (u < 4, j < 6: gains and feed-forward), L D L' factors at [FAC .. FAC + 9]
+    static constexpr int FAC = 32;                   // 1/d0 1/d1 1/d2 1/d3 l10 l20 l30 l21 l31 l32
+    static constexpr int DEAD = 48;                  // dead-store word of idle lanes (beyond everything the vector sweeps use: RowVec 0..44)
+    static __host__ __device__ constexpr int blocks(int N) { return N / 2; }
+    static __host__ __device__ constexpr int pad_front() { return HS; }                                  // the factor sweep requests one block ahead of block 0
+    static __host__ __device__ constexpr int pad_rear() { return RowLds::AHEAD * RS; }                   // the vector sweeps request three blocks ahead
+    // W^ blocks | pad | H^ blocks (M + 1: the terminal cost-to-go starts from H~aug_N) | result blocks (M + 1) | pad | per-stage [A b B] rows 0, 1 (16 words, N stages)
+    static __host__ __device__ constexpr int total(int N) { return WS * blocks(N) + pad_front() + HS * (blocks(N) + 1) + RS * (blocks(N) + 1) + pad_rear() + 16 * N; }
+    double *W, *H, *R, *S;
+    __device__ __forceinline__ Blk2Lds(double *base, int N)
+        : W(base + pad_front()), H(base + pad_front() + WS * blocks(N)), R(H + HS * (blocks(N) + 1)), S(R + RS * (blocks(N) + 1) + pad_rear()) {}
+};
+
+__device__ __forceinline__ void rowpar_factor2(int lane, int M, const Blk2Lds L, bool worker_row)
+{
+    constexpr int WS = Blk2Lds::WS, HS = Blk2Lds::HS, RS = Blk2Lds::RS;
+    const int l15 = lane & 15, j = l15 < 10 ? l15 : 9;      // column; lanes 10..15 of a row shadow column 9 and store nothing
+    const bool storeK = worker_row && l15 < 6, store0 = worker_row && l15 == 0;
+    const double d5 = (j == 5) ? 1.0 : 0.0;
+    double *kp = L.R + (storeK ? j : Blk2Lds::DEAD), *fp = L.R + (store0 ? Blk2Lds::FAC : Blk2Lds::DEAD);
+    const double *wp = L.W + j, *hp = L.H + 10 * j;
+    auto fetch = [&](int m, double Wc[5], double Hc[10]) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) Wc[k] = wp[WS * m + 10 * k];
+#pragma unroll
+        for (int i = 0; i < 10; i++) Hc[i] = hp[HS * m + i];
+    };
+    // T = P~ W^ : rows 0..5 (exactly stepT of rowpar_factor; the 10 columns are a matter of which lanes hold operands)
+    auto stepT = [&](const double Wc[5], const double Pc[6], double T[6]) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) T[r] = Pc[r] * d5;
+        asm volatile(
+            "s_nop 1\n"
+            "v_fmac_f64_dpp %0, %6, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %6, %12 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %6, %12 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %6, %12 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %6, %12 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %6, %12 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %0, %6, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %7, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %7, %13 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %7, %13 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %7, %13 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %7, %13 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %0, %6, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %7, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %8, %14 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %8, %14 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %8, %14 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %8, %14 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %0, %6, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %7, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %8, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %9, %15 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %9, %15 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %9, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %0, %6, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %7, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %8, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %9, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %10, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %10, %16 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5])
+            : "v"(Pc[0]), "v"(Pc[1]), "v"(Pc[2]), "v"(Pc[3]), "v"(Pc[4]), "v"(Pc[5]), "v"(Wc[0]), "v"(Wc[1]), "v"(Wc[2]), "v"(Wc[3]), "v"(Wc[4]));
+    };
+    // M~ = H^ + W^' T, input rows 6..9 first; structural zeros of W^ = [A^ b^ B^] skipped:
+    //   row 0 of W^: columns 0, 2..9      row 1: columns 1..9      row 2: columns 2, 4, 5, 7, 9      row 3: columns 3, 5, 6, 8      row 4: columns 4, 5, 7, 9
+    auto stepM = [&](int m, const double Wc[5], const double Hc[10], const double T[6], double M[10]) {
+        asm volatile("v_mov_b64_e32 %0, %10\nv_mov_b64_e32 %1, %11\nv_mov_b64_e32 %2, %12\nv_mov_b64_e32 %3, %13\nv_mov_b64_e32 %4, %14\n"
+                     "v_mov_b64_e32 %5, %15\nv_mov_b64_e32 %6, %16\nv_mov_b64_e32 %7, %17\nv_mov_b64_e32 %8, %18\nv_mov_b64_e32 %9, %19\n"
+                     : "=&v"(M[0]), "=&v"(M[1]), "=&v"(M[2]), "=&v"(M[3]), "=&v"(M[4]), "=&v"(M[5]), "=&v"(M[6]), "=&v"(M[7]), "=&v"(M[8]), "=&v"(M[9])
+                     : "v"(Hc[0]), "v"(Hc[1]), "v"(Hc[2]), "v"(Hc[3]), "v"(Hc[4]), "v"(Hc[5]), "v"(Hc[6]), "v"(Hc[7]), "v"(Hc[8]), "v"(Hc[9]));
+        // rows 6..9 (the input block and what the factorisation needs first)
+        asm volatile(
+            "s_nop 1\n"
+            "v_fmac_f64_dpp %0, %4, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %4, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %4, %9 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %4, %9 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %0, %5, %10 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %5, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %5, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %5, %10 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %6, %11 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %6, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %0, %7, %12 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %7, %12 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %8, %13 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %8, %13 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+            : "+v"(M[6]), "+v"(M[7]), "+v"(M[8]), "+v"(M[9])
+            : "v"(Wc[0]), "v"(Wc[1]), "v"(Wc[2]), "v"(Wc[3]), "v"(Wc[4]), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]), "v"(T[4]));
+        // Muu (rows / columns 6..9) to every lane: m[p][q] = M~[6 + p][6 + q], q >= p, is lane (6 + q)'s register (6 + p)
+        double m66, m67, m68, m69, m77, m78, m79, m88, m89, m99;
+        asm volatile(
+            "s_nop 1\n"
+            "v_mov_b64_dpp %0, %10 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+            "v_mov_b64_dpp %1, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+            "v_mov_b64_dpp %2, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+            "v_mov_b64_dpp %3, %10 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+            "v_mov_b64_dpp %4, %11 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+            "v_mov_b64_dpp %5, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+            "v_mov_b64_dpp %6, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+            "v_mov_b64_dpp %7, %12 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+            "v_mov_b64_dpp %8, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+            "v_mov_b64_dpp %9, %13 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+            : "=&v"(m66), "=&v"(m67), "=&v"(m68), "=&v"(m69), "=&v"(m77), "=&v"(m78), "=&v"(m79), "=&v"(m88), "=&v"(m89), "=&v"(m99)
+            : "v"(M[6]), "v"(M[7]), "v"(M[8]), "v"(M[9]));
+        // rows 0..5 of M~ (independent of the factorisation below: the scheduler interleaves them with its reciprocal chains)
+        asm volatile(
+            "s_nop 1\n"
+            "v_fmac_f64_dpp %0, %6, %11 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %6, %11 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %6, %11 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %6, %11 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %6, %11 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %7, %12 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %7, %12 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %7, %12 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %7, %12 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %7, %12 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %8, %13 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %8, %13 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %8, %13 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %9, %14 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %9, %14 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %10, %15 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %10, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            : "+v"(M[0]), "+v"(M[1]), "+v"(M[2]), "+v"(M[3]), "+v"(M[4]), "+v"(M[5])
+            : "v"(Wc[0]), "v"(Wc[1]), "v"(Wc[2]), "v"(Wc[3]), "v"(Wc[4]), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]), "v"(T[4]));
+        M[5] += T[5];                                                  // row 5 of W^~ is e_5'
+        // L D L' of Muu in the pivot order u_b (rows 8, 9), u_a (rows 6, 7): p = (8, 9, 6, 7).  a[r][c] = Muu[p_r][p_c]
+        const double a00 = m88, a10 = m89, a20 = m68, a30 = m78, a11 = m99, a21 = m69, a31 = m79, a22 = m66, a32 = m67, a33 = m77;
+        const double i0 = rcp_nr(a00);
+        const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+        const double d1 = fma(-l10, a10, a11), t21 = fma(-l20, a10, a21), t31 = fma(-l30, a10, a31);
+        const double i1 = rcp_nr(d1);
+        const double l21 = t21 * i1, l31 = t31 * i1;
+        const double d2 = fma(-l21, t21, fma(-l20, a20, a22)), t32 = fma(-l31, t21, fma(-l30, a20, a32));
+        const double i2 = rcp_nr(d2);
+        const double l32 = t32 * i2;
+        const double d3 = fma(-l32, t32, fma(-l31, t31, fma(-l30, a30, a33)));
+        const double i3 = rcp_nr(d3);
+        // column j of K^ = -Muu^-1 M~[u, j]: forward, scale, backward substitution in the pivot order; K^ rows are stored in the ORIGINAL order (u_a, u_b)
+        const double y0 = M[8], y1 = fma(-l10, y0, M[9]), y2 = fma(-l21, y1, fma(-l20, y0, M[6])), y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, M[7])));
+        const double k3 = -(y3 * i3);
+        const double k2 = fma(-l32, k3, -(y2 * i2));
+        const double k1 = fma(-l31, k3, fma(-l21, k2, -(y1 * i1)));
+        const double k0 = fma(-l30, k3, fma(-l20, k2, fma(-l10, k1, -(y0 * i0))));
+        const double K6 = k2, K7 = k3, K8 = k0, K9 = k1;                // original rows 6, 7 (u_a), 8, 9 (u_b)
+        double *kb = kp + RS * m, *fb = fp + RS * m;
+        kb[0] = K6; kb[8] = K7; kb[16] = K8; kb[24] = K9;
+        fb[0] = i0; fb[1] = i1; fb[2] = i2; fb[3] = i3; fb[4] = l10; fb[5] = l20; fb[6] = l30; fb[7] = l21; fb[8] = l31; fb[9] = l32;
+        // P~+ = M~[0..5][0..5] + M~[0..5][u] K^   (M~[i][6 + u] = M~[6 + u][i] is lane i's register 6 + u)
+        asm volatile(
+            "s_nop 1\n"
+            "v_fmac_f64_dpp %0, %6, %10 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %6, %10 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %6, %10 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %6, %10 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %6, %10 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %6, %10 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %0, %7, %11 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %7, %11 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %7, %11 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %7, %11 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %7, %11 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %7, %11 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %0, %8, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %8, %12 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %8, %12 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %8, %12 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %8, %12 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %8, %12 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %0, %9, %13 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %1, %9, %13 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %2, %9, %13 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %3, %9, %13 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %4, %9, %13 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+            "v_fmac_f64_dpp %5, %9, %13 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+            : "+v"(M[0]), "+v"(M[1]), "+v"(M[2]), "+v"(M[3]), "+v"(M[4]), "+v"(M[5])
+            : "v"(M[6]), "v"(M[7]), "v"(M[8]), "v"(M[9]), "v"(K6), "v"(K7), "v"(K8), "v"(K9));
+    };
+    double Wa[5], Ha[10], Wb[5], Hb[10], Pa[10], Pb[10], T[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) Pb[r] = hp[HS * M + r];              // P~_N = H~aug_N[0..5][0..5] (terminal block: row j, entries 0..5)
+    fetch(M - 1, Wa, Ha);
+    asm volatile("s_nop 4");
+    int m = M - 1;
+    for (; m >= 1; m -= 2) {
+        stepT(Wa, Pb, T); fetch(m - 1, Wb, Hb); stepM(m, Wa, Ha, T, Pa);
+        stepT(Wb, Pa, T); fetch(m - 2, Wa, Ha); stepM(m - 1, Wb, Hb, T, Pb);      // m - 2 = -1 reads the (dead) padding in front
+    }
+    if (m == 0) { stepT(Wa, Pb, T); stepM(0, Wa, Ha, T, Pa); }
+}
+
 // THE SAME SWEEP AS ONE ASM BLOCK (rowpar_factor_fast; text generated from the three blocks above, identical arithmetic and results).
 // What it saves per stage: the eight accumulator copies (the H~aug column is requested straight INTO the accumulator registers -- inside
 // one block no compiler can touch a register with a load in flight), four address updates, and every wait is counted exactly

@@ -27,7 +27,7 @@ namespace mpc {
 // W2 = true: TWO WAVEFRONTS PER SIMD for batches that are many rounds of wavefronts deep: compact stage blocks (RowLdsC), results
 //   overlaying the consumed H~aug blocks (so every operand word is restaged per iteration) and the look-ahead staged in the same region:
 //   14.7 KB per wavefront at N = 20, eight wavefronts per CU; the register allocator is held to 256 registers per lane.
-template <int LPS, int NOBST, bool W2 = false>
+template <int LPS, int NOBST, bool W2 = false, bool BLK2 = false>
 struct SplitLds {
     using LT = typename std::conditional<W2, RowLdsC, RowLds>::type;
     static constexpr int NBL = 6 / LPS;                       // box variables per lane
@@ -35,6 +35,7 @@ struct SplitLds {
     static __host__ __device__ constexpr int results(int N) { return W2 ? 0 : (N + 1) * RowLds::HS; }     // result blocks of the sweeps, apart from the H~aug blocks
     static __host__ __device__ constexpr int total(int N, bool lookahead)
     {
+        if (BLK2) return Blk2Lds::total(N) + (lookahead ? (N + 1) * NOBST * 2 : 0);
         return LT::total(N, 1) + results(N) + ((lookahead && !W2) ? (N + 1) * NOBST * 2 : 0);
     }
 };
@@ -55,11 +56,13 @@ __device__ __forceinline__ double nth_of_six(double a0, double a1, double a2, do
 #endif
 // MASKED: fewer obstacles than row pairs (p.n_obst < NOBST, see rti_solve_kernel): a template flag, because with the count known at compile time
 // the per-slot row flags fold into the stage flags (measured: the run-time count costs 1 % at C2)
-template <int NOBST, int LPS, bool W2 = false, bool MASKED = false>
+// BLK2: the stage recursions run on PAIRS of stages (Blk2Lds / rowpar_factor2, rti_kernel.hpp): even horizons, dense blocks, one wavefront per SIMD
+template <int NOBST, int LPS, bool W2 = false, bool MASKED = false, bool BLK2 = false>
 __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
 {
     static_assert(LPS == 2 || LPS == 3, "two or three lanes per horizon stage");
-    using SL = SplitLds<LPS, NOBST, W2>;
+    static_assert(!BLK2 || !W2, "the block-2 recursions exist on the dense layout only");
+    using SL = SplitLds<LPS, NOBST, W2, BLK2>;
     using LT = typename SL::LT;
     constexpr int NBL = SL::NBL, NSL = SL::NSL;
     constexpr int kKK = 45;                   // free words 45, 46 of a stage block (RowVec uses 0..44, dead-store words start at RowLds::TAIL)
@@ -134,8 +137,14 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
         if constexpr (W2) return RowLdsC(lds_raw + RowLdsC::CT + RowLdsC::pad_front(N), N, lds_raw);
         else return RowLds(lds_raw + RowLds::pad_front(N), N, lds_raw + RowLds::total(N, 1));
     }();
+    // block-2: blocks of stage pairs; the result blocks keep the dense layout (RV: what the vector sweeps walk, N / 2 + 1 blocks)
+    const Blk2Lds BL(lds_raw, N);
+    const RowLds RV(lds_raw, N / 2, BL.R);
+    const int Mb = N >> 1;                    // blocks; stage i belongs to block i >> 1 (the terminal stage N = 2 Mb heads block Mb)
+    const int mblk = i >> 1;
+    const bool odd = (i & 1) != 0;
     // look-ahead staging: a region of its own, or (W2) the H~aug region, which is first written after the positions have been read
-    double *lds_P = W2 ? RL.H : lds_raw + LT::total(N, 1) + SL::results(N);
+    double *lds_P = BLK2 ? lds_raw + Blk2Lds::total(N) : (W2 ? RL.H : lds_raw + LT::total(N, 1) + SL::results(N));
     // what part q of this lane's stage holds in the variable v: from_right shifts the whole wavefront by one lane, so the owner
     // (part 0) sees its neighbours' values; only the owner's result is meaningful
     auto of_part = [&](double v, int q) { return q == 0 ? v : (q == 1 ? from_right(v) : from_right(from_right(v))); };
@@ -211,6 +220,49 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
 #pragma unroll
         for (int c = 0; c < 5; c++) { d0[c] = x0v[c] - xi[c]; lin0 = fmax(lin0, fabs(d0[c])); }
     }
+    // ---- block-2: the pair's dynamics, once per solve ----
+    // Sa, bba: linearisation and defect of the stage IN FRONT of an odd stage (its block partner a = i - 1), published by the owners and read by every lane
+    // of the odd stage; even stages read their own (unused).  A^, B^, b^ of the pair are recomputed from (Sa, S) where needed (a few FMAs) rather than kept.
+    StageLin Sa = S;
+    double bba[5] = {0, 0, 0, 0, 0}, bh0[5] = {0, 0, 0, 0, 0};       // bh0: b^ = A_b b_a + b_b at rhoPi = 1 (odd owners)
+    if constexpr (BLK2) {
+        if (own && has_u) {     // [0] b2 [1] b3 [2] a02 [3] a03 [4] a04 [5] b0 [6] b00 [7] b01 | [8] b4 [9] - [10] a12 [11] a13 [12] a14 [13] b1 [14] b10 [15] b11
+            double *w = BL.S + 16 * i;
+            w[0] = bb[2]; w[1] = bb[3]; w[2] = S.a02; w[3] = S.a03; w[4] = S.a04; w[5] = bb[0]; w[6] = S.b00; w[7] = S.b01;
+            w[8] = bb[4]; w[9] = 0.0; w[10] = S.a12; w[11] = S.a13; w[12] = S.a14; w[13] = bb[1]; w[14] = S.b10; w[15] = S.b11;
+        }
+        wave_sync();
+        if (act && odd) {
+            const double *w = BL.S + 16 * (i - 1);
+            Sa.a02 = w[2]; Sa.a03 = w[3]; Sa.a04 = w[4]; Sa.b00 = w[6]; Sa.b01 = w[7];
+            Sa.a12 = w[10]; Sa.a13 = w[11]; Sa.a14 = w[12]; Sa.b10 = w[14]; Sa.b11 = w[15];
+            bba[0] = w[5]; bba[1] = w[13]; bba[2] = w[0]; bba[3] = w[1]; bba[4] = w[8];
+        }
+        if (own && odd && has_u) {      // W^ = [A^ b^ B^] rows 0..4, columns (x0..x4, 1, ua_a, ual_a, ua_b, ual_b); column 5 is rewritten every iteration
+            // A^ = A_b A_a, B^ = [A_b B_a, B_b] with A = I + E (rows 0, 1 carry the six non-trivial entries, row 2 has dt at column 4), B = [b00 b01; b10 b11; 0 h2; dt 0; 0 dt]
+            const double Wh[5][10] = {
+                {1.0, 0.0, Sa.a02 + S.a02, Sa.a03 + S.a03, fma(S.a02, dt, Sa.a04) + S.a04, 0.0,
+                 fma(S.a03, dt, Sa.b00), fma(S.a04, dt, fma(S.a02, h2, Sa.b01)), S.b00, S.b01},
+                {0.0, 1.0, Sa.a12 + S.a12, Sa.a13 + S.a13, fma(S.a12, dt, Sa.a14) + S.a14, 0.0,
+                 fma(S.a13, dt, Sa.b10), fma(S.a14, dt, fma(S.a12, h2, Sa.b11)), S.b10, S.b11},
+                {0.0, 0.0, 1.0, 0.0, 2.0 * dt, 0.0, 0.0, fma(dt, dt, h2), 0.0, h2},
+                {0.0, 0.0, 0.0, 1.0, 0.0, 0.0, dt, 0.0, dt, 0.0},
+                {0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, dt, 0.0, dt}};
+            double *w = BL.W + Blk2Lds::WS * mblk;
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+#pragma unroll
+                for (int c = 0; c < 10; c++) w[k * 10 + c] = Wh[k][c];
+            bh0[0] = fma(S.a04, bba[4], fma(S.a03, bba[3], fma(S.a02, bba[2], bba[0]))) + bb[0];
+            bh0[1] = fma(S.a14, bba[4], fma(S.a13, bba[3], fma(S.a12, bba[2], bba[1]))) + bb[1];
+            bh0[2] = fma(dt, bba[4], bba[2]) + bb[2]; bh0[3] = bba[3] + bb[3]; bh0[4] = bba[4] + bb[4];
+        }
+        if (own && act && (odd || i == N)) {      // H^ block of the pair (or of the terminal stage): the structural zeros once
+            double *hc = BL.H + Blk2Lds::HS * mblk;
+#pragma unroll
+            for (int e = 0; e < 100; e++) hc[e] = 0.0;
+        }
+    } else
     if constexpr (W2) {
         // (the look-ahead positions staged in this region have been read above: LDS operations of a wavefront complete in order)
         if (own && act) { double *hc = RL.H + LT::HS * i; hc[49] = 0.0; hc[50] = 0.0; }      // rows 6, 7 of H~aug read these as their zeros; nothing else writes them
@@ -420,6 +472,87 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
                 for (int e = 0; e < 5; e++) Ssum[e] += sh_s[e];
             }
             const double Sxx = Ssum[0], Syy = Ssum[1], Sxy = Ssum[2], Sgx = Ssum[3], Sgy = Ssum[4];
+            if constexpr (BLK2) {
+                // the stage's cost in sparse form: Q = diag(q[0..4]) + qxy at (0, 1), gradient g[0..4], input block diag(r0, r1) with gradient (lu0, lu1)
+                const double q[5] = {Hk[2] + Sxx, Hk[3] + Syy, hd_psi, Hk[4], Hk[5]};
+                const double g[5] = {gk[2] + Sgx, gk[3] + Sgy, hd_psi * z[4], gk[4], gk[5]};
+                const double r0 = Hk[0], r1 = Hk[1], lu0 = gk[0], lu1 = gk[1];
+                // the even stage of a pair hands its 15 numbers to the odd stage's owner through the pair's (not yet used) result block
+                if (own && act && !odd && i < N) {
+                    double *x = BL.R + Blk2Lds::RS * mblk;
+#pragma unroll
+                    for (int c = 0; c < 5; c++) { x[c] = q[c]; x[5 + c] = g[c]; }
+                    x[10] = Sxy; x[11] = r0; x[12] = r1; x[13] = lu0; x[14] = lu1;
+                }
+                if (own && i == N) {    // terminal stage: P~_N = H~aug_N[0..5][0..5]
+                    double *hc = BL.H + Blk2Lds::HS * mblk;
+#pragma unroll
+                    for (int c = 0; c < 5; c++) { hc[11 * c] = q[c]; hc[10 * c + 5] = g[c]; hc[50 + c] = g[c]; }
+                    hc[1] = Sxy; hc[10] = Sxy;
+                }
+                wave_sync();
+                if (own && odd && act) {
+                    const double *x = BL.R + Blk2Lds::RS * mblk;
+                    double qa[5], ga[5];
+#pragma unroll
+                    for (int c = 0; c < 5; c++) { qa[c] = x[c]; ga[c] = x[5 + c]; }
+                    const double qaxy = x[10], ra0 = x[11], ra1 = x[12], lua0 = x[13], lua1 = x[14];
+                    // Y = C' Q C and y = C' (Q c + g) with C = [A_a B_a] (columns x0..x4, ua, ual), c = rhoPi b_a: the odd stage's cost seen from (x_a, u_a).
+                    //   rows of C: r0 = (1, 0, a02, a03, a04, b00, b01), r1 = (0, 1, a12, a13, a14, b10, b11), r2 = (0, 0, 1, 0, dt, 0, h2), r3 = (0, 0, 0, 1, 0, dt, 0), r4 = (0, 0, 0, 0, 1, 0, dt)
+                    //   Y_ij = r0_i s0_j + r1_i s1_j + q2 r2_i r2_j + q3 r3_i r3_j + q4 r4_i r4_j,   s0 = q0 r0 + qxy r1,  s1 = qxy r0 + q1 r1
+                    const double C0[7] = {1.0, 0.0, Sa.a02, Sa.a03, Sa.a04, Sa.b00, Sa.b01}, C1[7] = {0.0, 1.0, Sa.a12, Sa.a13, Sa.a14, Sa.b10, Sa.b11};
+                    double s0[7], s1[7];
+                    s0[0] = q[0]; s0[1] = Sxy; s1[0] = Sxy; s1[1] = q[1];
+#pragma unroll
+                    for (int c = 2; c < 7; c++) { s0[c] = fma(q[0], C0[c], Sxy * C1[c]); s1[c] = fma(Sxy, C0[c], q[1] * C1[c]); }
+                    double Y[7][7];
+#pragma unroll
+                    for (int c = 0; c < 7; c++) { Y[0][c] = s0[c]; Y[1][c] = s1[c]; }
+#pragma unroll
+                    for (int r = 2; r < 7; r++)
+#pragma unroll
+                        for (int c = r; c < 7; c++) Y[r][c] = fma(C0[r], s0[c], C1[r] * s1[c]);
+                    const double q2dt = q[2] * dt, q2h2 = q[2] * h2, q3dt = q[3] * dt, q4dt = q[4] * dt;
+                    Y[2][2] += q[2]; Y[2][4] += q2dt; Y[2][6] += q2h2;
+                    Y[3][3] += q[3]; Y[3][5] += q3dt;
+                    Y[4][4] += fma(q2dt, dt, q[4]); Y[4][6] += fma(q2dt, h2, q4dt);
+                    Y[5][5] += q3dt * dt;
+                    Y[6][6] += fma(q2h2, h2, q4dt * dt);
+                    const double ca[5] = {rhoPi * bba[0], rhoPi * bba[1], rhoPi * bba[2], rhoPi * bba[3], rhoPi * bba[4]};
+                    const double v[5] = {fma(q[0], ca[0], fma(Sxy, ca[1], g[0])), fma(Sxy, ca[0], fma(q[1], ca[1], g[1])), fma(q[2], ca[2], g[2]),
+                                         fma(q[3], ca[3], g[3]), fma(q[4], ca[4], g[4])};
+                    double y[7];
+                    y[0] = v[0]; y[1] = v[1];
+                    y[2] = fma(Sa.a02, v[0], fma(Sa.a12, v[1], v[2])); y[3] = fma(Sa.a03, v[0], fma(Sa.a13, v[1], v[3]));
+                    y[4] = fma(Sa.a04, v[0], fma(Sa.a14, v[1], fma(dt, v[2], v[4])));
+                    y[5] = fma(Sa.b00, v[0], fma(Sa.b10, v[1], dt * v[3])); y[6] = fma(Sa.b01, v[0], fma(Sa.b11, v[1], fma(h2, v[2], dt * v[4])));
+                    // H^ in z^ order (x0..x4, 1, ua_a, ual_a, ua_b, ual_b): Y index 5, 6 (u_a) -> 6, 7; row-major 10 x 10, symmetric
+                    double Hh[8][8];
+                    const int zi[7] = {0, 1, 2, 3, 4, 6, 7};
+#pragma unroll
+                    for (int r = 0; r < 8; r++)
+#pragma unroll
+                        for (int c = 0; c < 8; c++) Hh[r][c] = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 7; r++)
+#pragma unroll
+                        for (int c = r; c < 7; c++) { Hh[zi[r]][zi[c]] = Y[r][c]; Hh[zi[c]][zi[r]] = Y[r][c]; }
+#pragma unroll
+                    for (int c = 0; c < 5; c++) { Hh[c][c] += qa[c]; Hh[c][5] = ga[c] + y[c]; Hh[5][c] = Hh[c][5]; }
+                    Hh[0][1] += qaxy; Hh[1][0] += qaxy;
+                    Hh[6][6] += ra0; Hh[7][7] += ra1;
+                    Hh[5][6] = lua0 + y[5]; Hh[6][5] = Hh[5][6]; Hh[5][7] = lua1 + y[6]; Hh[7][5] = Hh[5][7];
+                    double *hc = BL.H + Blk2Lds::HS * mblk;
+#pragma unroll
+                    for (int r = 0; r < 8; r++)
+#pragma unroll
+                        for (int c = 0; c < 8; c++) hc[10 * r + c] = Hh[r][c];
+                    hc[58] = lu0; hc[59] = lu1; hc[85] = lu0; hc[95] = lu1; hc[88] = r0; hc[99] = r1;
+                    double *w = BL.W + Blk2Lds::WS * mblk;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) w[10 * k + 5] = rhoPi * bh0[k];
+                }
+            } else
             if (own && act) {   // H~aug_t, dense 8 x 8, z~ order (x0..x4, 1, ua, ual); affine column of W~_t
                 const double hxx = Hk[2] + Sxx, hyy = Hk[3] + Syy;
                 const double gxs[5] = {gk[2] + Sgx, gk[3] + Sgy, hd_psi * z[4], gk[4], gk[5]};
@@ -455,15 +588,104 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
         MPC_TICK(9);
         // (the one-block asm variant rowpar_factor_fast saves 12 instructions per stage but claims 84 fixed registers: here, where the row
         // state lives in VGPRs next to the sweep, the extra AGPR round trips cost more than it gains -- measured 150.7 vs 148.0 us at C2)
+        // K^ of the pair (rows u_a: 0, 1; u_b: 2, 3; column 5 = feed-forward) and, in the odd owner, the L D L' factors for the corrector
+        double Kh[4][5], kh[4], fac[10];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            kh[u] = 0.0;
+#pragma unroll
+            for (int c = 0; c < 5; c++) Kh[u][c] = 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < 10; e++) fac[e] = 0.0;
+        StageFac F;
+        F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 5; c++) { F.K0[c] = 0.0; F.K1[c] = 0.0; }
+        double za[7] = {0, 0, 0, 0, 0, 0, 0};
+        // the affine part of x_b = A_a x_a + B_a u_a + c_a for the lanes of an odd stage (zero in the corrector's homogeneous solve)
+        auto odd_state = [&](const double xa[5], double ua0, double ua1, const double ca[5], double xb_[5]) {
+            xb_[0] = fma(Sa.b01, ua1, fma(Sa.b00, ua0, fma(Sa.a04, xa[4], fma(Sa.a03, xa[3], fma(Sa.a02, xa[2], xa[0]))))) + ca[0];
+            xb_[1] = fma(Sa.b11, ua1, fma(Sa.b10, ua0, fma(Sa.a14, xa[4], fma(Sa.a13, xa[3], fma(Sa.a12, xa[2], xa[1]))))) + ca[1];
+            xb_[2] = fma(h2, ua1, fma(dt, xa[4], xa[2])) + ca[2];
+            xb_[3] = fma(dt, ua0, xa[3]) + ca[3];
+            xb_[4] = fma(dt, ua1, xa[4]) + ca[4];
+        };
+        // the pair's step from the block's state: every lane of both stages evaluates it (same instruction stream)
+        auto pair_step = [&](const double ca[5], double zz[7]) {
+            const double *xx = BL.R + Blk2Lds::RS * mblk + RowVec::X;
+            const double xa[5] = {xx[0], xx[1], xx[2], xx[3], xx[4]};
+            double uu[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) uu[u] = fma(Kh[u][4], xa[4], fma(Kh[u][3], xa[3], fma(Kh[u][2], xa[2], fma(Kh[u][1], xa[1], fma(Kh[u][0], xa[0], kh[u])))));
+            double xb_[5];
+            odd_state(xa, uu[0], uu[1], ca, xb_);
+#pragma unroll
+            for (int c = 0; c < 5; c++) zz[2 + c] = odd ? xb_[c] : xa[c];
+            zz[0] = odd ? uu[2] : uu[0]; zz[1] = odd ? uu[3] : uu[1];
+            if (i == N) { zz[0] = 0.0; zz[1] = 0.0; }
+            if (!act) {
+#pragma unroll
+                for (int c = 0; c < 7; c++) zz[c] = 0.0;
+            }
+        };
+        double bbra[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) bbra[c] = rhoPi * bba[c];
+        if constexpr (BLK2) {
+            rowpar_factor2(lane, Mb, BL, lane < 16);
+            wave_sync();
+            if (has_u) {
+                const double *ko = BL.R + Blk2Lds::RS * mblk;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+#pragma unroll
+                    for (int c = 0; c < 5; c++) Kh[u][c] = ko[8 * u + c];
+                    kh[u] = ko[8 * u + 5];
+                }
+                if (own && odd) {
+#pragma unroll
+                    for (int e = 0; e < 10; e++) fac[e] = ko[Blk2Lds::FAC + e];
+                }
+            }
+            if (own && odd && has_u) {      // closed-loop pair: Acl^ = A^ + B^ K^ (row-major), c^ = rhoPi b^ + B^ k^; B^ rows 0, 1 recomputed, rows 2..4 are (0, h2 + dt^2, 0, h2), (dt, 0, dt, 0), (0, dt, 0, dt)
+                const double B0[4] = {fma(S.a03, dt, Sa.b00), fma(S.a04, dt, fma(S.a02, h2, Sa.b01)), S.b00, S.b01};
+                const double B1[4] = {fma(S.a13, dt, Sa.b10), fma(S.a14, dt, fma(S.a12, h2, Sa.b11)), S.b10, S.b11};
+                const double A0[5] = {1.0, 0.0, Sa.a02 + S.a02, Sa.a03 + S.a03, fma(S.a02, dt, Sa.a04) + S.a04};
+                const double A1[5] = {0.0, 1.0, Sa.a12 + S.a12, Sa.a13 + S.a13, fma(S.a12, dt, Sa.a14) + S.a14};
+                const double h2d = fma(dt, dt, h2);
+                double *acl = BL.R + Blk2Lds::RS * mblk + RowVec::ACL;
+#pragma unroll
+                for (int c = 0; c < 6; c++) {       // c = 5: the affine column (feed-forward)
+                    const double k0 = c < 5 ? Kh[0][c] : kh[0], k1 = c < 5 ? Kh[1][c] : kh[1], k2 = c < 5 ? Kh[2][c] : kh[2], k3 = c < 5 ? Kh[3][c] : kh[3];
+                    const double a0 = c < 5 ? A0[c] : rhoPi * bh0[0], a1 = c < 5 ? A1[c] : rhoPi * bh0[1];
+                    const double a2 = c < 5 ? (c == 2 ? 1.0 : (c == 4 ? 2.0 * dt : 0.0)) : rhoPi * bh0[2];
+                    const double a3 = c < 5 ? (c == 3 ? 1.0 : 0.0) : rhoPi * bh0[3], a4 = c < 5 ? (c == 4 ? 1.0 : 0.0) : rhoPi * bh0[4];
+                    acl[0 * RowVec::RS + c] = fma(B0[3], k3, fma(B0[2], k2, fma(B0[1], k1, fma(B0[0], k0, a0))));
+                    acl[1 * RowVec::RS + c] = fma(B1[3], k3, fma(B1[2], k2, fma(B1[1], k1, fma(B1[0], k0, a1))));
+                    acl[2 * RowVec::RS + c] = fma(h2, k3, fma(h2d, k1, a2));
+                    acl[3 * RowVec::RS + c] = fma(dt, k2, fma(dt, k0, a3));
+                    acl[4 * RowVec::RS + c] = fma(dt, k3, fma(dt, k1, a4));
+                }
+            }
+            MPC_TICK(2);
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) BL.R[RowVec::X + c] = x_init[c];
+            }
+            wave_sync();
+            MPC_TICK(3);
+            rowpar_vector_fast<true>(lane, Mb, RV, lane < 16);
+            MPC_TICK(15);
+            wave_sync();
+            pair_step(bbra, za);
+            MPC_TICK(3);
+        } else {
 #ifdef MPC_MFMA4
         if constexpr (!W2) mfma4_factor(lane, N, RL); else
 #endif
         rowpar_factor(lane, N, RL, lane < 16);
         wave_sync();
-        StageFac F;
-        F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;
-#pragma unroll
-        for (int c = 0; c < 5; c++) { F.K0[c] = 0.0; F.K1[c] = 0.0; }
         if (has_u) {
             const double *ko = RL.R + LT::HS * i;
 #pragma unroll
@@ -498,7 +720,6 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
         rowpar_vector_fast<true>(lane, N, RL, lane < 16);
         MPC_TICK(15);
         wave_sync();
-        double za[7] = {0, 0, 0, 0, 0, 0, 0};
         if (act) {
             const double *xx = RL.R + LT::HS * i + RowVec::X;
             double u0 = F.k0, u1 = F.k1;
@@ -507,6 +728,8 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
             za[0] = u0; za[1] = u1;
         }
         MPC_TICK(3);
+
+        }
 
         // ---- affine step: dt, dlam per row, step ratios, products dlam_aff * dt_aff ----
         double ppl[NBL], pph[NBL], pp1[NSL], pp2[NSL];
@@ -603,6 +826,61 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
                 Sgx = q == 0 ? vx : Sgx + vx; Sgy = q == 0 ? vy : Sgy + vy;
             }
             gc[2] += Sgx; gc[3] += Sgy;
+            if constexpr (BLK2) {
+                // the pair's right-hand side in (x_a, u_a, u_b): gc^_x = gc_a,x + A_a' gc_b,x,  gc^_ua = gc_a,u + B_a' gc_b,x,  gc^_ub = gc_b,u.
+                // The even owner hands its seven numbers to the odd owner through free words of the pair's result block.
+                constexpr int kGX = 50;
+                if (own && act && !odd && i < N) {
+                    double *x = BL.R + Blk2Lds::RS * mblk + kGX;
+#pragma unroll
+                    for (int c = 0; c < 7; c++) x[c] = gc[c];
+                }
+                if (own && i == N) {    // terminal stage: c~_N = gc_N,x
+                    double *cc = BL.R + Blk2Lds::RS * mblk + RowVec::CT;
+#pragma unroll
+                    for (int c = 0; c < 5; c++) cc[c] = gc[2 + c];
+                }
+                wave_sync();
+                double gu[4] = {0, 0, 0, 0};        // gc^_u in the order (ua_a, ual_a, ua_b, ual_b); odd owner
+                if (own && odd && act) {
+                    const double *x = BL.R + Blk2Lds::RS * mblk + kGX;
+                    const double gb[5] = {gc[2], gc[3], gc[4], gc[5], gc[6]};
+                    double gx[5];
+                    gx[0] = x[2] + gb[0]; gx[1] = x[3] + gb[1];
+                    gx[2] = x[4] + Sa.dpsi(gb); gx[3] = x[5] + Sa.dv(gb); gx[4] = x[6] + Sa.dom(gb);
+                    gu[0] = x[0] + Sa.dua(gb); gu[1] = x[1] + Sa.dual(gb); gu[2] = gc[0]; gu[3] = gc[1];
+                    double *cc = BL.R + Blk2Lds::RS * mblk + RowVec::CT;
+#pragma unroll
+                    for (int c = 0; c < 5; c++) cc[c] = fma(Kh[3][c], gu[3], fma(Kh[2][c], gu[2], fma(Kh[1][c], gu[1], fma(Kh[0][c], gu[0], gx[c]))));
+                }
+                wave_sync();
+                rowpar_vector_fast<false>(lane, Mb, RV, lane < 16);
+                wave_sync();
+                if (own && odd && has_u) {      // feed-forward of the corrector: k^ = -Muu^-1 (gc^_u + B^' p_{a+2}),  B^' p = [B_a' (A_b' p); B_b' p]
+                    const double *pp = BL.R + Blk2Lds::RS * (mblk + 1) + RowVec::P;
+                    const double pv[5] = {pp[0], pp[1], pp[2], pp[3], pp[4]};
+                    const double wv[5] = {pv[0], pv[1], S.dpsi(pv), S.dv(pv), S.dom(pv)};
+                    const double ma0 = gu[0] + Sa.dua(wv), ma1 = gu[1] + Sa.dual(wv), mb0 = gu[2] + S.dua(pv), mb1 = gu[3] + S.dual(pv);
+                    // substitution in the pivot order (u_b, u_a) with the stored factors: fac = 1/d0 1/d1 1/d2 1/d3 l10 l20 l30 l21 l31 l32
+                    const double y0 = mb0, y1 = fma(-fac[4], y0, mb1), y2 = fma(-fac[7], y1, fma(-fac[5], y0, ma0)), y3 = fma(-fac[9], y2, fma(-fac[8], y1, fma(-fac[6], y0, ma1)));
+                    const double k3 = -(y3 * fac[3]);
+                    const double k2 = fma(-fac[9], k3, -(y2 * fac[2]));
+                    const double k1 = fma(-fac[8], k3, fma(-fac[7], k2, -(y1 * fac[1])));
+                    const double k0 = fma(-fac[6], k3, fma(-fac[5], k2, fma(-fac[4], k1, -(y0 * fac[0]))));
+                    const double kc[4] = {k2, k3, k0, k1};      // (ua_a, ual_a, ua_b, ual_b)
+                    // homogeneous pair dynamics: c^ = B^ k^; k^ itself for the lanes of both stages (free words 45..48 of the pair's block)
+                    const double B0[4] = {fma(S.a03, dt, Sa.b00), fma(S.a04, dt, fma(S.a02, h2, Sa.b01)), S.b00, S.b01};
+                    const double B1[4] = {fma(S.a13, dt, Sa.b10), fma(S.a14, dt, fma(S.a12, h2, Sa.b11)), S.b10, S.b11};
+                    double *cc = BL.R + Blk2Lds::RS * mblk + RowVec::ACL + 5;
+                    cc[0 * RowVec::RS] = fma(B0[3], kc[3], fma(B0[2], kc[2], fma(B0[1], kc[1], B0[0] * kc[0])));
+                    cc[1 * RowVec::RS] = fma(B1[3], kc[3], fma(B1[2], kc[2], fma(B1[1], kc[1], B1[0] * kc[0])));
+                    cc[2 * RowVec::RS] = fma(h2, kc[3], fma(dt, dt, h2) * kc[1]);
+                    cc[3 * RowVec::RS] = fma(dt, kc[2], dt * kc[0]);
+                    cc[4 * RowVec::RS] = fma(dt, kc[3], dt * kc[1]);
+                    double *kk = BL.R + Blk2Lds::RS * mblk + kKK;       // words 45, 46, 47 and 49: word 48 (RowLds::TAIL) is where the idle lanes of the vector sweeps store
+                    kk[0] = kc[0]; kk[1] = kc[1]; kk[2] = kc[2]; kk[4] = kc[3];
+                }
+            } else {
             if (own && act) {   // c~_t = gc_x + K' gc_u  (K = 0 in the terminal lane)
                 double *cc = RL.R + LT::HS * i + RowVec::CT;
 #pragma unroll
@@ -618,8 +896,25 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
                 F.k1 = fma(F.l, m0, -m1) * F.i11;
                 F.k0 = fma(-F.l, F.k1, -(m0 * F.i00));
             }
+            }
         }
         MPC_TICK(6);
+        double dz[7] = {0, 0, 0, 0, 0, 0, 0};
+        if constexpr (BLK2) {
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) BL.R[RowVec::X + c] = 0.0;
+            }
+            wave_sync();
+            rowpar_vector_fast<true>(lane, Mb, RV, lane < 16);
+            wave_sync();
+            if (has_u) {
+                const double *kk = BL.R + Blk2Lds::RS * mblk + kKK;
+                kh[0] = kk[0]; kh[1] = kk[1]; kh[2] = kk[2]; kh[3] = kk[4];
+            }
+            const double zero5[5] = {0, 0, 0, 0, 0};
+            pair_step(zero5, dz);
+        } else {
         if (own && has_u) {     // homogeneous dynamics: c_t = B k; k itself for the other parts of the stage
             double *cc = RL.R + LT::HS * i + RowVec::ACL + 5;
             cc[0 * RowVec::RS] = S.b00 * F.k0 + S.b01 * F.k1; cc[1 * RowVec::RS] = S.b10 * F.k0 + S.b11 * F.k1;
@@ -633,13 +928,13 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
         wave_sync();
         rowpar_vector_fast<true>(lane, N, RL, lane < 16);
         wave_sync();
-        double dz[7] = {0, 0, 0, 0, 0, 0, 0};
         if (act) {
             const double *xx = RL.R + LT::HS * i + RowVec::X;
             double u0 = has_u ? RL.R[LT::HS * i + kKK] : 0.0, u1 = has_u ? RL.R[LT::HS * i + kKK + 1] : 0.0;
 #pragma unroll
             for (int c = 0; c < 5; c++) { dz[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }
             dz[0] = u0; dz[1] = u1;
+        }
         }
 #pragma unroll
         for (int c = 0; c < 7; c++) dz[c] += za[c];

@@ -80,6 +80,7 @@ SYMBOLS = {
     "mpc_get_waves_per_simd": (C.c_int, [_vp, C.c_int]),
     "mpc_set_matrix_cores": (C.c_int, [_vp, C.c_int]),
     "mpc_set_row_parallel": (C.c_int, [_vp, C.c_int]),
+    "mpc_set_block_riccati": (C.c_int, [_vp, C.c_int]),
     "mpc_generate_scenarios_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint, _vp, _vp, _vp]),
     "mpc_generate_scenarios": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint, _vp, _vp]),
 }

@@ -34,6 +34,7 @@ class BatchedMpc:
     default_lanes_per_stage = int(os.environ.get("MPC_LANES_PER_STAGE", "0"))
     default_waves_per_simd = int(os.environ.get("MPC_WAVES_PER_SIMD", "0"))
     default_lanes_per_instance = int(os.environ.get("MPC_LANES_PER_INSTANCE", "0"))
+    default_block_riccati = int(os.environ.get("MPC_BLOCK_RICCATI", "0"))      # 1: stage recursions on pairs of stages (A/B runs of unmodified programs)
     default_matrix_cores = int(os.environ.get("MPC_MATRIX_CORES", "0"))      # 1: the v_mfma_f64_16x16x4 Riccati sweep (evidence path, one instance per wavefront)
 
     def __init__(self, N=20, n_obst=3, Tf=2.0, max_batch=1, device=0, **cfg_overrides):
@@ -50,6 +51,8 @@ class BatchedMpc:
             _lib.check(_lib.lib().mpc_set_waves_per_simd(self._h, int(BatchedMpc.default_waves_per_simd)))
         if BatchedMpc.default_lanes_per_instance:
             _lib.check(_lib.lib().mpc_set_lanes_per_instance(self._h, int(BatchedMpc.default_lanes_per_instance)))
+        if BatchedMpc.default_block_riccati:
+            _lib.check(_lib.lib().mpc_set_block_riccati(self._h, 1))
         if BatchedMpc.default_matrix_cores:
             _lib.check(_lib.lib().mpc_set_lanes_per_stage(self._h, 1))
             _lib.check(_lib.lib().mpc_set_lanes_per_instance(self._h, 64))
@@ -227,6 +230,10 @@ class BatchedMpc:
     def set_row_parallel(self, on=True):
         """Riccati factorisation sweep: row-parallel 64-bit-DPP variant (True) or one-lane systolic sweep (False)."""
         _lib.check(_lib.lib().mpc_set_row_parallel(self._h, 1 if on else 0))
+
+    def set_block_riccati(self, on=True):
+        """stage recursions over pairs of stages (opt-in) or one stage per step (default) (mpc_set_block_riccati)"""
+        _lib.check(_lib.lib().mpc_set_block_riccati(self._h, 1 if on else 0))
 
     def set_matrix_cores(self, on=True):
         _lib.check(_lib.lib().mpc_set_matrix_cores(self._h, 1 if on else 0))

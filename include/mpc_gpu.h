@@ -198,6 +198,11 @@ int mpc_set_matrix_cores(mpc_handle *h, int on);
  * 0: one-lane systolic sweeps (no LDS), the independent implementation the default is tested against.
  * No reference counterpart (tuning / test hook). */
 int mpc_set_row_parallel(mpc_handle *h, int on);
+/* Block-2 (partially condensed) stage recursions, default OFF (opt-in: measured 5 % slower than one stage per step at C2): where the mapping has them (the stage-split kernel on dense blocks, even horizons, all of
+ * the kernel's obstacle rows in use) the Riccati factorisation and the three vector recursions of an interior-point iteration run over PAIRS of stages
+ * (state x_2m, inputs (u_2m, u_2m+1); x_2m+1 eliminated) -- half the sequential steps at ~0.75x the instructions.  What HPIPM's PARTIAL_CONDENSING
+ * (robot_ocp_problem.py:126) does on the CPU.  0: one stage per step (the default, and the form the block form is tested against).  Same interior point, same QP solution. */
+int mpc_set_block_riccati(mpc_handle *h, int on);
 /* Lanes per horizon stage.  0 (default): automatic -- a batch of at most eight instances per SIMD of the device (8192 on
  * MI355X) runs one instance per wavefront with the inequality rows of every stage dealt out to 3 (N <= 20) or 2 (N <= 31)
  * neighbouring lanes, which shortens the instruction stream such a latency-bound wavefront is limited by (and lets every
@@ -217,7 +222,7 @@ int mpc_get_lanes_per_stage(mpc_handle *h, int batch);
 int mpc_set_instance_scheduling(mpc_handle *h, int on);
 int mpc_get_instance_order(mpc_handle *h, int batch, int32_t *order);
 /* name of the solve kernel instantiation a batch of this size runs (as rocprofv3 prints it, without the namespace), for measurement
- * records: "rti_split_kernel<row capacity, lanes per stage, two wavefronts per SIMD, masked>" or "rti_solve_kernel<row capacity, lanes per
+ * records: "rti_split_kernel<row capacity, lanes per stage, two wavefronts per SIMD, masked, block-2 recursions>" or "rti_solve_kernel<row capacity, lanes per
  * instance, sweeps, masked>" (row capacity: 3, 5 or 10 obstacle row pairs per stage, the smallest that holds n_obst; masked: n_obst is below it;
  * sweeps: 0 systolic, 1 matrix cores, 2 row-parallel on dense LDS blocks, 3 row-parallel on compact LDS blocks).  lookahead: whether the
  * obstacle look-ahead runs inside the kernel (mpc_closed_loop_step_dev) -- it enters the LDS budget that selects the block layout. */

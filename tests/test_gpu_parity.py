@@ -410,7 +410,7 @@ def test_automatic_lane_mapping(env):
             assert s.lanes_per_stage(1) == 3 and s.lanes_per_stage(1024) == 3 and s.lanes_per_instance(1024) == 64
             assert s.lanes_per_stage(8192) == 3 and s.waves_per_simd(4096) == 1 and s.waves_per_simd(4097) == 2 and s.waves_per_simd(8192) == 2
             assert s.lanes_per_stage(8193) == 1 and s.lanes_per_instance(8193) == 21 and s.lanes_per_instance(65536) == 21     # three per wavefront
-            assert s.kernel_name(65536) == "rti_solve_kernel<3, 21, 3, false>" and s.kernel_name(1024) == "rti_split_kernel<3, 3, false, false>"
+            assert s.kernel_name(65536) == "rti_solve_kernel<3, 21, 3, false>" and s.kernel_name(1024) == "rti_split_kernel<3, 3, false, false, false>"
             s.set_waves_per_simd(1)
             assert s.waves_per_simd(8192) == 1
             assert _lib.lib().mpc_set_waves_per_simd(s._h, 3) == _lib.MPC_ERR_ARG
@@ -587,6 +587,43 @@ def test_instance_scheduling(env, G):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,no,B", [(20, 3, 200), (20, 5, 90), (10, 3, 64), (30, 3, 40), (20, 10, 48), (4, 3, 33)])
+def test_block_riccati_matches_the_oracle_and_the_stagewise_recursion(built, N, no, B):
+    """mpc_set_block_riccati(1): Riccati factorisation and vector recursions over PAIRS of stages (x_2m+1 eliminated, 4 x 4 input block, Blk2Lds /
+    rowpar_factor2) in the stage-split kernel -- opt-in, because it measured slower.  Two closed-loop steps (cold start; warm start with
+    defects and an explicit P) judged against the oracle instance by instance, and against the one-stage-per-step recursion: same statuses, iteration counts
+    within the end-game, iterates equal to rounding.  Odd horizons and partial obstacle counts fall back to the stagewise kernel."""
+    import mpc_gpu
+    from oracle import oracle as orc
+    x0, goal, obst = random_batch(B, no, seed=900 + N + no)
+    cfg = orc.config(N, no, 0.1 * N, qp_tol=1e-8)
+    P = oracle_P(orc, cfg, obst); X0, U0 = oracle_guess(orc, cfg, x0)
+    out = {}
+    for on in (1, 0):
+        with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
+            s.set_lanes_per_stage(3 if N <= 20 else 2); s.set_block_riccati(bool(on))
+            assert s.kernel_name(B).endswith("true>" if on else "false>"), s.kernel_name(B)
+            s.reset_guess(x0); g = s.solve(x0, obst, goal); X, U = s.get_traj(B)
+            s.shift(B); Xs, Us = s.get_traj(B); g2 = s.solve(x0, P, goal); X2, U2 = s.get_traj(B)
+            out[on] = (g, X, U, g2, X2, U2, Xs, Us)
+    g, X, U, g2, X2, U2, Xs, Us = out[1]
+    o = orc.rti_solve_batch(cfg, x0, P, goal, X0, U0)
+    n = judge_against_oracle(orc, cfg, x0, P, goal, X0, U0, g, X, U, o)
+    assert n["converged"] >= 0.85 * B and n["status_borderline"] == 0, n
+    o2 = orc.rti_solve_batch(cfg, x0, P, goal, Xs, Us)
+    n2 = judge_against_oracle(orc, cfg, x0, P, goal, Xs, Us, g2, X2, U2, o2)
+    assert n2["converged"] >= 0.8 * B, n2
+    ref = out[0]
+    assert np.array_equal(g["status"], ref[0]["status"]) and (np.abs(g["iters"].astype(int) - ref[0]["iters"]) <= 2).all()
+    ok = g["status"] == 0
+    d = np.abs(X - ref[1]).reshape(B, -1).max(1)[ok]
+    assert np.median(d) < 1e-10 and d.max() < (1e-6 if no < 10 else 1e-4)
+    with mpc_gpu.BatchedMpc(N + 1, no, 0.1 * (N + 1), max_batch=4) as s:      # odd horizon: no pairs
+        s.set_lanes_per_stage(3 if N + 1 <= 20 else 2); s.set_block_riccati(True)
+        assert s.kernel_name(4).endswith("false>")
+
+
+@pytest.mark.gpu
 def test_c5_kernel_at_a_scheduled_batch(built):
     """BASELINE configs[4]'s own instantiation, rti_solve_kernel<10, 64, 3, false>, at a batch the instance scheduling reorders (4096 = the per-GPU share of
     C5 on 8 GPUs; N = 50, 10 obstacles, fused closed-loop steps): after three control steps (the third runs in the order built from the second's iteration
@@ -714,7 +751,7 @@ def test_any_obstacle_count(built, N, no, B):
     cap = 3 if no <= 3 else (5 if no <= 5 else 10)
     with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
         name = s.kernel_name(B)
-        assert name.startswith(f"rti_split_kernel<{cap}," if N <= 31 else f"rti_solve_kernel<{cap}, 64,") and name.endswith("true>"), name
+        assert name.startswith(f"rti_split_kernel<{cap}," if N <= 31 else f"rti_solve_kernel<{cap}, 64,") and (name.endswith("true>") or name.endswith("true, false>")), name
         s.reset_guess(x0)
         for k in range(3):
             g = s.solve(x0, obst if k != 1 else P, goal); X, U = s.get_traj(B)
@@ -761,7 +798,7 @@ def test_instance_scheduling_with_fewer_obstacles_than_rows(built, N, no, B):
     res = {}
     for on in (1, 0):
         with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
-            assert s.kernel_name(B).endswith("true>")
+            assert "true" in s.kernel_name(B).split(",")[3]      # the masked (run-time obstacle count) instantiation
             s.set_instance_scheduling(bool(on)); s.reset_guess(x0); outs = []; xk = x0.copy()
             for k in range(3):
                 g = s.solve(xk, obst, goal); X, U = s.get_traj(B)
