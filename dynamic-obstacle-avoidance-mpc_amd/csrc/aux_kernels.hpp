@@ -74,6 +74,148 @@ __global__ void scenario_kernel(int count, int n_obst, int scenario, unsigned se
     for (int j = 0; j < n_obst; j++) o[j * 4 + 3] = uniform(-v_max, v_max);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// THE REFERENCE'S NOISE STREAM ON THE DEVICE.  experiments.py:33-36 seeds numpy's global legacy generator per run (np.random.seed(i)), draws the
+// scenario (obstacle_generator.py: uniform blocks) and then, in every control step, `for o in self.obstacles: o.step()` draws np.random.normal(size=2)
+// per obstacle (visualization.py:31).  Instance s of a batch carries that generator for seed seed0 + s: MT19937 state (624 words), position, and the
+// cached second value of the polar Gaussian method -- numpy's legacy_gauss:
+//     if cached: return it;  else  do { x1 = 2 u - 1; x2 = 2 u - 1; r2 = x1 x1 + x2 x2 } while (r2 >= 1 || r2 == 0);  f = sqrt(-2 log(r2) / r2);
+//     cache f x1, return f x2                       (u = random_sample() = ((a >> 5) 2^26 + (b >> 6)) / 2^53 from two outputs)
+// Everything but the logarithm is IEEE arithmetic in numpy's order (no contraction) and therefore bit-exact.  The logarithm is evaluated to ~2^-80 in
+// double-double arithmetic and rounded once, i.e. correctly rounded for all practical purposes; glibc's log (what numpy calls) is not quite -- it
+// differs from the correctly rounded value on a few inputs in 10^5 -- so the stream equals the host's in all but that fraction of the draws, where
+// one value differs in its last bit (measured: tests/test_gpu_aux.py).  The device library's own log differs from glibc's on 2.8 % of the inputs.
+// State layout per instance (uint32 words): mt[624] | pos | has_gauss | gauss (2 words).
+constexpr int kNoiseStateWords = 628;
+
+__device__ __forceinline__ void dd_two_sum(double a, double b, double &s, double &e)
+{
+#pragma clang fp contract(off)
+    s = a + b; const double bb = s - a; e = (a - (s - bb)) + (b - bb);
+}
+__device__ __forceinline__ void dd_fast_two_sum(double a, double b, double &s, double &e)       // |a| >= |b|
+{
+#pragma clang fp contract(off)
+    s = a + b; e = b - (s - a);
+}
+// (ah, al) * (bh, bl) -> (ph, pl), error ~2^-104
+__device__ __forceinline__ void dd_mul(double ah, double al, double bh, double bl, double &ph, double &pl)
+{
+    ph = ah * bh;
+    pl = fma(ah, bh, -ph) + (ah * bl + al * bh);
+    double s, e; dd_fast_two_sum(ph, pl, s, e); ph = s; pl = e;
+}
+__device__ __forceinline__ void dd_add(double ah, double al, double bh, double bl, double &sh, double &sl)
+{
+    double s, e; dd_two_sum(ah, bh, s, e);
+    e += al + bl;
+    dd_fast_two_sum(s, e, sh, sl);
+}
+// log(x) for a normal positive double, rounded once from a double-double value
+__device__ inline double log_dd(double x)
+{
+    static constexpr double kLogTab[25][2] = {{-0x1.7fafa3bd8151cp-2, 0x1.219024acd3b77p-58}, {-0x1.522ae0738a3d8p-2, 0x1.8f7e9b38a6979p-57}, {-0x1.269621134db92p-2, -0x1.e0efadd9db02bp-56}, {-0x1.f991c6cb3b379p-3, -0x1.f665066f980a2p-57}, {-0x1.a93ed3c8ad9e3p-3, -0x1.bcafa9de97203p-57}, {-0x1.5bf406b543db2p-3, 0x1.1f5b44c0df7e7p-61}, {-0x1.1178e8227e47cp-3, 0x1.0e63a5f01c691p-58}, {-0x1.9335e5d594989p-4, 0x1.478a85704ccb7p-58}, {-0x1.08598b59e3a07p-4, 0x1.dd7009902bf32p-58}, {-0x1.0415d89e74444p-5, -0x1.c05cf1d753622p-59}, {0x0.0p+0, 0x0.0p+0}, {0x1.f829b0e783300p-6, 0x1.33e3f04f1ef23p-60}, {0x1.f0a30c01162a6p-5, 0x1.85f325c5bbacdp-59}, {0x1.6f0d28ae56b4cp-4, -0x1.906d99184b992p-58}, {0x1.e27076e2af2e6p-4, -0x1.61578001e0162p-60}, {0x1.29552f81ff523p-3, 0x1.301771c407dbfp-57}, {0x1.5ff3070a793d4p-3, -0x1.bc60efafc6f6ep-58}, {0x1.9525a9cf456b4p-3, 0x1.d904c1d4e2e26p-57}, {0x1.c8ff7c79a9a22p-3, -0x1.4f689f8434012p-57}, {0x1.fb9186d5e3e2bp-3, -0x1.caaae64f21acbp-57}, {0x1.1675cababa60ep-2, 0x1.ce63eab883717p-61}, {0x1.2e8e2bae11d31p-2, -0x1.8f4cdb95ebdf9p-56}, {0x1.4618bc21c5ec2p-2, 0x1.f42decdeccf1dp-56}, {0x1.5d1bdbf5809cap-2, 0x1.4236383dc7fe1p-56}, {0x1.739d7f6bbd007p-2, -0x1.8c76ceb014b04p-56}};
+    int e;
+    double m = frexp(x, &e);                        // m in [0.5, 1)
+    if (m < 0.70710678118654752) { m *= 2.0; e -= 1; }      // m in [sqrt(1/2), sqrt(2)): log x = e ln 2 + log m without cancellation near x = 1
+    const int i = (int)rint(m * 32.0);              // 22 .. 46; c = i / 32 exactly, |m - c| <= 1 / 64
+    const double c = (double)i * 0.03125;
+    // t = (m - c) / (m + c) in double-double: the numerator is exact (m and c within a factor of two: Sterbenz)
+    const double num = m - c;
+    double dh, dl; dd_two_sum(m, c, dh, dl);
+    const double th = num / dh;
+    const double tl = (fma(-th, dh, num) - th * dl) / dh;
+    // log m = log c + 2 atanh t = log c + 2 (t + t^3 / 3 + t^5 / 5 + ...): t and t^3 / 3 in double-double, the rest (<= 3e-9 t) in double
+    double t2h, t2l; dd_mul(th, tl, th, tl, t2h, t2l);
+    double t3h, t3l; dd_mul(t2h, t2l, th, tl, t3h, t3l);
+    double ch, cl; dd_mul(t3h, t3l, 0x1.5555555555555p-2, 0x1.5555555555555p-56, ch, cl);
+    const double w = t2h;
+    const double tail = th * (w * w) * (1.0 / 5.0 + w * (1.0 / 7.0 + w * (1.0 / 9.0 + w * (1.0 / 11.0 + w * (1.0 / 13.0)))));
+    double ah, al; dd_add(th, tl, ch, cl, ah, al);
+    al += tail;
+    ah *= 2.0; al *= 2.0;
+    double rh, rl; dd_add(kLogTab[i - 22][0], kLogTab[i - 22][1], ah, al, rh, rl);
+    // e ln 2: the high part of ln 2 has 11 trailing zero bits, so e * ln2_hi is exact
+    const double ed = (double)e;
+    double eh = ed * 0x1.62e42fefa3800p-1, el = ed * 0x1.ef35793c76730p-45 + ed * 0x1.f97b57a079a19p-103;
+    double sh, sl; dd_add(eh, el, rh, rl, sh, sl);
+    return sh + sl;
+}
+
+struct NoiseGen {
+    unsigned *st;      // this instance's state words
+    __device__ __forceinline__ unsigned next32()
+    {
+        int pos = (int)st[624];
+        if (pos >= 624) {       // regenerate (numpy's rk_random / init by genrand: the standard twist)
+            for (int k = 0; k < 624; k++) {
+                const unsigned y0 = (st[k] & 0x80000000u) | (st[(k + 1) % 624] & 0x7fffffffu);
+                st[k] = st[(k + 397) % 624] ^ (y0 >> 1) ^ ((y0 & 1u) ? 0x9908b0dfu : 0u);
+            }
+            pos = 0;
+        }
+        unsigned y = st[pos];
+        st[624] = (unsigned)(pos + 1);
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        return y;
+    }
+    __device__ __forceinline__ double next_double()
+    {
+#pragma clang fp contract(off)
+        const unsigned a = next32() >> 5, b = next32() >> 6;
+        return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    }
+    __device__ __forceinline__ double gauss()
+    {
+#pragma clang fp contract(off)
+        if (st[625]) {
+            st[625] = 0u;
+            const double g = __hiloint2double((int)st[627], (int)st[626]);
+            st[626] = 0u; st[627] = 0u;
+            return g;
+        }
+        double x1, x2, r2;
+        do {
+            x1 = 2.0 * next_double() - 1.0;
+            x2 = 2.0 * next_double() - 1.0;
+            const double a = x1 * x1, b = x2 * x2;
+            r2 = a + b;
+        } while (r2 >= 1.0 || r2 == 0.0);
+        const double lg = log_dd(r2);
+        const double q = -2.0 * lg;
+        const double f = sqrt(q / r2);
+        const double g = f * x1;
+        st[625] = 1u; st[626] = (unsigned)__double2loint(g); st[627] = (unsigned)__double2hiint(g);
+        return f * x2;
+    }
+};
+
+// np.random.seed(seed0 + s) followed by the scenario generator's uniform draws (their VALUES come from scenario_kernel; here they are only consumed):
+// 4 n_obst doubles for RANDOM (x, y, vx, vy blocks), 2 n_obst otherwise
+__global__ void noise_init_kernel(int count, int n_obst, int scenario, unsigned seed0, unsigned *__restrict__ state)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= count) return;
+    unsigned *st = state + (size_t)s * kNoiseStateWords;
+    st[0] = seed0 + (unsigned)s;
+    for (int k = 1; k < 624; k++) st[k] = 1812433253u * (st[k - 1] ^ (st[k - 1] >> 30)) + (unsigned)k;
+    st[624] = 624u; st[625] = 0u; st[626] = 0u; st[627] = 0u;
+    NoiseGen g{st};
+    const int draws = (scenario == kScenarioRandom ? 4 : 2) * n_obst;
+    for (int k = 0; k < draws; k++) (void)g.next_double();
+}
+
+// one control step's np.random.normal(size=2) per obstacle, in the reference's order (obstacle 0 first): noise[s][j][0..1]
+__global__ void noise_draw_kernel(int count, int n_obst, unsigned *__restrict__ state, double *__restrict__ noise, const int32_t *__restrict__ ep_flags)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= count) return;
+    if (ep_flags && (ep_flags[s] & 1)) return;      // the episode is over: the reference's loop has left (robot_ocp_problem.py:247-250), nothing is drawn any more
+    NoiseGen g{state + (size_t)s * kNoiseStateWords};
+    double *o = noise + (size_t)s * n_obst * 2;
+    for (int j = 0; j < n_obst; j++) { o[2 * j] = g.gauss(); o[2 * j + 1] = g.gauss(); }
+}
+
 // INSTANCE SCHEDULING.  Where several instances share a wavefront (one lane per stage: 2, 3 or 4 of them) the wavefront runs until its
 // slowest instance has converged, and interior-point iteration counts are heavy-tailed: on the randomized C3 workload the mean is 6.6 but the
 // mean of the per-wavefront maximum is 8.2 with two and 9.4 with three instances per wavefront.  Iteration counts of consecutive control

@@ -765,6 +765,34 @@ int mpc_generate_scenarios(mpc_handle *h, int count, int scenario, unsigned seed
     return MPC_OK;
 }
 
+/* ------------------------------------------------- the reference's noise stream -------------------------------------------------- */
+
+int mpc_noise_state_words(void) { return mpc::kNoiseStateWords; }
+
+int mpc_noise_init_dev(mpc_handle *h, int count, int scenario, unsigned seed0, uint32_t *d_state, void *stream)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    if (count < 0 || scenario < 0 || scenario > 2) return fail(MPC_ERR_ARG, "bad count or scenario");
+    if (count == 0) return MPC_OK;
+    if (!d_state) return fail(MPC_ERR_ARG, "null device pointer");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(mpc::noise_init_kernel, dim3((count + 63) / 64), dim3(64), 0, pick(h, stream), count, h->cfg.n_obst, scenario, seed0, d_state);
+    HIPCHK(hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_noise_draw_dev(mpc_handle *h, int count, uint32_t *d_state, double *d_noise, const int32_t *d_ep_flags, void *stream)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    if (count < 0) return fail(MPC_ERR_ARG, "bad count");
+    if (count == 0) return MPC_OK;
+    if (!d_state || !d_noise) return fail(MPC_ERR_ARG, "null device pointer");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(mpc::noise_draw_kernel, dim3((count + 63) / 64), dim3(64), 0, pick(h, stream), count, h->cfg.n_obst, d_state, d_noise, d_ep_flags);
+    HIPCHK(hipGetLastError());
+    return MPC_OK;
+}
+
 /* ------------------------------------------------- slack schedule -------------------------------------------------- */
 
 int mpc_set_slack_schedule_dev(mpc_handle *h, const double *d_alpha)

@@ -81,6 +81,9 @@ SYMBOLS = {
     "mpc_set_matrix_cores": (C.c_int, [_vp, C.c_int]),
     "mpc_set_row_parallel": (C.c_int, [_vp, C.c_int]),
     "mpc_set_block_riccati": (C.c_int, [_vp, C.c_int]),
+    "mpc_noise_state_words": (C.c_int, []),
+    "mpc_noise_init_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint, _vp, _vp]),
+    "mpc_noise_draw_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     "mpc_generate_scenarios_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint, _vp, _vp, _vp]),
     "mpc_generate_scenarios": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint, _vp, _vp]),
 }

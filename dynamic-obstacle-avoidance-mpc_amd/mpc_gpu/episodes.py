@@ -23,8 +23,11 @@ def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, i
     from the reference generator's draw for np.random.seed(first_seed + s), produced on the device (experiments.py:26-29).
     record=True also returns simX (steps+1,B,5), obst_traj (steps+1,B,n_obst,4) and pred (steps,B,N+1,5): what the reference keeps
     for its visualisation (robot_ocp_problem.py:232-240,270-276).
-    noise: None -> standard normals from torch's generator (`seed`); an array (steps, B, n_obst, 2) -> exactly these normals, control step
-    k using noise[k] (world.reference_streams gives the sequences the reference's own runs consumed, per seed).
+    noise: an array (steps, B, n_obst, 2) -> exactly these normals, control step k using noise[k] (world.reference_streams gives the sequences the
+    reference's own runs consumed, per seed); "reference" -> the same sequences produced ON THE DEVICE per instance (numpy's legacy generator for seed
+    first_seed + s continued behind the scenario draw: mpc_noise_init_dev / mpc_noise_draw_dev, no host upload) -- the default when `obst` is a scenario
+    name, i.e. run_episodes(x0, goal, "RANDOM", first_seed=0) IS experiments.py:20-36 for seeds 0 .. B-1; "torch" (and None with explicit obstacle states)
+    -> standard normals from torch's generator (`seed`).
     interpolate_init: set_initial_guess() is the straight-line variant the reference keeps commented out (robot_ocp_problem.py:293-300; spec key
     `interpolate_init` of two recorded tables) -- at the start and on every status-4 reset.
     status_log: also return, per episode, how many of its solves ended with status 2 / status 4 and the first control step with a status != 0
@@ -32,7 +35,10 @@ def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, i
     Returns dict(table (B,6), x_last (B,5), steps_run, solves)."""
     import torch
     x0 = np.ascontiguousarray(x0, dtype=np.float64); B = x0.shape[0]
-    if isinstance(obst, str):
+    scenario_name = obst if isinstance(obst, str) else None
+    if scenario_name is not None:
+        if noise is None and random_move:
+            noise = "reference"
         with BatchedMpc(N, n_obst, Tf, max_batch=B, device=device) as g:
             obst = g.generate_scenarios(obst, B, seed0=first_seed)
     obst = np.ascontiguousarray(obst, dtype=np.float64); n_obst = obst.shape[1]
@@ -62,16 +68,31 @@ def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, i
             first_bad = torch.full((B,), -1, dtype=torch.int32, device=dev)
         gen = torch.Generator(device=dev); gen.manual_seed(seed)
         dnoise = None
-        if noise is not None and random_move:
+        gen_state, nbuf = None, None
+        if isinstance(noise, str) and noise == "torch":
+            noise = None
+        if isinstance(noise, str):
+            if noise != "reference" or scenario_name is None:
+                raise ValueError("noise='reference' continues the generator of a scenario draw: pass the scenario name as `obst`")
+            if random_move:
+                gen_state = m.noise_state(B, scenario_name, seed0=first_seed, stream=s)
+                nbuf = torch.zeros(B, n_obst, 2, dtype=torch.float64, device=dev)
+        elif noise is not None and random_move:
             noise = np.ascontiguousarray(noise, dtype=np.float64)
             if noise.shape[1:] != (B, n_obst, 2) or noise.shape[0] < max_iter:
                 raise ValueError(f"noise must be (>= {max_iter}, {B}, {n_obst}, 2), got {noise.shape}")
             dnoise = torch.from_numpy(noise).to(dev)
         k = 0
         rec_x, rec_o, rec_p = [dx0.clone()], [dobst.clone()], []
+        # "every instance has reached its goal" without stalling the queue: every 25 control steps the flag goes to pinned host memory behind an event,
+        # and is looked at only once that event has passed (so the loop runs at most ~25 steps longer than it has to -- on idle instances, which cost nothing)
+        done_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        done_event = None
         while k < max_iter:
             if not random_move:
                 nz = None
+            elif gen_state is not None:
+                m.noise_draw_dev(B, gen_state, nbuf, ep_flags=flags, stream=s); nz = nbuf
             elif dnoise is not None:
                 nz = dnoise[k]
             else:
@@ -85,8 +106,13 @@ def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, i
             k += 1
             if record:      # X holds the shifted prediction: stage j of the solve is X[j - 1], stage N is kept (:253-258)
                 rec_x.append(dx0.clone()); rec_o.append(dobst.clone()); rec_p.append(X.clone())
-            if k % 25 == 0 and bool((flags & 1).all().item()):     # every instance reached its goal
-                break
+            if done_event is not None and done_event.query():
+                if int(done_host[0]) == 1:
+                    break
+                done_event = None
+            if k % 25 == 0 and done_event is None:
+                done_host.copy_((flags & 1).min().to(torch.int32).reshape(1), non_blocking=True)
+                done_event = torch.cuda.Event(); done_event.record(stream)
         stream.synchronize()
         fl_h = flags.cpu().numpy(); xl = dx0.cpu().numpy()
         table = np.column_stack([(fl_h & 4) != 0, (fl_h & 1) != 0, margin.cpu().numpy(),

@@ -170,6 +170,17 @@ class BatchedMpc:
         box = self._scenario_box()
         _lib.check(_lib.lib().mpc_generate_scenarios_dev(self._h, count, self.SCENARIOS[scenario], seed0, _ptr(box), _ptr(obst), _ptr(stream)))
 
+    def noise_state(self, count, scenario, seed0=0, stream=None):
+        """device generator states of `count` instances after np.random.seed(seed0 + s) and the scenario draw (a torch int32 tensor)"""
+        import torch
+        st = torch.zeros(count, _lib.lib().mpc_noise_state_words(), dtype=torch.int32, device=torch.device("cuda", self.device))
+        _lib.check(_lib.lib().mpc_noise_init_dev(self._h, count, self.SCENARIOS[scenario], seed0, _ptr(st), _ptr(stream)))
+        return st
+
+    def noise_draw_dev(self, count, state, noise, ep_flags=None, stream=None):
+        """one control step's normals of the reference's stream -> noise (count, n_obst, 2); advances `state`"""
+        _lib.check(_lib.lib().mpc_noise_draw_dev(self._h, count, _ptr(state), _ptr(noise), _ptr(ep_flags), _ptr(stream)))
+
     def terminal_state(self, batch):
         """x_N of the current iterate (the reference reads it at robot_ocp_problem.py:232; hook for a sub-goal policy)"""
         return self.get_traj(batch)[0][:, -1].copy()

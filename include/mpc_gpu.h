@@ -155,6 +155,15 @@ int mpc_plant_step_dev(mpc_handle *h, int batch, const double *d_x, const double
 /* Obstacle.step() ground-truth motion (visualization.py:20-33); d_noise[B*n_obst][2] standard normals or NULL */
 int mpc_obstacle_step_dev(mpc_handle *h, int count, double *d_obst, const double *d_noise,
                           double randomness, double vmax, void *stream);
+/* The reference's NOISE stream on the device (experiments.py:33-36, visualization.py:28-33): instance s carries numpy's legacy generator after
+ * np.random.seed(seed0 + s) and the scenario generator's uniform draws (mpc_generate_scenarios_dev produces those values; here they are consumed), and
+ * mpc_noise_draw_dev writes one control step's np.random.normal(size=2) per obstacle -- d_noise[count][n_obst][2], the array mpc_closed_loop_step_dev
+ * takes -- and advances the state.  d_state: count * mpc_noise_state_words() uint32.  d_ep_flags (optional): instances whose episode is over (bit 0)
+ * draw nothing, like the reference's loop that has left.  Bit for bit numpy's stream except for the last bit of ~1 draw in 10^4 (glibc's log is not
+ * correctly rounded there; the device evaluates it in double-double arithmetic).  No host upload: 13000 episodes x 400 steps of normals are 416 MB. */
+int mpc_noise_state_words(void);
+int mpc_noise_init_dev(mpc_handle *h, int count, int scenario, unsigned seed0, uint32_t *d_state, void *stream);
+int mpc_noise_draw_dev(mpc_handle *h, int count, uint32_t *d_state, double *d_noise, const int32_t *d_ep_flags, void *stream);
 /* generate_random_moving_obstacles (src/utils/obstacle_generator.py:8-28) for the seeds seed0 .. seed0+count-1: instance s gets
  * bit for bit what the reference draws after np.random.seed(seed0 + s) (numpy legacy MT19937 stream, reference draw order).
  * scenario: 0 RANDOM, 1 CENTER, 2 EDGE (:10-18).  box = {X_MIN_OBST, X_MAX_OBST, Y_MIN_OBST, Y_MAX_OBST, V_MAX_OBST, edge (7)}
