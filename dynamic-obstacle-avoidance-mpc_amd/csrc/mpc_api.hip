@@ -5,7 +5,9 @@
 #include "rti_kernel.hpp"
 #include "rti_split_kernel.hpp"
 
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types and enums only: the functions are resolved from librccl.so.1 on first use (no link-time dependency)
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -62,6 +64,10 @@ struct mpc_handle {
     const double *d_alpha;            // slack schedule in effect: d_alpha_own, a caller's device array, or null (the reference's formula)
     std::vector<hipEvent_t> ev_start, ev_stop;
     int ev_used;
+    ncclComm_t comm;                  // RCCL communicator of the cost exchange (mpc_comm_init), or null
+    int comm_rank, comm_world;
+    double *d_gather_in, *d_gather_out;   // staging of the host-pointer all-gather
+    size_t gather_cap;                // ... and its capacity in doubles of d_gather_in
 };
 
 namespace {
@@ -450,6 +456,9 @@ int mpc_destroy(mpc_handle *h)
     for (auto e : h->ev_start) (void)hipEventDestroy(e);
     for (auto e : h->ev_stop) (void)hipEventDestroy(e);
     if (h->sched_done) (void)hipEventDestroy(h->sched_done);
+    (void)mpc_comm_destroy(h);
+    if (h->d_gather_in) (void)hipFree(h->d_gather_in);
+    if (h->d_gather_out) (void)hipFree(h->d_gather_out);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MPC_OK;
@@ -790,6 +799,121 @@ int mpc_noise_draw_dev(mpc_handle *h, int count, uint32_t *d_state, double *d_no
     HIPCHK(hipSetDevice(h->device));
     hipLaunchKernelGGL(mpc::noise_draw_kernel, dim3((count + 63) / 64), dim3(64), 0, pick(h, stream), count, h->cfg.n_obst, d_state, d_noise, d_ep_flags);
     HIPCHK(hipGetLastError());
+    return MPC_OK;
+}
+
+/* ------------------------------------------------- multi-GPU: all-gather of the costs over RCCL -------------------------------------------------- */
+
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.lib) return MPC_OK;
+    void *lib = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+    if (!lib) return fail(MPC_ERR_HIP, "librccl.so.1 not found (%s): the cost exchange has no other transport", dlerror());
+    Rccl r; r.lib = lib;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    r.AllGather = (decltype(r.AllGather))dlsym(lib, "ncclAllGather");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString) { dlclose(lib); return fail(MPC_ERR_HIP, "librccl lacks an entry point of the cost exchange"); }
+    g_rccl = r;
+    return MPC_OK;
+}
+#define RCCLCHK(expr)                                                                                   \
+    do {                                                                                                \
+        ncclResult_t r_ = (expr);                                                                       \
+        if (r_ != ncclSuccess) return fail(MPC_ERR_HIP, "%s: %s", #expr, g_rccl.GetErrorString(r_));    \
+    } while (0)
+}  // namespace
+
+int mpc_comm_unique_id(unsigned char *id)
+{
+    static_assert(sizeof(ncclUniqueId) == MPC_COMM_ID_BYTES, "MPC_COMM_ID_BYTES is RCCL's ncclUniqueId");
+    if (!id) return fail(MPC_ERR_ARG, "null id buffer");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MPC_ERR_NODEVICE, "no HIP device visible: libmpcgpu has no CPU path");
+    int rc = rccl_load(); if (rc) return rc;
+    ncclUniqueId u;
+    RCCLCHK(g_rccl.GetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return MPC_OK;
+}
+
+int mpc_comm_init(mpc_handle *h, int rank, int world, const unsigned char *id)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(MPC_ERR_ARG, "bad rank / world / id");
+    if (h->comm) return fail(MPC_ERR_ARG, "the handle has a communicator already (mpc_comm_destroy first)");
+    int rc = rccl_load(); if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    RCCLCHK(g_rccl.CommInitRank(&h->comm, world, u, rank));
+    h->comm_rank = rank; h->comm_world = world;
+    return MPC_OK;
+}
+
+int mpc_comm_world(const mpc_handle *h) { return h && h->comm ? h->comm_world : 0; }
+
+int mpc_comm_destroy(mpc_handle *h)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    if (!h->comm) return MPC_OK;
+    (void)hipSetDevice(h->device);
+    ncclComm_t c = h->comm;
+    h->comm = nullptr; h->comm_world = 0; h->comm_rank = 0;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->d_gather_in) { (void)hipFree(h->d_gather_in); h->d_gather_in = nullptr; }          // sized for this communicator's world
+    if (h->d_gather_out) { (void)hipFree(h->d_gather_out); h->d_gather_out = nullptr; }
+    h->gather_cap = 0;
+    RCCLCHK(g_rccl.CommDestroy(c));
+    return MPC_OK;
+}
+
+int mpc_allgather_cost_dev(mpc_handle *h, int count, const double *d_cost, double *d_cost_all, void *stream)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    if (!h->comm) return fail(MPC_ERR_ARG, "no communicator: mpc_comm_init first");
+    if (count < 0) return fail(MPC_ERR_ARG, "bad count");
+    if (count == 0) return MPC_OK;
+    if (!d_cost || !d_cost_all) return fail(MPC_ERR_ARG, "null device pointer");
+    HIPCHK(hipSetDevice(h->device));
+    RCCLCHK(g_rccl.AllGather(d_cost, d_cost_all, (size_t)count, ncclDouble, h->comm, pick(h, stream)));
+    return MPC_OK;
+}
+
+int mpc_allgather_cost(mpc_handle *h, int count, const double *cost, double *cost_all)
+{
+    if (!h) return fail(MPC_ERR_ARG, "null handle");
+    if (!h->comm) return fail(MPC_ERR_ARG, "no communicator: mpc_comm_init first");
+    if (count < 0) return fail(MPC_ERR_ARG, "bad count");
+    if (count == 0) return MPC_OK;
+    if (!cost || !cost_all) return fail(MPC_ERR_ARG, "null pointer");
+    HIPCHK(hipSetDevice(h->device));
+    if ((size_t)count > h->gather_cap) {
+        if (h->d_gather_in) { (void)hipFree(h->d_gather_in); h->d_gather_in = nullptr; }
+        if (h->d_gather_out) { (void)hipFree(h->d_gather_out); h->d_gather_out = nullptr; }
+        h->gather_cap = 0;
+        HIPCHK(hipMalloc(&h->d_gather_in, (size_t)count * sizeof(double)));
+        HIPCHK(hipMalloc(&h->d_gather_out, (size_t)count * h->comm_world * sizeof(double)));
+        h->gather_cap = (size_t)count;
+    }
+    HIPCHK(hipMemcpyAsync(h->d_gather_in, cost, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    int rc = mpc_allgather_cost_dev(h, count, h->d_gather_in, h->d_gather_out, nullptr); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(cost_all, h->d_gather_out, (size_t)count * h->comm_world * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return MPC_OK;
 }
 

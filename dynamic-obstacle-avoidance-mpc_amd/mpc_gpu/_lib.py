@@ -15,6 +15,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 
 MPC_OK, MPC_ERR_ARG, MPC_ERR_HIP, MPC_ERR_NODEVICE = 0, -1, -2, -3
 STEP_SHIFT, STEP_PLANT, STEP_OBSTACLES, STEP_RESET_ON_FAIL, STEP_ALIAS_BUG, STEP_METRICS, STEP_INTERP_GUESS = 1, 2, 4, 8, 16, 32, 64
+COMM_ID_BYTES = 128      # MPC_COMM_ID_BYTES (RCCL unique id)
 
 _d = C.c_double
 _i32 = C.c_int32
@@ -84,6 +85,12 @@ SYMBOLS = {
     "mpc_noise_state_words": (C.c_int, []),
     "mpc_noise_init_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint, _vp, _vp]),
     "mpc_noise_draw_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "mpc_comm_unique_id": (C.c_int, [_vp]),
+    "mpc_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "mpc_comm_world": (C.c_int, [_vp]),
+    "mpc_allgather_cost_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "mpc_allgather_cost": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "mpc_comm_destroy": (C.c_int, [_vp]),
     "mpc_generate_scenarios_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint, _vp, _vp, _vp]),
     "mpc_generate_scenarios": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint, _vp, _vp]),
 }

@@ -181,6 +181,38 @@ class BatchedMpc:
         """one control step's normals of the reference's stream -> noise (count, n_obst, 2); advances `state`"""
         _lib.check(_lib.lib().mpc_noise_draw_dev(self._h, count, _ptr(state), _ptr(noise), _ptr(ep_flags), _ptr(stream)))
 
+    # ------------------------------------------------------------------ multi-GPU: all-gather of the costs, RCCL called by the library itself
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes that rank 0 creates and hands to every rank (any transport: a file, a socket, torch.distributed's store)"""
+        buf = (C.c_ubyte * _lib.COMM_ID_BYTES)()
+        _lib.check(_lib.lib().mpc_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, rank, world, unique_id):
+        """collective: this handle becomes rank `rank` of `world` of the cost exchange"""
+        if len(unique_id) != _lib.COMM_ID_BYTES:
+            raise ValueError(f"unique_id must be {_lib.COMM_ID_BYTES} bytes")
+        buf = (C.c_ubyte * _lib.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _lib.check(_lib.lib().mpc_comm_init(self._h, int(rank), int(world), buf))
+
+    def comm_world(self):
+        return int(_lib.lib().mpc_comm_world(self._h))
+
+    def comm_destroy(self):
+        _lib.check(_lib.lib().mpc_comm_destroy(self._h))
+
+    def allgather_cost_dev(self, count, cost, cost_all, stream=None):
+        """collective: cost (count,) of every rank -> cost_all (world, count), rank-major; device arrays, enqueued on `stream`"""
+        _lib.check(_lib.lib().mpc_allgather_cost_dev(self._h, int(count), _ptr(cost), _ptr(cost_all), _ptr(stream)))
+
+    def allgather_cost(self, cost):
+        """collective, host arrays: returns (world, count)"""
+        cost = _f64(cost).ravel()
+        out = np.empty((self.comm_world(), cost.size))
+        _lib.check(_lib.lib().mpc_allgather_cost(self._h, int(cost.size), _ptr(cost), _ptr(out)))
+        return out
+
     def terminal_state(self, batch):
         """x_N of the current iterate (the reference reads it at robot_ocp_problem.py:232; hook for a sub-goal policy)"""
         return self.get_traj(batch)[0][:, -1].copy()

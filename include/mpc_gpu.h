@@ -164,6 +164,20 @@ int mpc_obstacle_step_dev(mpc_handle *h, int count, double *d_obst, const double
 int mpc_noise_state_words(void);
 int mpc_noise_init_dev(mpc_handle *h, int count, int scenario, unsigned seed0, uint32_t *d_state, void *stream);
 int mpc_noise_draw_dev(mpc_handle *h, int count, uint32_t *d_state, double *d_noise, const int32_t *d_ep_flags, void *stream);
+/* MULTI-GPU: one process per GPU, every rank solves its own contiguous slice of the scenarios (the reference's 13 000 closed
+ * loops, experiments.py:20-36, are independent), and the only exchange is an all-gather of the per-instance costs -- RCCL over xGMI, called directly
+ * from this library (librccl.so.1 is loaded on first use; there is no link-time dependency and no other transport).  A C host does:
+ *   rank 0: mpc_comm_unique_id(id), ships the 128 bytes to the other ranks by whatever means it has (a file, a socket, MPI);
+ *   every rank: mpc_comm_init(h, rank, world, id)  [collective];  per round: mpc_allgather_cost_dev(h, count, d_cost, d_all, stream)  [collective,
+ *   d_all[world][count], rank-major, equal counts on all ranks; enqueued on `stream` (NULL: the handle's), so it overlaps whatever runs on other streams];
+ *   mpc_comm_destroy(h) (mpc_destroy does it too).  mpc_allgather_cost is the host-pointer form (stages through the handle's stream and waits). */
+#define MPC_COMM_ID_BYTES 128
+int mpc_comm_unique_id(unsigned char *id /* MPC_COMM_ID_BYTES */);
+int mpc_comm_init(mpc_handle *h, int rank, int world, const unsigned char *id /* MPC_COMM_ID_BYTES */);
+int mpc_comm_world(const mpc_handle *h);      /* ranks of the handle's communicator, 0 without one */
+int mpc_allgather_cost_dev(mpc_handle *h, int count, const double *d_cost, double *d_cost_all, void *stream);
+int mpc_allgather_cost(mpc_handle *h, int count, const double *cost, double *cost_all);
+int mpc_comm_destroy(mpc_handle *h);
 /* generate_random_moving_obstacles (src/utils/obstacle_generator.py:8-28) for the seeds seed0 .. seed0+count-1: instance s gets
  * bit for bit what the reference draws after np.random.seed(seed0 + s) (numpy legacy MT19937 stream, reference draw order).
  * scenario: 0 RANDOM, 1 CENTER, 2 EDGE (:10-18).  box = {X_MIN_OBST, X_MAX_OBST, Y_MIN_OBST, Y_MAX_OBST, V_MAX_OBST, edge (7)}

@@ -58,6 +58,8 @@ def test_no_device_means_loud_failure_not_a_fallback(lib):
         mpc_gpu.BatchedMpc(20, 3, 2.0)
     with pytest.raises(mpc_gpu.MpcError):
         mpc_gpu.solve([0, 0, 0, 0, 0], [[1, 1, 0, 0]] * 3, [1, 1])
+    buf = (C.c_ubyte * lib.COMM_ID_BYTES)()
+    assert L.mpc_comm_unique_id(buf) == lib.MPC_ERR_NODEVICE           # the cost exchange is RCCL between GPUs, nothing else
 
 
 def test_argument_validation_without_device(lib):
@@ -73,6 +75,9 @@ def test_argument_validation_without_device(lib):
     assert L.mpc_create(C.byref(cfg), 0, 0, C.byref(h)) == lib.MPC_ERR_ARG
     assert L.mpc_solve(None, 1, None, None, None, None, None, None, None) == lib.MPC_ERR_ARG
     assert L.mpc_destroy(None) == 0
+    assert L.mpc_comm_unique_id(None) == lib.MPC_ERR_ARG and L.mpc_comm_init(None, 0, 1, None) == lib.MPC_ERR_ARG
+    assert L.mpc_allgather_cost_dev(None, 1, None, None, None) == lib.MPC_ERR_ARG and L.mpc_allgather_cost(None, 1, None, None) == lib.MPC_ERR_ARG
+    assert L.mpc_comm_world(None) == 0
 
 
 def test_product_does_not_touch_the_oracle():

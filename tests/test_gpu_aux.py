@@ -386,3 +386,51 @@ def test_episodes_from_a_scenario_name_are_the_reference_experiment(env):
     assert same.sum() >= 95, same.sum()
     stable = [0, 2, 3, 4, 5, 24, 25, 36, 41, 53, 63, 65, 66, 69, 76, 79, 80, 81, 82, 84, 95]
     assert same[stable].all()
+
+
+@pytest.mark.gpu
+def test_cost_exchange_through_the_c_abi(env):
+    """mpc_comm_* / mpc_allgather_cost(_dev): the all-gather of the per-instance costs as the library's own RCCL call.  One GPU here, so the
+    communicator has ONE rank (RCCL refuses two ranks on one device): the collective really runs -- librccl loaded, communicator built from the unique id,
+    ncclAllGather enqueued on the caller's stream -- and must return the rank's own costs; the rank-major layout for world > 1 is RCCL's contract, and the
+    multi-rank slicing around it is covered by the gloo tests of tests/test_host_logic.py.  Plus the refusals: no communicator, a second init, a short id."""
+    import torch
+    mpc_gpu, _ = env
+    dev = torch.device("cuda:0")
+    with mpc_gpu.BatchedMpc(20, 3, 2.0, max_batch=64) as s:
+        assert s.comm_world() == 0
+        with pytest.raises(mpc_gpu.MpcError, match="no communicator"):
+            s.allgather_cost(np.arange(4.0))
+        uid = mpc_gpu.BatchedMpc.comm_unique_id()
+        assert len(uid) == 128 and any(uid)
+        with pytest.raises(ValueError):
+            s.comm_init(0, 1, uid[:64])
+        with pytest.raises(mpc_gpu.MpcError):
+            s.comm_init(1, 1, uid)                    # rank outside the world
+        s.comm_init(0, 1, uid)
+        assert s.comm_world() == 1
+        with pytest.raises(mpc_gpu.MpcError, match="already"):
+            s.comm_init(0, 1, uid)
+        rng = np.random.default_rng(5)
+        for count in (1, 64, 4097):                   # the host form grows its staging
+            c = rng.normal(size=count)
+            out = s.allgather_cost(c)
+            assert out.shape == (1, count) and (out[0] == c).all()
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            q = torch.cuda.current_stream().cuda_stream
+            # costs of a real solve, gathered on the stream the solve ran on
+            x0, goal, obst = random_batch(64, 3, seed=11)
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            X = torch.zeros(64, 21, 5, dtype=torch.float64, device=dev); U = torch.zeros(64, 20, 2, dtype=torch.float64, device=dev)
+            cost = torch.zeros(64, dtype=torch.float64, device=dev); allc = torch.full((1, 64), -1.0, dtype=torch.float64, device=dev)
+            dx0, dg, do = t(x0), t(goal), t(obst)
+            P = torch.zeros(64, 21, 3, 2, dtype=torch.float64, device=dev)
+            s.reset_guess_dev(64, dx0, X, U, stream=q); s.predict_dev(64, do, P, stream=q)
+            s.solve_dev(64, dx0, P, dg, X, U, cost=cost, stream=q)
+            s.allgather_cost_dev(64, cost, allc, stream=q)
+            torch.cuda.current_stream().synchronize()
+            assert (allc[0] == cost).all() and float(cost.abs().sum()) > 0
+        s.comm_destroy(); s.comm_destroy()            # idempotent
+        assert s.comm_world() == 0
+        s.comm_init(0, 1, mpc_gpu.BatchedMpc.comm_unique_id())      # a new communicator on the same handle
+        assert (s.allgather_cost(np.ones(3)) == 1.0).all()
