@@ -229,7 +229,7 @@ def cpu_baseline(N, n_obst, x0, goal, obst, budget_s=24.0):
     (oracle/Makefile: liborc_bench.so); the checker the tests use stays -O2 without contraction."""
     from oracle import oracle as orc
     orc.use_bench_build()
-    cfg = orc.config(N, n_obst, 0.1 * N, qp_tol=1e-8)
+    cfg = orc.config(N, n_obst, 0.1 * N)      # the library's defaults (qp_tol 1e-10)
     ncpu = os.cpu_count() or 1
     dt = 0.1
 
@@ -503,12 +503,12 @@ def main():
            "value": value, "unit": "solves/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["elapsed"] / args.steps * 1e3, "higher_is_better": True,
            "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": desc, "global_batch": G, "per_gpu_batch": hi - lo, "N": N, "n_obst": no, "qp_tol": 1e-8, "qp_iter_max": 50,
+           "config": {"workload": desc, "global_batch": G, "per_gpu_batch": hi - lo, "N": N, "n_obst": no, "qp_tol": float(loop.m.cfg.qp_tol), "qp_iter_max": int(loop.m.cfg.qp_iter_max),
                       "step": f"one episode of the whole batch = set_initial_guess + {EPISODE} closed-loop control steps; a control step is ONE fused "
                               "launch (obstacle look-ahead + RTI solve + plant step + obstacle motion + warm-start shift), device resident",
                       "control_steps_per_step": EPISODE, "solves_per_step": G * EPISODE,
-                      "comparability": ("whole episodes (10.7 interior-point iterations per solve; 11.5 with round 1's interior-point constants: 6.95e6 solves/s); round 1's driver line timed control steps 5-25 of one "
-                                        "episode (7.5 iterations per solve: 9.4e6 solves/s) and its own 500-step run gave 6.95e6 -- the C2 kernel is the same")
+                      "comparability": ("whole episodes at qp_tol 1e-10 (round 3: the tolerance at which the reference's recorded closed loops come back best, DESIGN.md section 2; 11.2 interior-point "
+                                        "iterations per solve); rounds 1-2 ran qp_tol 1e-8 (10.7 iterations: 7.4-7.5e6 solves/s with the same kernel)")
                                        if args.workload == "c2" else None,
                       "parallelism": (f"batch slices over {world} ranks (mpc_gpu.sharding.shard_slice), no data-path collective; per-scenario costs "
                                       f"all-gathered over RCCL, {GATHER_EVERY} control steps per message") if world > 1 else "single GPU"},

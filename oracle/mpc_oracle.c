@@ -46,7 +46,7 @@ void orc_default_config(orc_config *c, int N, int n_obst, double Tf)
     c->r_safe = 1.0 + 0.2 + 1.2;                      /* robot_model.py:62 */
     c->slack_a = 1e4; c->slack_b = 50.0;              /* :146 */
     c->qp_iter_max = 50;                              /* world_specification.py:48 */
-    c->qp_tol = 1e-8;
+    c->qp_tol = 1e-10;
     c->cost_scale_dt = 1; c->slack_scale_dt = 1; c->lm_scaled = 1;   /* lm_scaled: see DESIGN.md section 2 (statistical pin) */ c->bx_terminal = 0; c->soft_h = 1;
     c->arena[0] = -8.0; c->arena[1] = 8.0; c->arena[2] = -8.0; c->arena[3] = 8.0;
     c->bug_compat_predict = 1;

@@ -23,7 +23,7 @@ while time.time() - t0 < budget:
     x0, goal, obst = random_batch(B, no, seed=seed)
     x0[:, 3] = rng.uniform(-0.5, 1.5, B)
     noise = np.random.default_rng(seed).standard_normal((K, B, no, 2))
-    cfg = orc.config(N, no, 0.1 * N, qp_tol=1e-8)
+    cfg = orc.config(N, no, 0.1 * N)
     rec = dict(N=N, n_obst=no, B=B, alias=alias, lps=lps, lanes=lanes, seed=seed)
     mpc_gpu.BatchedMpc.default_lanes_per_stage = lps
     try:

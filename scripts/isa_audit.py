@@ -17,6 +17,12 @@ Rules (LLVM GCNHazardRecognizer for gfx940-class parts; a "wait state" is one is
       split copy or a spill placed there silently loses the other lanes' values.  Found as `v_accvgpr_write_b32 a0, v106` (the instance index) in
       front of the exec restore in one build of rti_solve_kernel<10, 64, 3>: its status / iteration / cost stores went to wrong addresses.
 
+  P2  (the same kind: a second register-allocator defect of this toolchain)  a TORN TUPLE SPILL: a run of v_writelane_b32 that saves
+      consecutive scalar registers into consecutive lanes of one VGPR (the spill of ONE wide scalar value) whose registers were last written by TWO different
+      s_load instructions with overlapping destinations, the later one having overwritten part of the earlier one's destination before anything read it.
+      Found in rti_solve_kernel<3, 32, 2>: `s_load_dwordx16 s[12:27], .. 0x1c8` (iters_acc, status_acc, ...) followed by a re-materialised
+      `s_load_dwordx8 s[8:15], .. 0x248` (ep_min_margin .. trace), then s12..s27 spilled as one value: `iters_acc` became the pointer to the step counter.
+
 The scan is linear over the listing (branches are not followed): a hazard window that straddles a taken backward branch is checked by
 treating the loop body as falling through into itself once (labels 1: ... s_cbranch 1b inside an asm block are unrolled once).
 Only pairs with at least one instruction INSIDE an asm block (between ;;#ASMSTART and ;;#ASMEND) are reported by default; --all reports
@@ -156,6 +162,79 @@ def prologue_findings(path, kernel=None):
     return out
 
 
+def torn_spill_findings(path, kernel=None):
+    """P2: see the module docstring.  Linear scan per kernel; last[s] = index of the s_load that last wrote scalar register s (None: something else did)."""
+    lines = open(path).read().split("\n")
+    out, cur, active = [], None, kernel is None
+    last, loads, run = {}, [], []          # run = pending v_writelane entries (line, vgpr, sreg, lane, last def of sreg)
+
+    def flush():
+        nonlocal run
+        groups, g = [], []
+        for e in sorted(run, key=lambda e: (e[1], e[2] - e[3], e[2])):
+            if g and (e[1] != g[-1][1] or e[2] - e[3] != g[-1][2] - g[-1][3] or e[2] != g[-1][2] + 1):
+                groups.append(g); g = []
+            g.append(e)
+        if g:
+            groups.append(g)
+        for g in groups:
+            if len(g) < 4:
+                continue
+            defs = {e[2]: e[4] for e in g}
+            ids = sorted({d for d in defs.values() if d is not None})
+            for ia in ids:
+                for ib in ids:
+                    A, B = loads[ia], loads[ib]
+                    torn = B["tore"].get(ia, set())       # registers of A that B overwrote before anything had read them
+                    if ib <= ia or not torn:
+                        continue
+                    keptA = [r for r in defs if defs[r] == ia]
+                    tornB = [r for r in defs if defs[r] == ib and r in torn]
+                    if keptA and tornB:
+                        out.append((cur, g[0][0] + 1, f"s[{g[0][2]}:{g[-1][2]}] -> {g[0][1]} lanes {g[0][3]}..{g[-1][3]}", A["line"] + 1, A["text"], B["line"] + 1, B["text"],
+                                    f"s[{min(tornB)}:{max(tornB)}]"))
+        run = []
+
+    for ln, raw in enumerate(lines):
+        t = raw.strip()
+        m = re.match(r"^([_A-Za-z0-9.$]+):", t)
+        if m:
+            if not t.startswith(".L"):
+                flush(); cur = m.group(1); active = kernel is None or kernel in cur; last, loads = {}, []
+            continue
+        if not active or not t or t.startswith((";", ".")):
+            continue
+        op = t.split()[0]
+        ops = split_ops(t[len(op):])
+        if op == "v_writelane_b32" and len(ops) >= 3 and regs(ops[1], "s") and re.fullmatch(r"\d+", ops[2]):
+            sreg = regs(ops[1], "s")[0]
+            run.append((ln, ops[0], sreg, int(ops[2]), last.get(sreg)))       # (saving a register is not a use of its value)
+            continue
+        if op.startswith(("s_cbranch", "s_branch", "s_endpgm")) or len(run) > 64:
+            flush()
+        no_dst = op.startswith(("s_cmp", "s_bitcmp", "s_nop", "s_waitcnt", "s_cbranch", "s_branch", "s_endpgm", "s_barrier", "s_setprio", "s_sleep", "global_store", "ds_write",
+                                "buffer_store", "flat_store", "scratch_store"))
+        for o in (ops if no_dst else ops[1:]):
+            for r in regs(o, "s"):
+                if last.get(r) is not None:
+                    loads[last[r]]["read"].add(r)
+        if op.startswith("s_load_dword") and ops:
+            dst = regs(ops[0], "s")
+            rec = dict(line=ln, text=t, regs=dst, read=set(), tore={})
+            for ia, A in enumerate(loads):
+                unread = (set(A["regs"]) & set(dst)) - A["read"]
+                if unread:
+                    rec["tore"][ia] = unread
+            loads.append(rec)
+            for r in dst:
+                last[r] = len(loads) - 1
+        elif not no_dst and ops and op.startswith(("s_", "v_readlane", "v_readfirstlane", "v_cmp")):
+            for r in regs(ops[0], "s"):
+                last[r] = None
+    flush()
+    return out
+
+
 def main():
     path = sys.argv[1]
     report_all = "--all" in sys.argv
@@ -211,6 +290,9 @@ def main():
     for kern, lab, l2, t2, ln, rest in prologue_findings(path, kernel):
         found += 1
         print(f"P1 per-lane instruction ahead of the exec restore of block {lab} (reached by s_cbranch_execz), in {kern}\n   L{l2}: {t2}\n   L{ln}: {rest}")
+    for kern, ln, what, la, ta, lb, tb, torn in torn_spill_findings(path, kernel):
+        found += 1
+        print(f"P2 torn tuple spill in {kern}: L{ln} saves {what} as one value, but {torn} of it were overwritten before anything read them\n   L{la}: {ta}\n   L{lb}: {tb}")
     print(f"{len(ins)} instructions scanned, {found} finding(s)")
     return 1 if found else 0
 

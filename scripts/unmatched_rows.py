@@ -31,7 +31,7 @@ def matches(tb, rows):
 def oracle_episode(sp, seed, obst, noise, interp, alias):
     from oracle import oracle as orc
     from helpers import OracleLoop
-    cfg = orc.config(sp["N_SOLV"], 5, float(sp["TF"]), qp_tol=1e-8, qp_iter_max=sp["QP_ITER"])
+    cfg = orc.config(sp["N_SOLV"], 5, float(sp["TF"]), qp_iter_max=sp["QP_ITER"])
     lp = OracleLoop(orc, cfg, [-7.0, -7.0, np.pi / 4, 0, 0], [7.0, 7.0], obst[seed], reset_on_fail=True, alias=alias, interp=interp)
     n2 = n4 = 0
     for k in range(400):

@@ -57,8 +57,8 @@ def judge_against_oracle(orc, cfg, x0, P, goal, X0, U0, g, Xg, Ug, o, tol_x=1e-6
         interior point, it is judged by the QP itself (qp_merit): the GPU's step satisfies the linearised dynamics and the boxes to 1e-7 and its QP objective
         does not exceed the oracle's;
       * the iteration counts are equal, or they differ by at most 2 AND the oracle's own record shows the end-game: where the earlier side stopped, the
-        oracle's largest complementarity product was already within four decades of the tolerance (the last, superlinear iterations, where a rounding
-        difference decides whether the tolerance is met one iteration sooner).
+        oracle's largest complementarity product was already below 1e-4 (the last, superlinear iterations: from there ONE step takes it to ~1e-10, and a
+        rounding difference decides whether that step lands under the tolerance or just above it).
     Returns the numbers of instances that took each escape, for the caller to bound or report."""
     B = x0.shape[0]
     cap, tol = cfg.qp_iter_max, cfg.qp_tol
@@ -89,7 +89,7 @@ def judge_against_oracle(orc, cfg, x0, P, goal, X0, U0, g, Xg, Ug, o, tol_x=1e-6
             assert abs(ig - io) <= 2, f"instance {b}: {ig} (GPU) vs {io} (oracle) interior-point iterations"
             tr = orc.rti_solve_trace(cfg, x0[b], P[b], goal[b], X0[b], U0[b], alpha=None if alpha is None else alpha[b])["trace"]
             m = min(ig, io)
-            assert m >= 1 and tr[min(m, len(tr) - 1), 3] <= 1e4 * tol, f"instance {b}: iteration counts {ig} / {io} differ away from the end-game (oracle cmax {tr[min(m, len(tr) - 1), 3]:.2e} at iteration {m})"
+            assert m >= 1 and tr[min(m, len(tr) - 1), 3] <= max(1e4 * tol, 1e-4), f"instance {b}: iteration counts {ig} / {io} differ away from the end-game (oracle cmax {tr[min(m, len(tr) - 1), 3]:.2e} at iteration {m})"
             n["iter_borderline"] += 1
     return n
 
@@ -197,3 +197,52 @@ class OraclePlant:
 
     def get(self, fieldname):
         return self.x.copy()
+
+
+def exact_from_active_set(q, v0, tol=1e-7):
+    """The solution of an exported QP (oracle.export_qp) that owes the interior point nothing but the GUESS of the active set: the active rows are read off the
+    candidate v0 (bounds, soft rows h + C v + s >= 0, s >= 0 within `tol`), the equality-constrained QP on them is solved by one dense KKT system (equilibrated,
+    iterative refinement with the residual in extended precision: the slack penalties reach 4e6 next to O(0.1) curvature), and the caller verifies the KKT
+    conditions of the full QP with what comes back: (v, smallest multiplier of an active row, smallest constraint value, number of active rows, stationarity
+    residual).  Multipliers >= 0 and constraints >= 0 to rounding => v is the unique minimiser of the strictly convex QP.  Test infrastructure."""
+    nv, ns = q["H"].shape[0], len(q["hs"])
+    n = nv + ns
+    H = np.zeros((n, n)); H[:nv, :nv] = q["H"]; H[nv:, nv:] = np.diag(q["Zs"])
+    g = np.concatenate([q["g"], q["zs"]])
+    # slack values implied by v0: s = max(0, -(hs + Cs v)) is the minimiser for a given v when the penalty is positive ... take the interior point's own active set instead
+    rho = q["hs"] + q["Cs"] @ v0
+    s0 = np.maximum(0.0, -rho)
+    rows = []      # equality rows E x = e
+    rhs = []
+    for r in range(q["Aeq"].shape[0]):
+        rows.append(np.concatenate([q["Aeq"][r], np.zeros(ns)])); rhs.append(q["beq"][r])
+    ineq = []      # (row, rhs, sign) of the active inequality rows, written as  a x >= b
+    for v in range(nv):
+        if np.isfinite(q["lb"][v]) and v0[v] - q["lb"][v] < tol:
+            a = np.zeros(n); a[v] = 1.0; ineq.append((a, q["lb"][v]))
+        if np.isfinite(q["ub"][v]) and q["ub"][v] - v0[v] < tol:
+            a = np.zeros(n); a[v] = -1.0; ineq.append((a, -q["ub"][v]))
+    for j in range(ns):
+        if rho[j] + s0[j] < tol:          # hs + Cs v + s >= 0 active
+            a = np.zeros(n); a[:nv] = q["Cs"][j]; a[nv + j] = 1.0; ineq.append((a, -q["hs"][j]))
+        if s0[j] < tol:                   # s >= 0 active
+            a = np.zeros(n); a[nv + j] = 1.0; ineq.append((a, 0.0))
+    E = np.array(rows + [a for a, _ in ineq]); e = np.array(rhs + [b for _, b in ineq])
+    m = E.shape[0]
+    K = np.block([[H, -E.T], [E, np.zeros((m, m))]])
+    b = np.concatenate([-g, e])
+    # the slack penalties (up to 4e6) next to O(0.1) curvature make K ill-conditioned: equilibrate, then iterative refinement with the residual in extended precision
+    dsc = 1.0 / np.sqrt(np.maximum(np.abs(K).max(axis=1), 1e-300))
+    Ks = K * dsc[:, None] * dsc[None, :]
+    Kl, bl = K.astype(np.longdouble), b.astype(np.longdouble)
+    sol = dsc * np.linalg.lstsq(Ks, dsc * b, rcond=1e-15)[0]
+    for _ in range(6):
+        r = (bl - Kl @ sol.astype(np.longdouble)).astype(np.float64)
+        sol = sol + dsc * np.linalg.lstsq(Ks, dsc * r, rcond=1e-15)[0]
+    x, lam = sol[:n], sol[n:]
+    lam_in = lam[len(rows):]
+    # verification of the KKT conditions on the full QP
+    v, s = x[:nv], x[nv:]
+    feas = min(np.min(v - q["lb"]), np.min(q["ub"] - v), np.min(q["hs"] + q["Cs"] @ v + s) if ns else 0.0, np.min(s) if ns else 0.0)
+    res = float(np.abs((bl - Kl @ sol.astype(np.longdouble)).astype(np.float64)[:n]).max())      # stationarity residual of the refined solve
+    return v, float(lam_in.min()) if len(lam_in) else 0.0, float(feas), len(ineq), res

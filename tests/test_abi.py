@@ -39,10 +39,10 @@ def test_default_config_matches_reference_constants_and_oracle(lib):
         a, b = getattr(cfg, name), getattr(o, name)
         if hasattr(a, "__len__"):
             assert list(a) == list(b), name
-        elif name != "qp_tol":
+        else:
             assert a == b, name
     assert list(cfg.W) == [2, 2, 2, 2, 0.15, 0.15] and list(cfg.We) == [5, 5, 5, 5] and cfg.lm == 2.0
-    assert cfg.r_safe == pytest.approx(2.4) and cfg.qp_iter_max == 50 and list(cfg.bu_hi) == [8, 8]
+    assert cfg.r_safe == pytest.approx(2.4) and cfg.qp_iter_max == 50 and list(cfg.bu_hi) == [8, 8] and cfg.qp_tol == 1e-10
 
 
 def test_no_device_means_loud_failure_not_a_fallback(lib):

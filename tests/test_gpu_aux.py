@@ -77,7 +77,7 @@ def test_python_solve_surface_scalar_and_batched(env):
     np.random.seed(0)
     obstacles = W.generate_random_moving_obstacles("RANDOM", False, n_obst=3)
     x0 = np.array([-6.0, -6.0, np.pi / 4, 0, 0]); ref = np.array([6.0, 6.0])
-    cfg = orc.config(20, 3, 2.0, qp_tol=1e-8)
+    cfg = orc.config(20, 3, 2.0)
     P = orc.predict_params(cfg, W.obstacle_states(obstacles))
     Xg, Ug = orc.initial_guess(cfg, x0)
     want = orc.rti_solve(cfg, x0, P, ref, Xg, Ug)["u0"]
@@ -104,7 +104,7 @@ def test_reference_step_loop_on_the_shims(env):
         o.x, o.y, o.vx, o.vy = -7.0, 7.0, 0.0, 0.0
     x_last, hit, reached, min_margin, dist, iters, oob = prob.step(300)
     assert reached and not hit and not oob and iters < 200 and dist <= 0.15
-    cfg = orc.config(20, 3, 2.0, qp_tol=1e-8)
+    cfg = orc.config(20, 3, 2.0)
     x0 = np.array([-6.0, -6.0, np.pi / 4, 0, 0])
     Xg, Ug = orc.initial_guess(cfg, x0)
     want = orc.rti_solve(cfg, x0, orc.predict_params(cfg, np.array([[-7.0, 7.0, 0, 0]] * 3)), np.array([6.0, 6.0]), Xg, Ug)["u0"]
@@ -270,7 +270,7 @@ def test_visualisation_inputs_against_the_oracle_loop(env):
     steps = 40
     rec = mpc_gpu.run_episodes(x0[None], goal[None], obst[None], N=20, Tf=2.0, max_iter=steps, random_move=False, record=True)
     vis = mpc_gpu.visualisation_inputs(rec, 0, steps=steps)
-    cfg = orc.config(20, 3, 2.0, qp_tol=1e-8)
+    cfg = orc.config(20, 3, 2.0)
     lp = OracleLoop(orc, cfg, x0, goal, obst, reset_on_fail=True, alias=True)
     traj, horizons, tracks = [lp.x[:2].copy()], [np.zeros((21, 2))], [lp.obst[:, :2].copy()]
     for k in range(steps):

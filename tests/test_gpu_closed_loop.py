@@ -78,7 +78,7 @@ def test_fused_step_against_the_oracle_loop_with_resync(env):
     obst, noise = reference_streams("RANDOM", range(B), no, K)
     x0 = np.tile([-7.0, -7.0, np.pi / 4, 0, 0], (B, 1)); goal = np.tile([7.0, 7.0], (B, 1))
     x0[B // 2:, :2] = [[-6.0, 5.0]]; goal[B // 2:] = [5.0, -6.0]
-    cfg = orc.config(N, no, Tf, qp_tol=1e-8)
+    cfg = orc.config(N, no, Tf)
     g = GpuLoop(mpc_gpu, N, no, Tf, x0, goal, obst)
     loops = [OracleLoop(orc, cfg, x0[b], goal[b], obst[b]) for b in range(B)]
     worst = dict(X=0.0, x=0.0, u=0.0, margin=0.0)
@@ -149,7 +149,7 @@ def test_free_running_episodes_three_way(env):
     B = len(seeds)
     x0 = np.tile([-7.0, -7.0, np.pi / 4, 0, 0], (B, 1)); goal = np.tile([7.0, 7.0], (B, 1))
     tb = mpc_gpu.run_episodes(x0, goal, obst, N=N, Tf=Tf, max_iter=400, noise=noise, qp_iter_max=100)["table"]
-    cfg = orc.config(N, no, Tf, qp_tol=1e-8, qp_iter_max=100)
+    cfg = orc.config(N, no, Tf, qp_iter_max=100)
     for b in range(B):
         L = OracleLoop(orc, cfg, x0[b], goal[b], obst[b])
         for k in range(400):
@@ -167,7 +167,7 @@ def test_explicit_slack_schedule(env):
     mpc_gpu, orc = env
     N, no, B = 20, 3, 48
     x0, goal, obst = random_batch(B, no, seed=77)
-    cfg = orc.config(N, no, 2.0, qp_tol=1e-8)
+    cfg = orc.config(N, no, 2.0)
     P = oracle_P(orc, cfg, obst); Xg, Ug = oracle_guess(orc, cfg, x0)
     own = np.stack([orc.slack_alpha(cfg, x0[b], goal[b]) for b in range(B)])
     other = np.full((B, N + 1), 3.0e5); other[:, -3:] = 0.0
@@ -228,7 +228,7 @@ def test_outliers_are_judged_by_the_qp_not_by_a_count(env):
     mpc_gpu, orc = env
     N, no, B = 50, 10, 96
     x0, goal, obst = random_batch(B, no, seed=1234)
-    cfg = orc.config(N, no, 5.0, qp_tol=1e-8)
+    cfg = orc.config(N, no, 5.0)
     P = oracle_P(orc, cfg, obst); Xg, Ug = oracle_guess(orc, cfg, x0)
     with mpc_gpu.BatchedMpc(N, no, 5.0, max_batch=B) as s:
         s.set_warmstart(Xg, Ug); g = s.solve(x0, P, goal); X1, U1 = s.get_traj(B)
@@ -263,7 +263,7 @@ def test_interpolate_init_guess(env):
     N, no, B = 20, 3, 48
     x0, goal, obst = random_batch(B, no, seed=123)
     x0[:, 3:] = np.random.default_rng(3).uniform(-1, 1, (B, 2)); goal[5, 1] = x0[5, 1]      # one instance with dy = 0
-    cfg = orc.config(N, no, 2.0, qp_tol=1e-8)
+    cfg = orc.config(N, no, 2.0)
     with mpc_gpu.BatchedMpc(N, no, 2.0, max_batch=B) as s:
         s.reset_guess_interp(x0, goal)
         X, U = s.get_traj(B)
@@ -281,7 +281,7 @@ def test_interpolate_init_guess(env):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     x0[:, 3:] = 0.0
     obst[::2, 0, :2] = x0[::2, :2] + 0.4; obst[::2, 0, 2:] = 0.0
-    cfgh = orc.config(N, no, 2.0, qp_tol=1e-8, soft_h=0)
+    cfgh = orc.config(N, no, 2.0, soft_h=0)
     loops = [OracleLoop(orc, cfgh, x0[b], goal[b], obst[b], reset_on_fail=True, alias=False, interp=True) for b in range(B)]
     fl = _lib.STEP_SHIFT | _lib.STEP_PLANT | _lib.STEP_OBSTACLES | _lib.STEP_RESET_ON_FAIL | _lib.STEP_INTERP_GUESS
     resets = 0

@@ -2,7 +2,7 @@
 
 Tolerances (BASELINE.md section 3 / SURVEY.md 8(c)): linearisation 1e-12; trajectories |X - X_ref| <= 1e-6;
 |u* - u*_ref| <= 1e-6 * C_MAX; cost relative 1e-8.  Both sides run the same interior-point specification with
-qp_tol = 1e-8 and cap QP_ITER = 50, so the observed differences are far below these bounds.
+qp_tol = 1e-10 (the library's and the oracle's default) and cap QP_ITER = 50, so the observed differences are far below these bounds.
 """
 import numpy as np
 import pytest
@@ -33,7 +33,7 @@ def run_pair(mpc_gpu, orc, N, no, Tf, x0, goal, obst, steps=1, X=None, U=None, r
     oracle's iterate, so each comparison is a single solve on IDENTICAL inputs (the parity contract); resync=False lets
     each side carry its own iterate (differences then compound through the closed loop)."""
     B = x0.shape[0]
-    cfg = orc.config(N, no, Tf, qp_tol=1e-8, **cfgkw)
+    cfg = orc.config(N, no, Tf, **cfgkw)
     P = oracle_P(orc, cfg, obst)
     if X is None:
         X, U = oracle_guess(orc, cfg, x0)
@@ -165,7 +165,7 @@ def test_permutation_invariance_large_batch(env):
         d = np.abs(X1[perm] - X2).reshape(B, -1).max(1)[same & (g2["status"] == 0)]
         assert np.median(d) < 1e-12 and np.quantile(d, 0.999) < 1e-6 and d.max() < 1e-3
     # spot-check 64 of them against the oracle
-    cfg = orc.config(N, no, 2.0, qp_tol=1e-8)
+    cfg = orc.config(N, no, 2.0)
     idx = perm[:64]
     P = oracle_P(orc, cfg, obst[idx]); Xg, Ug = oracle_guess(orc, cfg, x0[idx])
     o = orc.rti_solve_batch(cfg, x0[idx], P, goal[idx], Xg, Ug)
@@ -525,7 +525,7 @@ def test_full_size_batches_c3_and_c4_share(env, B):
         assert same.all() and np.array_equal(X1[perm], X2) and np.array_equal(U1[perm], U2)
     assert (g1["status"] != 4).mean() > 0.99 and 5.0 < g1["iters"].mean() < 12.0
     idx = np.linspace(0, B - 1, 256).astype(int)
-    cfg = orc.config(N, no, 2.0, qp_tol=1e-8)
+    cfg = orc.config(N, no, 2.0)
     P = oracle_P(orc, cfg, obst[idx])
     o = orc.rti_solve_batch(cfg, x0[idx], P, goal[idx], Xs[idx], Us[idx])          # second step, from the GPU's own shifted iterate
     assert (o["status"] == h1["status"][idx]).all()
@@ -596,7 +596,7 @@ def test_block_riccati_matches_the_oracle_and_the_stagewise_recursion(built, N, 
     import mpc_gpu
     from oracle import oracle as orc
     x0, goal, obst = random_batch(B, no, seed=900 + N + no)
-    cfg = orc.config(N, no, 0.1 * N, qp_tol=1e-8)
+    cfg = orc.config(N, no, 0.1 * N)
     P = oracle_P(orc, cfg, obst); X0, U0 = oracle_guess(orc, cfg, x0)
     out = {}
     for on in (1, 0):
@@ -636,7 +636,7 @@ def test_c5_kernel_at_a_scheduled_batch(built):
     x0, goal, obst = random_batch(B, no, seed=5050)
     dev = torch.device("cuda:0")
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    cfg = orc.config(N, no, 5.0, qp_tol=1e-8)
+    cfg = orc.config(N, no, 5.0)
     res = []
     perm = np.random.default_rng(1).permutation(B)
     for order in (np.arange(B), perm):

@@ -106,7 +106,7 @@ def test_step_counts_per_call_for_the_subgoal_hook(built):
     from mpc_gpu.closed_loop import EpisodeState, ShimLoop
     from mpc_gpu.world import Obstacle
     N, no, k = 10, 3, 7
-    cfg = orc.config(N, no, 1.0, qp_tol=1e-8)
+    cfg = orc.config(N, no, 1.0)
     x0 = np.array([-5.0, -4.0, 0.3, 0.0, 0.0]); g1, g2 = np.array([4.0, 3.0]), np.array([-2.0, 5.0])
     obst = np.array([[0.0, -1.0, 0.4, 0.6], [2.0, 2.5, -0.5, 0.3], [-3.0, 1.0, 0.2, -0.7]])
     ocp = OracleAsAcados(orc, cfg, g1); sim = OraclePlant(orc, 0.1)

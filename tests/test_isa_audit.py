@@ -4,7 +4,9 @@ Why this is a test: hipcc treats an inline-asm statement as one opaque instructi
 allocator of this toolchain can place a live-range split copy in front of the `s_or_b64 exec` that re-opens the lanes at an if / else join --
 the copy then runs under one side's mask (possibly no lane) and the value is lost for the other lanes.  Round 2 met that as a build variant
 whose rti_solve_kernel<10, 64, 3> stored status / iterations / cost to wrong addresses.  Both defects are visible in
-the listing and invisible to every functional test that happens not to touch the damaged lanes."""
+the listing and invisible to every functional test that happens not to touch the damaged lanes.  Round 3 met a second register-allocator defect (rule P2, a
+kernel-argument load re-materialised over the live part of another one: rti_solve_kernel<3, 32, 2> added its iteration count to the episode's step counter,
+DESIGN.md section 8.5b); its dynamic counterpart is tests/test_gpu_every_kernel.py."""
 import os
 import subprocess
 import sys
@@ -37,6 +39,31 @@ kern:
 	s_endpgm
 """
 
+BAD_TORN = """
+kern:
+	s_load_dwordx8 s[8:15], s[6:7], 0x248
+	s_waitcnt lgkmcnt(0)
+	v_writelane_b32 v253, s12, 18
+	v_writelane_b32 v253, s13, 19
+	s_load_dwordx16 s[12:27], s[6:7], 0x1c8
+	s_waitcnt lgkmcnt(0)
+	s_load_dwordx8 s[8:15], s[6:7], 0x248
+	s_waitcnt lgkmcnt(0)
+	s_cmp_lg_u64 s[10:11], 0
+	v_writelane_b32 v254, s12, 12
+	v_writelane_b32 v254, s13, 13
+	v_writelane_b32 v254, s14, 14
+	v_writelane_b32 v254, s15, 15
+	v_writelane_b32 v254, s16, 16
+	v_writelane_b32 v254, s17, 17
+	v_writelane_b32 v254, s18, 18
+	v_writelane_b32 v254, s19, 19
+	s_endpgm
+"""
+# the same, but the first four registers of the wide load were consumed before the narrow load took them over: legitimate reuse
+GOOD_TORN = BAD_TORN.replace("\ts_load_dwordx16 s[12:27], s[6:7], 0x1c8\n\ts_waitcnt lgkmcnt(0)\n",
+                             "\ts_load_dwordx16 s[12:27], s[6:7], 0x1c8\n\ts_waitcnt lgkmcnt(0)\n\ts_cmp_eq_u64 s[12:13], 0\n\ts_add_u32 s30, s14, s15\n")
+
 
 def run(path):
     return subprocess.run([sys.executable, AUDIT, path], capture_output=True, text=True)
@@ -44,12 +71,13 @@ def run(path):
 
 def test_audit_rules_fire_on_minimal_listings(tmp_path):
     for name, text, clean in (("bad_join", BAD_JOIN, False), ("good_join", GOOD_JOIN, True), ("bad_dpp", BAD_DPP, False),
-                              ("good_dpp", BAD_DPP.replace("\t;;#ASMSTART\n", "\t;;#ASMSTART\n\ts_nop 1\n"), True)):
+                              ("good_dpp", BAD_DPP.replace("\t;;#ASMSTART\n", "\t;;#ASMSTART\n\ts_nop 1\n"), True), ("bad_torn", BAD_TORN, False),
+                              ("good_torn", GOOD_TORN, True)):
         f = tmp_path / f"{name}.s"
         f.write_text(text)
         r = run(str(f))
         assert (r.returncode == 0) == clean, (name, r.stdout)
-    assert "P1" in run(str(tmp_path / "bad_join.s")).stdout and "R1" in run(str(tmp_path / "bad_dpp.s")).stdout
+    assert "P1" in run(str(tmp_path / "bad_join.s")).stdout and "R1" in run(str(tmp_path / "bad_dpp.s")).stdout and "P2" in run(str(tmp_path / "bad_torn.s")).stdout
 
 
 def test_shipped_library_listing_is_clean(built):

@@ -105,7 +105,7 @@ def test_oracle_closed_loop_reproduces_recorded_rows(orc, stem):
     t = TABLES["tables"][stem]; sp = t["spec"]; rows = np.array(t["rows"])
     seeds = RECORDED_SEEDS[stem]
     obst, noise = reference_streams(sp["scenario"], seeds, sp["N_OBST"], 400)
-    cfg = orc.config(sp["N_SOLV"], sp["N_OBST"], float(sp["TF"]), qp_tol=1e-8, qp_iter_max=sp["QP_ITER"])
+    cfg = orc.config(sp["N_SOLV"], sp["N_OBST"], float(sp["TF"]), qp_iter_max=sp["QP_ITER"])
     for b, seed in enumerate(seeds):
         L = OracleLoop(orc, cfg, [-7.0, -7.0, np.pi / 4, 0, 0], [7.0, 7.0], obst[b])        # experiments.py:20
         for k in range(400):
@@ -123,7 +123,7 @@ def test_unscaled_lm_term_does_not_reproduce_the_recorded_rows(orc):
     t = TABLES["tables"]["20221031_215846"]; rows = np.array(t["rows"])
     seeds = [0, 2, 3, 4]
     obst, noise = reference_streams("RANDOM", seeds, 5, 400)
-    cfg = orc.config(20, 5, 2.0, qp_tol=1e-8, qp_iter_max=100, lm_scaled=0)
+    cfg = orc.config(20, 5, 2.0, qp_iter_max=100, lm_scaled=0)
     for b, seed in enumerate(seeds):
         L = OracleLoop(orc, cfg, [-7.0, -7.0, np.pi / 4, 0, 0], [7.0, 7.0], obst[b])
         for k in range(400):
