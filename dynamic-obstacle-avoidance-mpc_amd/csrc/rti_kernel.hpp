@@ -3276,11 +3276,34 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     // in (spilled) scalar registers across the whole interior point -- and in one instantiation (rti_solve_kernel<3, 32, 2>) this toolchain's register allocator
     // re-materialised a kernel-argument load over the live half of another one in the prologue, so that `iters_acc` arrived here holding `ep_steps`
     // (tests/test_gpu_every_kernel.py).  Read here through an opaque copy of the segment pointer they are a handful of scalar
-    // loads with live ranges of a few instructions, and the prologue no longer holds them.
+    // loads with live ranges of a few instructions, and the prologue no longer holds them (132 -> 75 spilled scalars at <3, 21, 3>, 152 -> 73 at <10, 64, 3>;
+    // same speed).  The stage-split kernel keeps its arguments from the prologue: it spills 20 scalars, no instantiation of it shows the defect (audit rule P2
+    // refuses a build that does), and there the six kernel-argument cache lines have left the scalar cache by the time the tail runs (-1 % at C2, measured).
     KTail *pt = (KTail *)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(pt));
     World wld_t;
     wld_t.xmin = pt->world.xmin; wld_t.xmax = pt->world.xmax; wld_t.ymin = pt->world.ymin; wld_t.ymax = pt->world.ymax; wld_t.bug_compat_predict = pt->world.bug_compat_predict;
+    // every field the tail uses, read in ONE block (the loads cluster and are waited for once; read where they are used they would be issued one by one inside the branches)
+    int const t_fused = pt->fused;
+    double *const t_x0_rw = pt->x0_rw;
+    const double *const t_obst = pt->obst;
+    double *const t_obst_rw = pt->obst_rw;
+    const double *const t_noise = pt->noise;
+    double const t_randomness = pt->randomness;
+    double const t_vmax = pt->vmax;
+    double const t_r_hit = pt->r_hit;
+    double const t_tol_goal = pt->tol_goal;
+    double const t_r2 = pt->r2;
+    double *const t_ep_min_margin = pt->ep_min_margin;
+    int32_t *const t_ep_flags = pt->ep_flags;
+    int32_t *const t_ep_steps = pt->ep_steps;
+    double *const t_u0 = pt->u0;
+    double *const t_cost = pt->cost;
+    int32_t *const t_status = pt->status;
+    int32_t *const t_iters = pt->iters;
+    int32_t *const t_iters_acc = pt->iters_acc;
+    int32_t *const t_status_acc = pt->status_acc;
+    const double t_Wg[6] = {pt->Wg[0], pt->Wg[1], pt->Wg[2], pt->Wg[3], pt->Wg[4], pt->Wg[5]}, t_Weg[4] = {pt->Weg[0], pt->Weg[1], pt->Weg[2], pt->Weg[3]};
     // ---- full step on the iterate; status 4 leaves it unchanged ----
     const bool store = valid && !ep_done;
     if (status != 4) {
@@ -3289,12 +3312,12 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         ui[0] += z[0]; ui[1] += z[1];
     }
     const double u_apply[2] = {lane_value_seg<G>(ui[0], lane), lane_value_seg<G>(ui[1], lane)};   // u* = U[0] of this instance
-    if ((pt->fused & kFuseResetOnFail) && status == 4) {      // set_initial_guess(), robot_ocp_problem.py:203-205,286-306
+    if ((t_fused & kFuseResetOnFail) && status == 4) {      // set_initial_guess(), robot_ocp_problem.py:203-205,286-306
         xi[0] = x0v[0]; xi[1] = x0v[1]; xi[2] = x0v[2]; xi[3] = 0.0; xi[4] = 0.0; ui[0] = ui[1] = 0.0;
-        if (pt->fused & kFuseInterpGuess) interp_guess(x0v, gl[1], i <= N ? i : N, N, xi);
+        if (t_fused & kFuseInterpGuess) interp_guess(x0v, gl[1], i <= N ? i : N, N, xi);
     }
-    if (store && (status != 4 || (pt->fused & (kFuseResetOnFail | kFuseShift)))) {
-        if (pt->fused & kFuseShift) {                          // X[j] <- X[j+1], U[j] <- U[j+1], U[N-1] <- 0, X[N] kept (:253-258)
+    if (store && (status != 4 || (t_fused & (kFuseResetOnFail | kFuseShift)))) {
+        if (t_fused & kFuseShift) {                          // X[j] <- X[j+1], U[j] <- U[j+1], U[N-1] <- 0, X[N] kept (:253-258)
             if (act && i >= 1) {
 #pragma unroll
                 for (int c = 0; c < 5; c++) Xg[(i - 1) * 5 + c] = xi[c];
@@ -3314,68 +3337,68 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         }
     }
     // ---- plant, obstacles, episode bookkeeping (fused closed-loop step) ----
-    if (pt->fused & (kFusePlant | kFuseObstacles | kFuseMetrics)) {
+    if (t_fused & (kFusePlant | kFuseObstacles | kFuseMetrics)) {
         double xp[5] = {x0v[0], x0v[1], x0v[2], x0v[3], x0v[4]};
-        if ((pt->fused & kFuseAliasBug) && (pt->fused & kFuseResetOnFail) && status == 4) { xp[3] = 0.0; xp[4] = 0.0; }
+        if ((t_fused & kFuseAliasBug) && (t_fused & kFuseResetOnFail) && status == 4) { xp[3] = 0.0; xp[4] = 0.0; }
         double xnew[5] = {xp[0], xp[1], xp[2], xp[3], xp[4]};
-        if (pt->fused & kFusePlant) dyn_step<false>(xp, u_apply, dt, xnew, nullptr, nullptr);     // every lane, same value
-        if ((pt->fused & kFusePlant) && i == 0 && store && pt->x0_rw) {
+        if (t_fused & kFusePlant) dyn_step<false>(xp, u_apply, dt, xnew, nullptr, nullptr);     // every lane, same value
+        if ((t_fused & kFusePlant) && i == 0 && store && t_x0_rw) {
 #pragma unroll
-            for (int c = 0; c < 5; c++) pt->x0_rw[(size_t)inst * 5 + c] = xnew[c];
+            for (int c = 0; c < 5; c++) t_x0_rw[(size_t)inst * 5 + c] = xnew[c];
         }
         double margin = INFINITY;
-        if (pt->obst && i < nact) {                            // ground-truth motion of obstacle j = i
-            const double *o = pt->obst + ((size_t)inst * nact + i) * 4;
+        if (t_obst && i < nact) {                            // ground-truth motion of obstacle j = i
+            const double *o = t_obst + ((size_t)inst * nact + i) * 4;
             double ox = o[0], oy = o[1], ovx = o[2], ovy = o[3];
-            if (pt->fused & kFuseObstacles) {
-                if (pt->noise) obstacle_noise(pt->randomness, pt->vmax, pt->noise[((size_t)inst * nact + i) * 2], pt->noise[((size_t)inst * nact + i) * 2 + 1], ovx, ovy);
+            if (t_fused & kFuseObstacles) {
+                if (t_noise) obstacle_noise(t_randomness, t_vmax, t_noise[((size_t)inst * nact + i) * 2], t_noise[((size_t)inst * nact + i) * 2 + 1], ovx, ovy);
                 obstacle_advance(wld_t, dt, ox, ovx, oy, ovy);
-                if (store && pt->obst_rw) { double *w = pt->obst_rw + ((size_t)inst * nact + i) * 4; w[0] = ox; w[1] = oy; w[2] = ovx; w[3] = ovy; }
+                if (store && t_obst_rw) { double *w = t_obst_rw + ((size_t)inst * nact + i) * 4; w[0] = ox; w[1] = oy; w[2] = ovx; w[3] = ovy; }
             }
             const double ddx = xnew[0] - ox, ddy = xnew[1] - oy;
-            margin = sqrt(ddx * ddx + ddy * ddy) - pt->r_hit;  // :222-228
+            margin = sqrt(ddx * ddx + ddy * ddy) - t_r_hit;  // :222-228
         }
-        if (pt->fused & kFuseMetrics) {
+        if (t_fused & kFuseMetrics) {
             margin = -seg_max<G>(-margin, lane);
             if (i == 0 && store) {
-                int fl = pt->ep_flags[inst];
+                int fl = t_ep_flags[inst];
                 if (xnew[0] < wld_t.xmin || xnew[0] > wld_t.xmax || xnew[1] < wld_t.ymin || xnew[1] > wld_t.ymax) fl |= 2;   // :213-214
-                const double mm = fmin(pt->ep_min_margin[inst], margin);
-                pt->ep_min_margin[inst] = mm;
+                const double mm = fmin(t_ep_min_margin[inst], margin);
+                t_ep_min_margin[inst] = mm;
                 if (mm <= 0.0) fl |= 4;
                 const double gx_ = xnew[0] - gl[0], gy_ = xnew[1] - gl[1];
-                if (sqrt(gx_ * gx_ + gy_ * gy_) <= pt->tol_goal) fl |= 1;      // :247-250: reached, the loop breaks before i += 1
-                else pt->ep_steps[inst] += 1;
-                pt->ep_flags[inst] = fl;
+                if (sqrt(gx_ * gx_ + gy_ * gy_) <= t_tol_goal) fl |= 1;      // :247-250: reached, the loop breaks before i += 1
+                else t_ep_steps[inst] += 1;
+                t_ep_flags[inst] = fl;
             }
         }
     }
-    if (i == 0 && pt->u0 && store) { pt->u0[(size_t)inst * 2] = u_apply[0]; pt->u0[(size_t)inst * 2 + 1] = u_apply[1]; }
+    if (i == 0 && t_u0 && store) { t_u0[(size_t)inst * 2] = u_apply[0]; t_u0[(size_t)inst * 2 + 1] = u_apply[1]; }
     // NLP objective at the returned iterate: LS cost + exact penalty of the obstacle violation
-    if (pt->cost) {
+    if (t_cost) {
         double J = 0.0;
         if (act) {
             const double ex = xi[0] - gl[0], ey = xi[1] - gl[1];
-            if (has_u) J = 0.5 * (pt->Wg[0] * ex * ex + pt->Wg[1] * ey * ey + pt->Wg[2] * xi[3] * xi[3] + pt->Wg[3] * xi[4] * xi[4]
-                                  + pt->Wg[4] * ui[0] * ui[0] + pt->Wg[5] * ui[1] * ui[1]);
-            else J = 0.5 * (pt->Weg[0] * ex * ex + pt->Weg[1] * ey * ey + pt->Weg[2] * xi[3] * xi[3] + pt->Weg[3] * xi[4] * xi[4]);
+            if (has_u) J = 0.5 * (t_Wg[0] * ex * ex + t_Wg[1] * ey * ey + t_Wg[2] * xi[3] * xi[3] + t_Wg[3] * xi[4] * xi[4]
+                                  + t_Wg[4] * ui[0] * ui[0] + t_Wg[5] * ui[1] * ui[1]);
+            else J = 0.5 * (t_Weg[0] * ex * ex + t_Weg[1] * ey * ey + t_Weg[2] * xi[3] * xi[3] + t_Weg[3] * xi[4] * xi[4]);
 #pragma unroll
             for (int j = 0; j < NOBST; j++) {
                 if (ROW_OFF(j)) continue;
                 const double dx = xi[0] - pos_x(j), dy = xi[1] - pos_y(j);
-                const double hv = dx * dx + dy * dy - pt->r2;
+                const double hv = dx * dx + dy * dy - t_r2;
                 const double v = hv < 0 ? -hv : 0.0;
                 J += zpen * (v + 0.5 * v * v);
             }
         }
         J = seg_sum<G>(J, lane);
-        if (i == 0 && store) pt->cost[inst] = J;
+        if (i == 0 && store) t_cost[inst] = J;
     }
     if (i == 0 && store) {
-        if (pt->iters_acc) pt->iters_acc[inst] += it_done;
-        if (pt->status_acc) pt->status_acc[inst] += (status == 4 ? 1 : 0) + (status == 2 ? 65536 : 0);
-        if (pt->status) pt->status[inst] = status;
-        if (pt->iters) pt->iters[inst] = it_done;
+        if (t_iters_acc) t_iters_acc[inst] += it_done;
+        if (t_status_acc) t_status_acc[inst] += (status == 4 ? 1 : 0) + (status == 2 ? 65536 : 0);
+        if (t_status) t_status[inst] = status;
+        if (t_iters) t_iters[inst] = it_done;
     }
 }
 #undef ROW_OFF

@@ -1017,16 +1017,6 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
         for (int c = 0; c < 5; c++) x0v[c] = xg[c];
         gl[0] = gg[0]; gl[1] = gg[1];
     }
-    typedef const __attribute__((address_space(4))) KParams KTail;
-    // THE TAIL READS ITS KERNEL ARGUMENTS AGAIN.  Output pointers and fused-step parameters are used only from here on; carried from the prologue they live
-    // in (spilled) scalar registers across the whole interior point -- and in one instantiation (rti_solve_kernel<3, 32, 2>) this toolchain's register allocator
-    // re-materialised a kernel-argument load over the live half of another one in the prologue, so that `iters_acc` arrived here holding `ep_steps`
-    // (tests/test_gpu_every_kernel.py).  Read here through an opaque copy of the segment pointer they are a handful of scalar
-    // loads with live ranges of a few instructions, and the prologue no longer holds them.
-    KTail *pt = (KTail *)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(pt));
-    World wld_t;
-    wld_t.xmin = pt->world.xmin; wld_t.xmax = pt->world.xmax; wld_t.ymin = pt->world.ymin; wld_t.ymax = pt->world.ymax; wld_t.bug_compat_predict = pt->world.bug_compat_predict;
     // ---- full step on the iterate; status 4 leaves it unchanged ----
     const bool store = !ep_done;
     if (status != 4) {
@@ -1035,12 +1025,12 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
         ui[0] += z[0]; ui[1] += z[1];
     }
     const double u_apply[2] = {lane_value(ui[0], 0), lane_value(ui[1], 0)};   // u* = U[0]
-    if ((pt->fused & kFuseResetOnFail) && status == 4) {      // set_initial_guess(), robot_ocp_problem.py:203-205,286-306
+    if ((p.fused & kFuseResetOnFail) && status == 4) {      // set_initial_guess(), robot_ocp_problem.py:203-205,286-306
         xi[0] = x0v[0]; xi[1] = x0v[1]; xi[2] = x0v[2]; xi[3] = 0.0; xi[4] = 0.0; ui[0] = ui[1] = 0.0;
-        if (pt->fused & kFuseInterpGuess) interp_guess(x0v, gl[1], i <= N ? i : N, N, xi);
+        if (p.fused & kFuseInterpGuess) interp_guess(x0v, gl[1], i <= N ? i : N, N, xi);
     }
-    if (store && own && (status != 4 || (pt->fused & (kFuseResetOnFail | kFuseShift)))) {
-        if (pt->fused & kFuseShift) {                          // X[j] <- X[j+1], U[j] <- U[j+1], U[N-1] <- 0, X[N] kept (:253-258)
+    if (store && own && (status != 4 || (p.fused & (kFuseResetOnFail | kFuseShift)))) {
+        if (p.fused & kFuseShift) {                          // X[j] <- X[j+1], U[j] <- U[j+1], U[N-1] <- 0, X[N] kept (:253-258)
             if (act && i >= 1) {
 #pragma unroll
                 for (int c = 0; c < 5; c++) Xg[(i - 1) * 5 + c] = xi[c];
@@ -1060,74 +1050,74 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
         }
     }
     // ---- plant, obstacles, episode bookkeeping (fused closed-loop step) ----
-    if (pt->fused & (kFusePlant | kFuseObstacles | kFuseMetrics)) {
+    if (p.fused & (kFusePlant | kFuseObstacles | kFuseMetrics)) {
         double xp[5] = {x0v[0], x0v[1], x0v[2], x0v[3], x0v[4]};
-        if ((pt->fused & kFuseAliasBug) && (pt->fused & kFuseResetOnFail) && status == 4) { xp[3] = 0.0; xp[4] = 0.0; }
+        if ((p.fused & kFuseAliasBug) && (p.fused & kFuseResetOnFail) && status == 4) { xp[3] = 0.0; xp[4] = 0.0; }
         double xnew[5] = {xp[0], xp[1], xp[2], xp[3], xp[4]};
-        if (pt->fused & kFusePlant) dyn_step<false>(xp, u_apply, dt, xnew, nullptr, nullptr);     // every lane, same value
-        if ((pt->fused & kFusePlant) && lane == 0 && store && pt->x0_rw) {
+        if (p.fused & kFusePlant) dyn_step<false>(xp, u_apply, dt, xnew, nullptr, nullptr);     // every lane, same value
+        if ((p.fused & kFusePlant) && lane == 0 && store && p.x0_rw) {
 #pragma unroll
-            for (int c = 0; c < 5; c++) pt->x0_rw[(size_t)inst * 5 + c] = xnew[c];
+            for (int c = 0; c < 5; c++) p.x0_rw[(size_t)inst * 5 + c] = xnew[c];
         }
         double margin = INFINITY;
-        if (pt->obst && lane < nact) {                         // ground-truth motion of obstacle j = lane
-            const double *o = pt->obst + ((size_t)inst * nact + lane) * 4;
+        if (p.obst && lane < nact) {                         // ground-truth motion of obstacle j = lane
+            const double *o = p.obst + ((size_t)inst * nact + lane) * 4;
             double ox = o[0], oy = o[1], ovx = o[2], ovy = o[3];
-            if (pt->fused & kFuseObstacles) {
-                if (pt->noise) obstacle_noise(pt->randomness, pt->vmax, pt->noise[((size_t)inst * nact + lane) * 2], pt->noise[((size_t)inst * nact + lane) * 2 + 1], ovx, ovy);
-                obstacle_advance(wld_t, dt, ox, ovx, oy, ovy);
-                if (store && pt->obst_rw) { double *w = pt->obst_rw + ((size_t)inst * nact + lane) * 4; w[0] = ox; w[1] = oy; w[2] = ovx; w[3] = ovy; }
+            if (p.fused & kFuseObstacles) {
+                if (p.noise) obstacle_noise(p.randomness, p.vmax, p.noise[((size_t)inst * nact + lane) * 2], p.noise[((size_t)inst * nact + lane) * 2 + 1], ovx, ovy);
+                obstacle_advance(p.world, dt, ox, ovx, oy, ovy);
+                if (store && p.obst_rw) { double *w = p.obst_rw + ((size_t)inst * nact + lane) * 4; w[0] = ox; w[1] = oy; w[2] = ovx; w[3] = ovy; }
             }
             const double ddx = xnew[0] - ox, ddy = xnew[1] - oy;
-            margin = sqrt(ddx * ddx + ddy * ddy) - pt->r_hit;  // :222-228
+            margin = sqrt(ddx * ddx + ddy * ddy) - p.r_hit;  // :222-228
         }
-        if (pt->fused & kFuseMetrics) {
+        if (p.fused & kFuseMetrics) {
             margin = -seg_max<64>(-margin, lane);
             if (lane == 0 && store) {
-                int fl = pt->ep_flags[inst];
-                if (xnew[0] < wld_t.xmin || xnew[0] > wld_t.xmax || xnew[1] < wld_t.ymin || xnew[1] > wld_t.ymax) fl |= 2;   // :213-214
-                const double mm = fmin(pt->ep_min_margin[inst], margin);
-                pt->ep_min_margin[inst] = mm;
+                int fl = p.ep_flags[inst];
+                if (xnew[0] < p.world.xmin || xnew[0] > p.world.xmax || xnew[1] < p.world.ymin || xnew[1] > p.world.ymax) fl |= 2;   // :213-214
+                const double mm = fmin(p.ep_min_margin[inst], margin);
+                p.ep_min_margin[inst] = mm;
                 if (mm <= 0.0) fl |= 4;
                 const double gx_ = xnew[0] - gl[0], gy_ = xnew[1] - gl[1];
-                if (sqrt(gx_ * gx_ + gy_ * gy_) <= pt->tol_goal) fl |= 1;      // :247-250: reached, the loop breaks before i += 1
-                else pt->ep_steps[inst] += 1;
-                pt->ep_flags[inst] = fl;
+                if (sqrt(gx_ * gx_ + gy_ * gy_) <= p.tol_goal) fl |= 1;      // :247-250: reached, the loop breaks before i += 1
+                else p.ep_steps[inst] += 1;
+                p.ep_flags[inst] = fl;
             }
         }
     }
-    if (lane == 0 && pt->u0 && store) { pt->u0[(size_t)inst * 2] = u_apply[0]; pt->u0[(size_t)inst * 2 + 1] = u_apply[1]; }
+    if (lane == 0 && p.u0 && store) { p.u0[(size_t)inst * 2] = u_apply[0]; p.u0[(size_t)inst * 2 + 1] = u_apply[1]; }
     // NLP objective at the returned iterate: LS cost (the stage's owner) + exact penalty of the obstacle violation (the rows' lanes)
-    if (pt->cost) {
+    if (p.cost) {
         double J = 0.0;
         if (act) {
             if (own) {
                 const double ex = xi[0] - gl[0], ey = xi[1] - gl[1];
-                if (has_u) J = 0.5 * (pt->Wg[0] * ex * ex + pt->Wg[1] * ey * ey + pt->Wg[2] * xi[3] * xi[3] + pt->Wg[3] * xi[4] * xi[4]
-                                      + pt->Wg[4] * ui[0] * ui[0] + pt->Wg[5] * ui[1] * ui[1]);
-                else J = 0.5 * (pt->Weg[0] * ex * ex + pt->Weg[1] * ey * ey + pt->Weg[2] * xi[3] * xi[3] + pt->Weg[3] * xi[4] * xi[4]);
+                if (has_u) J = 0.5 * (p.Wg[0] * ex * ex + p.Wg[1] * ey * ey + p.Wg[2] * xi[3] * xi[3] + p.Wg[3] * xi[4] * xi[4]
+                                      + p.Wg[4] * ui[0] * ui[0] + p.Wg[5] * ui[1] * ui[1]);
+                else J = 0.5 * (p.Weg[0] * ex * ex + p.Weg[1] * ey * ey + p.Weg[2] * xi[3] * xi[3] + p.Weg[3] * xi[4] * xi[4]);
             }
 #pragma unroll
             for (int s = 0; s < NSL; s++) if (s * LPS + h < nact) {
                 const double dx = xi[0] - pxy[s][0], dy = xi[1] - pxy[s][1];
-                const double hv = dx * dx + dy * dy - pt->r2;
+                const double hv = dx * dx + dy * dy - p.r2;
                 const double v = hv < 0 ? -hv : 0.0;
                 J += zpen * (v + 0.5 * v * v);
             }
         }
         J = seg_sum<64>(J, lane);
-        if (lane == 0 && store) pt->cost[inst] = J;
+        if (lane == 0 && store) p.cost[inst] = J;
     }
     if (lane == 0 && store) {
-        if (pt->iters_acc) pt->iters_acc[inst] += it_done;
-        if (pt->status_acc) pt->status_acc[inst] += (status == 4 ? 1 : 0) + (status == 2 ? 65536 : 0);
-        if (pt->status) pt->status[inst] = status;
-        if (pt->iters) pt->iters[inst] = it_done;
+        if (p.iters_acc) p.iters_acc[inst] += it_done;
+        if (p.status_acc) p.status_acc[inst] += (status == 4 ? 1 : 0) + (status == 2 ? 65536 : 0);
+        if (p.status) p.status[inst] = status;
+        if (p.iters) p.iters[inst] = it_done;
     }
 #ifdef MPC_PHASE_TIMING
     __builtin_amdgcn_s_waitcnt(0);
     MPC_TICK(14);
-    if (pt->trace && lane == 0) { for (int k = 0; k < 16; k++) pt->trace[((size_t)inst * pt->iter_max) * 4 + k] = (double)tacc_[k]; }
+    if (p.trace && lane == 0) { for (int k = 0; k < 16; k++) p.trace[((size_t)inst * p.iter_max) * 4 + k] = (double)tacc_[k]; }
 #endif
 }
 
