@@ -11,7 +11,7 @@ switch combinations that selected the defaults):
     mathematical problem alone.  Every such seed is reproduced (RANDOM 21 of 21, EDGE 20 of 20): control-step count EXACTLY, all three flags, min_margin
     to 1e-4 (measured <= 2e-8 RANDOM, <= 2.7e-6 EDGE after 100+ closed-loop steps), dist_to_goal to 1e-3.  Of the seeds whose rows agree at caps 100 and
     50, 41 of 48 (RANDOM) and 43 of 48 (EDGE) are reproduced -- at an agreement of 1e-6, EDGE 37 of 37; of the seeds whose recorded rows DIFFER between the
-    caps (acados truncated a QP: what it returned then is not reproducible by any converged solver) 7 and 12 of 52;
+    caps (acados truncated a QP: what it returned then is not reproducible by any converged solver) 7 and 14 of 52;
   * per table, the number of reproduced rows is at least the measured number minus 2 (all ten tables, both lane mappings; the two `interpolate_init`
     tables with the straight-line initial guess of robot_ocp_problem.py:293-300);
   * any other setting of the unverifiable acados-semantics switches reproduces NO row (checked for lm_scaled = 0 here).

@@ -187,9 +187,10 @@ def test_non_finite_inputs_fail_with_status_4_and_leave_the_iterate(orc):
 
 def test_interior_point_against_the_exact_active_set_solution_along_an_episode(orc):
     """How exact IS a converged solve?  Along the first 25 control steps of the reference's seed-0 RANDOM experiment (a row the replay reproduces to 4e-9) every QP
-    is also solved through its active set (helpers.exact_from_active_set; KKT conditions of the full QP verified).  The interior point stops at complementarity
-    products <= 1e-8, which pins weakly active rows only to ~sqrt(1e-8): measured over whole episodes (scripts/exact_qp_check.py -> profiles/r03_exact_qp_check.json)
-    the APPLIED control is within 3e-7 ... 2e-5 of the exact one, far-horizon inputs within 5e-5.  Asserted here with a margin: 1e-5 / 2e-4."""
+    is also solved through its active set (helpers.exact_from_active_set; KKT conditions of the full QP verified).  An interior point that stops at complementarity
+    products <= tol pins weakly active rows only to ~sqrt(tol): measured over whole episodes (scripts/exact_qp_check.py -> profiles/r03_exact_qp_check.json) the APPLIED
+    control is within 3e-7 ... 2e-5 of the exact one at qp_tol 1e-8 and within 7e-10 ... 7e-7 at the default 1e-10 -- the reason the default changed in round 3.
+    Asserted here at the default, with a margin: 1e-6 for the applied control, 1e-5 for every variable."""
     from helpers import OracleLoop, exact_from_active_set
     from mpc_gpu.world import reference_streams
     obst, noise = reference_streams("RANDOM", [0], 5, 30)
@@ -208,5 +209,5 @@ def test_interior_point_against_the_exact_active_set_solution_along_an_episode(o
         if lam_min < -1e-7 or feas < -1e-7 or res > 1e-9:
             continue            # a row within 1e-7 of its bound on the wrong side of the guess: no statement for this step
         verified += 1
-        assert np.abs(v_ip[:2] - v_ex[:2]).max() < 1e-5 and np.abs(v_ip - v_ex).max() < 2e-4, (k, np.abs(v_ip - v_ex).max())
+        assert np.abs(v_ip[:2] - v_ex[:2]).max() < 1e-6 and np.abs(v_ip - v_ex).max() < 1e-5, (k, np.abs(v_ip - v_ex).max())
     assert verified >= 20
