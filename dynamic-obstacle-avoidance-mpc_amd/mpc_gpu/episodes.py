@@ -18,7 +18,7 @@ from .solver import BatchedMpc
 
 def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, init_guess_when_error=True,
                  bug_compat_alias=True, seed=0, device=0, solver=None, n_obst=5, first_seed=0, record=False, noise=None,
-                 interpolate_init=False, status_log=False, **cfg):
+                 interpolate_init=False, status_log=False, compact_from=4096, **cfg):
     """x0 (B,5), goal (B,2), obst (B,n_obst,4) -- or a scenario name ("RANDOM" | "CENTER" | "EDGE"): instance s then starts
     from the reference generator's draw for np.random.seed(first_seed + s), produced on the device (experiments.py:26-29).
     record=True also returns simX (steps+1,B,5), obst_traj (steps+1,B,n_obst,4) and pred (steps,B,N+1,5): what the reference keeps
@@ -32,6 +32,11 @@ def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, i
     `interpolate_init` of two recorded tables) -- at the start and on every status-4 reset.
     status_log: also return, per episode, how many of its solves ended with status 2 / status 4 and the first control step with a status != 0
     (-1: none) -- `status2`, `status4`, `first_bad`.
+    compact_from: batches of at least this many episodes are COMPACTED while they run -- an episode that has reached its goal idles in its wavefront slot, and
+    with the reference's protocol the mean episode is 120-170 of 400 control steps long: every 25 control steps, once a quarter of the episodes in the batch
+    have finished, their results are parked and the live ones move together (device-side gathers, one host read of the count).  Each episode's arithmetic is
+    its own: results are those of the uncompacted run, bit for bit where an instance's result does not depend on its wavefront neighbours (one instance
+    per wavefront) and to the rounding of the wavefront sums otherwise (three per wavefront).  Off with record / status_log; None: never.
     Returns dict(table (B,6), x_last (B,5), steps_run, solves)."""
     import torch
     x0 = np.ascontiguousarray(x0, dtype=np.float64); B = x0.shape[0]
@@ -83,6 +88,12 @@ def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, i
                 raise ValueError(f"noise must be (>= {max_iter}, {B}, {n_obst}, 2), got {noise.shape}")
             dnoise = torch.from_numpy(noise).to(dev)
         k = 0
+        # compaction of finished episodes (compact_from): results of parked episodes live in full-size arrays, `ids` maps the live batch to them
+        compact = compact_from is not None and B >= compact_from and not record and not status_log
+        B0 = B
+        if compact:
+            ids = torch.arange(B, device=dev)
+            full = dict(margin=margin.clone(), flags=flags.clone(), steps=steps.clone(), x=dx0.clone())
         rec_x, rec_o, rec_p = [dx0.clone()], [dobst.clone()], []
         # "every instance has reached its goal" without stalling the queue: every 25 control steps the flag goes to pinned host memory behind an event,
         # and is looked at only once that event has passed (so the loop runs at most ~25 steps longer than it has to -- on idle instances, which cost nothing)
@@ -94,7 +105,7 @@ def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, i
             elif gen_state is not None:
                 m.noise_draw_dev(B, gen_state, nbuf, ep_flags=flags, stream=s); nz = nbuf
             elif dnoise is not None:
-                nz = dnoise[k]
+                nz = dnoise[k] if B == B0 else dnoise[k][ids]
             else:
                 nz = torch.randn(B, n_obst, 2, dtype=torch.float64, device=dev, generator=gen)
             m.closed_loop_step_dev(B, dx0, dobst, dgoal, X, U, None, None, status, iters, nz, flags=fl,
@@ -110,10 +121,28 @@ def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, i
                 if int(done_host[0]) == 1:
                     break
                 done_event = None
+            if compact and k % 25 == 0:
+                live = (flags & 1) == 0
+                n_live = int(live.sum().item())                 # (the one host read: at these batch sizes 25 control steps take tens of milliseconds)
+                if n_live == 0:
+                    break
+                if n_live <= 0.75 * B:
+                    park = ids[~live]
+                    full["margin"][park] = margin[~live]; full["flags"][park] = flags[~live]; full["steps"][park] = steps[~live]; full["x"][park] = dx0[~live]
+                    take = lambda a: a[live].contiguous()
+                    ids, dx0, dgoal, dobst, X, U = take(ids), take(dx0), take(dgoal), take(dobst), take(X), take(U)
+                    status, iters, margin, flags, steps = take(status), take(iters), take(margin), take(flags), take(steps)
+                    if gen_state is not None:
+                        gen_state, nbuf = take(gen_state), take(nbuf)
+                    B = n_live
+                continue
             if k % 25 == 0 and done_event is None:
                 done_host.copy_((flags & 1).min().to(torch.int32).reshape(1), non_blocking=True)
                 done_event = torch.cuda.Event(); done_event.record(stream)
         stream.synchronize()
+        if compact:
+            full["margin"][ids] = margin; full["flags"][ids] = flags; full["steps"][ids] = steps; full["x"][ids] = dx0
+            margin, flags, steps, dx0 = full["margin"], full["flags"], full["steps"], full["x"]
         fl_h = flags.cpu().numpy(); xl = dx0.cpu().numpy()
         table = np.column_stack([(fl_h & 4) != 0, (fl_h & 1) != 0, margin.cpu().numpy(),
                                  np.linalg.norm(xl[:, :2] - goal, axis=1), steps.cpu().numpy(), (fl_h & 2) != 0]).astype(np.float64)

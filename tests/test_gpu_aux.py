@@ -434,3 +434,31 @@ def test_cost_exchange_through_the_c_abi(env):
         assert s.comm_world() == 0
         s.comm_init(0, 1, mpc_gpu.BatchedMpc.comm_unique_id())      # a new communicator on the same handle
         assert (s.allgather_cost(np.ones(3)) == 1.0).all()
+
+
+@pytest.mark.gpu
+def test_compaction_of_finished_episodes_changes_nothing(env):
+    """run_episodes(compact_from=...) parks finished episodes and moves the live ones together every 25 control steps.  With one instance per wavefront (300 episodes:
+    the stage-split mapping) every episode's arithmetic is independent of its neighbours: the table is that of the uncompacted run BIT FOR BIT, host-fed and
+    device-made noise alike.  With three instances per wavefront (6000 episodes) the wavefront sums round differently once the neighbours change: >= 99 % of the rows
+    identical, the statistics equal."""
+    mpc_gpu, _ = env
+    from mpc_gpu.world import reference_streams
+    B = 300
+    x0 = np.tile([-7.0, -7.0, np.pi / 4, 0, 0], (B, 1)); goal = np.tile([7.0, 7.0], (B, 1))
+    kw = dict(N=20, Tf=2.0, max_iter=400, random_move=True, init_guess_when_error=True, qp_iter_max=100)
+    a = mpc_gpu.run_episodes(x0, goal, "RANDOM", first_seed=0, compact_from=None, **kw)
+    b = mpc_gpu.run_episodes(x0, goal, "RANDOM", first_seed=0, compact_from=64, **kw)
+    assert np.array_equal(a["table"], b["table"]) and np.array_equal(a["x_last"], b["x_last"]) and a["solves"] == b["solves"]
+    assert b["steps_run"] <= a["steps_run"]
+    obst, noise = reference_streams("EDGE", range(B), 5, 400)
+    c = mpc_gpu.run_episodes(x0, goal, obst, noise=noise, compact_from=None, **kw)
+    d = mpc_gpu.run_episodes(x0, goal, obst, noise=noise, compact_from=64, **kw)
+    assert np.array_equal(c["table"], d["table"])
+    B = 6000
+    x0 = np.tile([-7.0, -7.0, np.pi / 4, 0, 0], (B, 1)); goal = np.tile([7.0, 7.0], (B, 1))
+    e = mpc_gpu.run_episodes(x0, goal, "RANDOM", first_seed=0, compact_from=None, **kw)["table"]
+    f = mpc_gpu.run_episodes(x0, goal, "RANDOM", first_seed=0, **kw)["table"]                     # default: compaction from 4096 episodes
+    same = np.all(e == f, axis=1)
+    assert same.mean() >= 0.99, same.mean()
+    assert np.abs(e[:, [0, 1, 5]].mean(axis=0) - f[:, [0, 1, 5]].mean(axis=0)).max() < 0.005 and abs(e[:, 4].mean() - f[:, 4].mean()) < 0.5
