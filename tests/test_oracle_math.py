@@ -211,3 +211,30 @@ def test_interior_point_against_the_exact_active_set_solution_along_an_episode(o
         verified += 1
         assert np.abs(v_ip[:2] - v_ex[:2]).max() < 1e-6 and np.abs(v_ip - v_ex).max() < 1e-5, (k, np.abs(v_ip - v_ex).max())
     assert verified >= 20
+
+
+@pytest.mark.parametrize("N,no,steps", [(20, 3, 8), (50, 10, 3)])
+def test_exact_active_set_solution_for_the_workload_sizes(orc, N, no, steps):
+    """The same check at the sizes of BASELINE's workloads (3 obstacles / N = 20; 10 obstacles / N = 50), for which the reference holds no recorded output at all:
+    along a few closed-loop steps of a randomized scenario the interior point's step equals the exact active-set solution of the exported QP."""
+    from helpers import OracleLoop, exact_from_active_set
+    x0, goal, obst = random_batch(2, no, seed=77)
+    cfg = orc.config(N, no, 0.1 * N)
+    verified = 0
+    for b in range(2):
+        lp = OracleLoop(orc, cfg, x0[b], goal[b], obst[b], reset_on_fail=True, alias=False)
+        for k in range(steps):
+            P = orc.predict_params(cfg, lp.obst)
+            q = orc.export_qp(cfg, lp.x, P, lp.goal, lp.X, lp.U)
+            X0, U0 = lp.X.copy(), lp.U.copy()
+            r = lp.step(None)
+            if r is None or r["status"] != 0:
+                continue
+            dX, dU = r["X"] - X0, r["U"] - U0
+            v_ip = np.concatenate([np.concatenate([dU[i], dX[i + 1]]) for i in range(N)])
+            v_ex, lam_min, feas, _, res = exact_from_active_set(q, v_ip)
+            if lam_min < -1e-7 or feas < -1e-7 or res > 1e-9:
+                continue
+            verified += 1
+            assert np.abs(v_ip[:2] - v_ex[:2]).max() < 1e-6 and np.abs(v_ip - v_ex).max() < 1e-5, (b, k, np.abs(v_ip - v_ex).max())
+    assert verified >= steps
