@@ -814,3 +814,31 @@ def test_instance_scheduling_with_fewer_obstacles_than_rows(built, N, no, B):
     assert (g["status"][:200] == o["status"]).all()
     ok = o["status"] == 0
     assert np.median(np.abs(X[:200] - o["X"]).reshape(200, -1).max(1)[ok]) < 1e-9
+
+
+@pytest.mark.parametrize("N,no,B", [(20, 3, 8), (20, 5, 8), (50, 10, 4)])
+def test_hip_path_against_the_exact_active_set_solution(env, N, no, B):
+    """The HIP path against a solution that owes NO interior point anything (helpers.exact_from_active_set on the exported QP; the export is the linearisation the kernels
+    are checked against to 1e-12 in test_linearize_parity): the first RTI step of B random scenarios, applied control to 1e-6, every variable to 1e-5."""
+    from helpers import exact_from_active_set
+    mpc_gpu, orc = env
+    x0, goal, obst = random_batch(B, no, seed=900 + N + no)
+    cfg = orc.config(N, no, 0.1 * N)
+    P = oracle_P(orc, cfg, obst); X, U = oracle_guess(orc, cfg, x0)
+    with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
+        s.set_warmstart(X, U)
+        g = s.solve(x0, P, goal)
+        Xg, Ug = s.get_traj(B)
+    verified = 0
+    for b in range(B):
+        if g["status"][b] != 0:
+            continue
+        q = orc.export_qp(cfg, x0[b], P[b], goal[b], X[b], U[b])
+        dX, dU = Xg[b] - X[b], Ug[b] - U[b]
+        v_gpu = np.concatenate([np.concatenate([dU[i], dX[i + 1]]) for i in range(N)])
+        v_ex, lam_min, feas, _, res = exact_from_active_set(q, v_gpu)
+        if lam_min < -1e-7 or feas < -1e-7 or res > 1e-9:
+            continue
+        verified += 1
+        assert np.abs(v_gpu[:2] - v_ex[:2]).max() < 1e-6 and np.abs(v_gpu - v_ex).max() < 1e-5, (b, np.abs(v_gpu - v_ex).max())
+    assert verified >= B // 2
