@@ -100,6 +100,10 @@ mpc::KParams make_params(const mpc_config &c, int batch)
     p.r2 = c.r_safe * c.r_safe;
     p.slack_a = c.slack_a; p.slack_b = c.slack_b; p.ss = c.slack_scale_dt ? p.dt : 1.0;
     p.tol = c.qp_tol; p.mu0 = c.mu0; p.thr0 = c.thr0;
+    const bool truncate = c.qp_fail_policy == 1;      // oracle/mpc_oracle.c ipm_solve: the same three tests
+    p.mu_div = truncate ? 1e300 : mpc::kMuDiverged * c.mu0;
+    p.mu_cap = truncate ? INFINITY : mpc::kMuCapFailed * c.mu0;
+    p.mu_settled = truncate ? INFINITY : c.mu0;
     return p;
 }
 
@@ -419,6 +423,7 @@ int mpc_default_config(mpc_config *c, int N, int n_obst, double Tf)
     c->arena[0] = -8.0; c->arena[1] = 8.0; c->arena[2] = -8.0; c->arena[3] = 8.0;   // world_specification.py:7-10
     c->bug_compat_predict = 1;
     c->mu0 = 1e4; c->thr0 = 1e-1;
+    c->qp_fail_policy = 0;
     return MPC_OK;
 }
 
@@ -429,6 +434,7 @@ int mpc_create(const mpc_config *cfg, int device, int max_batch, mpc_handle **ou
     if (cfg->n_obst < 1 || cfg->n_obst > 10) return fail(MPC_ERR_ARG, "n_obst must be in [1, 10]");
     if (max_batch < 1) return fail(MPC_ERR_ARG, "max_batch must be >= 1");
     if (!(cfg->Tf > 0) || !(cfg->qp_tol > 0) || cfg->qp_iter_max < 1) return fail(MPC_ERR_ARG, "Tf, qp_tol, qp_iter_max must be positive");
+    if (cfg->qp_fail_policy != 0 && cfg->qp_fail_policy != 1) return fail(MPC_ERR_ARG, "qp_fail_policy must be 0 (divergence tests) or 1 (truncate at qp_iter_max)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(MPC_ERR_NODEVICE, "no HIP device visible: libmpcgpu has no CPU path");

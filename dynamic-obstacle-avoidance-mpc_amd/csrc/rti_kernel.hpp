@@ -70,6 +70,8 @@ struct KParams {
     double r2;                // r_safe^2
     double slack_a, slack_b, ss;  // ss: penalty scale for stages < N (dt or 1)
     double tol, mu0, thr0;
+    double mu_div, mu_cap, mu_settled;   // the divergence tests of the interior point as thresholds on mu (mpc_api.hip::make_params): kMuDiverged mu0, kMuCapFailed mu0, mu0 --
+                                         // or, mpc_config.qp_fail_policy = 1 ("truncate"), 1e300 / inf / inf: a diverging solve runs to the iteration cap and ends as status 2
     const double *x0, *P, *goal;
     const double *alpha;      // optional [B][N+1]: explicit slack weights zl_i = Zl_i (mpc_set_slack_schedule); null = the schedule of robot_ocp_problem.py:145-148
     double *X, *U, *u0, *cost;
@@ -89,7 +91,8 @@ struct KParams {
     double *trace;            // optional [batch][iter_max][4] = (mu, sigma, alpha, cmax) per IPM iteration (debug)
 };
 
-static constexpr double kTLMin = 1e-13;  // floor for lam and t (see oracle/mpc_oracle.c TL_MIN)
+static constexpr double kTLMin = 1e-11;  // floor for lam and t (oracle/mpc_oracle.c TL_MIN: 1e-13 until round 3 -- the weights lam / t of collapsed pairs then cost the
+                                         // end-game's Newton step its last digits: worst distance from the exact QP solution 7e-4 -> 8e-6 on first solves of C5's problem)
 // Mehrotra constants shared with the oracle (oracle/mpc_oracle.c FRAC_TO_BOUNDARY, sigma): step = kFracToBoundary * (largest step that keeps t, lam > 0),
 // centring sigma = (mu_aff / mu)^2.  Scanned on the oracle over three problem classes: 0.999995 / square needs 4 - 7 % fewer
 // iterations than round 1's 0.9995 / cube at the same number of non-converged instances.
@@ -2217,9 +2220,9 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         const double mu = msum * inv_items;
         const double lin = rhoPi * lin0;
         if (running) {
-            if (!(mu == mu) || !(fabs(mu) <= kMuDiverged * p.mu0)) { status = 4; running = false; it_done = it; }      // NaN, or diverged: an infeasible QP
+            if (!(mu == mu) || !(fabs(mu) <= p.mu_div)) { status = 4; running = false; it_done = it; }      // NaN, or diverged: an infeasible QP
             else if (lin <= p.tol && cmax <= p.tol) { status = 0; running = false; it_done = it; }
-            else if (it >= p.iter_max) { status = (mu > kMuCapFailed * p.mu0 || (it >= kMuCapSettled && mu > p.mu0)) ? 4 : 2; running = false; it_done = it; }      // at the cap with mu above a healthy solve's: diverging or stalled, not slow
+            else if (it >= p.iter_max) { status = (mu > p.mu_cap || (it >= kMuCapSettled && mu > p.mu_settled)) ? 4 : 2; running = false; it_done = it; }      // at the cap with mu above a healthy solve's: diverging or stalled, not slow
         }
         if (__ballot(running) == 0ull) break;
         MPC_TICK(0);
@@ -2767,9 +2770,9 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         const double mu = msum * inv_items;
         const double lin = rhoPi * lin0;
         if (running) {
-            if (!(mu == mu) || !(fabs(mu) <= kMuDiverged * p.mu0)) { status = 4; running = false; it_done = it; }      // NaN, or diverged: an infeasible QP
+            if (!(mu == mu) || !(fabs(mu) <= p.mu_div)) { status = 4; running = false; it_done = it; }      // NaN, or diverged: an infeasible QP
             else if (lin <= p.tol && cmax <= p.tol) { status = 0; running = false; it_done = it; }
-            else if (it >= p.iter_max) { status = (mu > kMuCapFailed * p.mu0 || (it >= kMuCapSettled && mu > p.mu0)) ? 4 : 2; running = false; it_done = it; }      // at the cap with mu above a healthy solve's: diverging or stalled, not slow
+            else if (it >= p.iter_max) { status = (mu > p.mu_cap || (it >= kMuCapSettled && mu > p.mu_settled)) ? 4 : 2; running = false; it_done = it; }      // at the cap with mu above a healthy solve's: diverging or stalled, not slow
         }
         if (__ballot(running) == 0ull) break;
         MPC_TICK(0);

@@ -392,9 +392,9 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
         const double mu = msum * inv_items;
         const double lin = rhoPi * lin0;
         if (running) {
-            if (!(mu == mu) || !(fabs(mu) <= kMuDiverged * p.mu0)) { status = 4; running = false; it_done = it; }      // NaN, or diverged: an infeasible QP
+            if (!(mu == mu) || !(fabs(mu) <= p.mu_div)) { status = 4; running = false; it_done = it; }      // NaN, or diverged: an infeasible QP
             else if (lin <= p.tol && cmax <= p.tol) { status = 0; running = false; it_done = it; }
-            else if (it >= p.iter_max) { status = (mu > kMuCapFailed * p.mu0 || (it >= kMuCapSettled && mu > p.mu0)) ? 4 : 2; running = false; it_done = it; }      // at the cap with mu above a healthy solve's: diverging or stalled, not slow
+            else if (it >= p.iter_max) { status = (mu > p.mu_cap || (it >= kMuCapSettled && mu > p.mu_settled)) ? 4 : 2; running = false; it_done = it; }      // at the cap with mu above a healthy solve's: diverging or stalled, not slow
         }
         if (!running) break;      // wave-uniform: one instance per wavefront
         MPC_TICK(0);

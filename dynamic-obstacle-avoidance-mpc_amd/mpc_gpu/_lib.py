@@ -5,7 +5,10 @@ point needs a HIP device.  Loading the library and reading its symbol table work
 """
 import ctypes as C
 import os
+import shutil
 import subprocess
+import sys
+import tempfile
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
@@ -33,6 +36,7 @@ class MpcConfig(C.Structure):
         ("bx_terminal", _i32), ("soft_h", _i32),
         ("arena", _d * 4), ("bug_compat_predict", _i32),
         ("mu0", _d), ("thr0", _d),
+        ("qp_fail_policy", _i32),
     ]
 
 
@@ -115,15 +119,27 @@ def _audit_isa(path):
     instructions the register allocator placed in front of the exec restore of an if / else join (rule P1: the cause of the build variant
     that stored status / iterations / cost to wrong addresses).  Returns the findings as text ('' = clean)."""
     script = os.path.join(REPO_ROOT, "scripts", "isa_audit.py")
-    r = subprocess.run([os.environ.get("PYTHON", "python3"), script, path], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, script, path], capture_output=True, text=True)
     return "" if r.returncode == 0 else (r.stdout + r.stderr)
+
+
+def audit(listing):
+    """Audit entry point for a library that did not come out of build() (MPC_GPU_LIB diagnostic builds, which build() uses as they are): pass the
+    device listing of THAT compile -- `hipcc ... -save-temps` leaves it as mpc_api-hip-amdgcn-amd-amdhsa-gfx950.s beside the objects; the rules
+    need the compiler's labels and inline-asm markers, which a disassembly of the .so no longer has.  Raises MpcError on any finding."""
+    findings = _audit_isa(listing)
+    if findings:
+        raise MpcError("ISA audit failed (scripts/isa_audit.py):\n" + findings[-4000:])
+    return True
 
 
 def build(force=False, verbose=False, audit=True):
     """Compile csrc/*.hip for gfx950 into libmpcgpu.so (in-tree).  hipcc cross-compiles without a GPU.
-    The same command with -S runs beside it and its listing (build/mpc_api-gfx950.s) is audited: a build that fails the audit is deleted and
-    the call raises -- a library with a lost-lane copy in it stores to wrong addresses without any test having to notice (MPC_SKIP_ISA_AUDIT=1
-    skips the listing, for diagnostic builds)."""
+    ONE compile (-save-temps, in a private directory): the device listing that is audited (kept as build/mpc_api-gfx950.s) is the assembler input of
+    the code object that ships, not the output of a second compiler run.  A build that fails the audit is deleted and the call raises -- a library
+    with a lost-lane copy in it stores to wrong addresses without any test having to notice (MPC_SKIP_ISA_AUDIT=1 skips the audit, for diagnostic
+    builds; mpc_gpu._lib.audit(listing) is the entry point for a library supplied through MPC_GPU_LIB).  Concurrent builders (ranks, pytest-xdist) each work under
+    their own temporary names and the last os.replace wins."""
     if os.environ.get("MPC_GPU_LIB"):
         return LIB_PATH                  # a diagnostic build supplied by the caller is used as it is
     srcs = sources()
@@ -134,30 +150,28 @@ def build(force=False, verbose=False, audit=True):
         hipcc = "hipcc"
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value"] + os.environ.get("MPC_EXTRA_HIPCC_FLAGS", "").split()
     src = os.path.join(CSRC, "mpc_api.hip")
-    cmd = [hipcc] + flags + ["-fPIC", "-shared", "-o", LIB_PATH + ".new", src]
-    audit = audit and not os.environ.get("MPC_SKIP_ISA_AUDIT")
-    lister = None
-    if audit:
-        os.makedirs(os.path.dirname(ISA_PATH), exist_ok=True)
-        lister = subprocess.Popen([hipcc] + flags + ["--cuda-device-only", "-S", "-o", ISA_PATH, src], stderr=subprocess.PIPE, text=True)
+    do_audit = audit and not os.environ.get("MPC_SKIP_ISA_AUDIT")
+    os.makedirs(os.path.dirname(ISA_PATH), exist_ok=True)
+    work = tempfile.mkdtemp(prefix=f"tmp.{os.getpid()}.", dir=os.path.dirname(ISA_PATH))
+    new = f"{LIB_PATH}.{os.getpid()}.new"
+    cmd = [hipcc] + flags + ["-fPIC", "-shared"] + (["-save-temps"] if do_audit else []) + ["-o", new, src]
     if verbose:
         print(" ".join(cmd))
     try:
-        subprocess.check_call(cmd)
-    except BaseException:
-        if lister is not None:
-            lister.kill()
-        raise
-    if lister is not None:
-        err = lister.communicate()[1]
-        if lister.returncode != 0:
-            os.remove(LIB_PATH + ".new")
-            raise MpcError(f"device listing failed:\n{err}")
-        findings = _audit_isa(ISA_PATH)
-        if findings:
-            os.remove(LIB_PATH + ".new")
-            raise MpcError("ISA audit of the new build failed (scripts/isa_audit.py; the previous library, if any, is left in place):\n" + findings[-4000:])
-    os.replace(LIB_PATH + ".new", LIB_PATH)
+        subprocess.check_call(cmd, cwd=work)
+        if do_audit:
+            listing = os.path.join(work, "mpc_api-hip-amdgcn-amd-amdhsa-gfx950.s")
+            if not os.path.exists(listing):
+                raise MpcError(f"hipcc -save-temps left no device listing in {work}")
+            findings = _audit_isa(listing)
+            if findings:
+                raise MpcError("ISA audit of the new build failed (scripts/isa_audit.py; the previous library, if any, is left in place):\n" + findings[-4000:])
+            os.replace(listing, ISA_PATH)
+        os.replace(new, LIB_PATH)
+    finally:
+        if os.path.exists(new):
+            os.remove(new)
+        shutil.rmtree(work, ignore_errors=True)
     return LIB_PATH
 
 

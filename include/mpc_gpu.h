@@ -66,6 +66,12 @@ typedef struct mpc_config {
     int32_t bug_compat_predict; /* look-ahead uses vx = vy, src/utils/visualization.py:69  default 1 */
     double mu0;             /* interior-point cold start: lam = mu0 / t                          */
     double thr0;            /*                            t = max(rho, thr0)                     */
+    int32_t qp_fail_policy; /* what a QP that does not converge does (robot_ocp_problem.py:131 qp_solver_iter_max, :203-205 status 4 -> set_initial_guess()):
+                               0: the divergence tests are on -- mu > 1e8 mu0 ends the solve at once with status 4 (iterate untouched), and a solve that
+                                  reaches qp_iter_max with mu > 1e4 mu0 (from iteration 20 on: above mu0) is a failure (4), not a slow solve (2);
+                               1: "truncate" -- no divergence test: the interior point runs to qp_iter_max and its step is applied (status 2), as acados'
+                                  SQP_RTI did with a HPIPM solve that returned MAX_ITER; NaN / overflow / step collapse stay status 4.
+                               default: what the reference's recorded tables select                                    */
 } mpc_config;
 
 typedef struct mpc_handle mpc_handle;

@@ -22,7 +22,39 @@
 #define NX ORC_NX
 #define NU ORC_NU
 #define NZ ORC_NZ
-#define TL_MIN 1e-13
+/* floor of t and lam.  1e-13 until round 3; 1e-11 since round 4: a pair that collapses to the floor enters the reduced Hessian with the weight
+ * lam / t, and at 1e-13 those weights (1e15 and more) cost the Newton step of the end-game its last digits -- measured against the EXACT solution of
+ * the QP (tests/helpers.py::exact_qp) on first solves of C5's problem: worst 7.3e-4 -> 7.5e-6, 2.7 % -> 1.0 % of the instances beyond 1e-6, same
+ * iteration counts (scripts/tail_scan_cpu.py).  Shared with the HIP kernels (rti_kernel.hpp kTLMin).  Must stay below qp_tol:
+ * an active row's residual rho - t is the floor itself. */
+#define TL_MIN 1e-11
+
+/* Per-thread workspace of the solve path (round 4): the ~35 arrays of one solve come from a thread-local arena that is reset, not freed, when the
+ * outermost solve returns -- the batch driver's OpenMP threads used to malloc / free each of them per solve, and the all-core cpu_baseline of
+ * bench.py measured glibc's allocator (15x on 128 cores).  Outside a solve (depth 0: orc_export_qp, orc_linearize, ...) WS_ALLOC is malloc.
+ * The arithmetic is untouched: results are bit-identical to the malloc build (tests/test_oracle_golden.py). */
+#define WS_CHUNKS 32
+typedef struct { char *chunk[WS_CHUNKS]; size_t cap[WS_CHUNKS]; size_t used; int cur, n, depth; } ws_t;
+static _Thread_local ws_t g_ws;
+static void ws_enter(void) { g_ws.depth++; }
+static void ws_leave(void) { if (--g_ws.depth == 0) { g_ws.cur = 0; g_ws.used = 0; } }
+static void *ws_alloc(size_t n)
+{
+    if (g_ws.depth == 0) return malloc(n);
+    n = (n + 63) & ~(size_t)63;
+    while (g_ws.cur < g_ws.n && g_ws.used + n > g_ws.cap[g_ws.cur]) { g_ws.cur++; g_ws.used = 0; }
+    if (g_ws.cur == g_ws.n) {
+        if (g_ws.n == WS_CHUNKS) abort();
+        size_t cap = n > ((size_t)1 << 20) ? n : ((size_t)1 << 20);
+        g_ws.chunk[g_ws.n] = aligned_alloc(64, cap); g_ws.cap[g_ws.n] = cap; g_ws.n++; g_ws.used = 0;
+        if (!g_ws.chunk[g_ws.cur]) abort();
+    }
+    void *r = g_ws.chunk[g_ws.cur] + g_ws.used; g_ws.used += n;
+    return r;
+}
+static void ws_free(void *q) { if (g_ws.depth == 0) free(q); }
+#define WS_ALLOC(n) ws_alloc(n)
+#define WS_FREE(q) ws_free(q)
 
 static const int IDXBX[4] = {0, 1, 3, 4}; /* robot_ocp_problem.py:93 */
 
@@ -51,6 +83,7 @@ void orc_default_config(orc_config *c, int N, int n_obst, double Tf)
     c->arena[0] = -8.0; c->arena[1] = 8.0; c->arena[2] = -8.0; c->arena[3] = 8.0;
     c->bug_compat_predict = 1;
     c->mu0 = 1e4; c->thr0 = 1e-1;
+    c->qp_fail_policy = 0;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -373,8 +406,8 @@ static double cost_with_alpha(const orc_config *c, const double *x0, const doubl
                               const double *X, const double *U, const double *alpha_in)
 {
     int N = c->N, no = c->n_obst; double cs = stage_cs(c), ss = stage_ss(c);
-    double *alpha = (double *)malloc(sizeof(double) * (N + 1));
-    double *h = (double *)malloc(sizeof(double) * no);
+    double *alpha = (double *)WS_ALLOC(sizeof(double) * (N + 1));
+    double *h = (double *)WS_ALLOC(sizeof(double) * no);
     if (alpha_in) memcpy(alpha, alpha_in, sizeof(double) * (N + 1)); else orc_slack_alpha(c, x0, goal, alpha);
     double J = 0;
     for (int i = 0; i <= N; i++) {
@@ -394,7 +427,7 @@ static double cost_with_alpha(const orc_config *c, const double *x0, const doubl
             J += sc * alpha[i] * (v + 0.5 * v * v);
         }
     }
-    free(alpha); free(h);
+    WS_FREE(alpha); WS_FREE(h);
     return J;
 }
 
@@ -430,7 +463,7 @@ typedef struct {
 
 static void qp_free(qp_t *Q)
 {
-    free(Q->Hd); free(Q->q); free(Q->A); free(Q->B); free(Q->b); free(Q->it); free(Q->zs); free(Q->Zs); free(Q->s_stage);
+    WS_FREE(Q->Hd); WS_FREE(Q->q); WS_FREE(Q->A); WS_FREE(Q->B); WS_FREE(Q->b); WS_FREE(Q->it); WS_FREE(Q->zs); WS_FREE(Q->Zs); WS_FREE(Q->s_stage);
 }
 
 static void add_box(qp_t *Q, int stage, int zidx, double val, double lo, double hi)
@@ -447,14 +480,14 @@ static void build_qp(const orc_config *c, const double *x0, const double *P, con
 {
     int N = c->N, no = c->n_obst; double dt = c->Tf / N;
     Q->N = N;
-    Q->Hd = malloc(sizeof(double[NZ]) * (N + 1)); Q->q = malloc(sizeof(double[NZ]) * (N + 1));
-    Q->A = malloc(sizeof(double[25]) * N); Q->B = malloc(sizeof(double[10]) * N); Q->b = malloc(sizeof(double[NX]) * N);
+    Q->Hd = WS_ALLOC(sizeof(double[NZ]) * (N + 1)); Q->q = WS_ALLOC(sizeof(double[NZ]) * (N + 1));
+    Q->A = WS_ALLOC(sizeof(double[25]) * N); Q->B = WS_ALLOC(sizeof(double[10]) * N); Q->b = WS_ALLOC(sizeof(double[NX]) * N);
     int max_items = (N + 1) * (4 + 8 + 2 * no);
-    Q->it = malloc(sizeof(item_t) * max_items); Q->n_items = 0;
-    Q->zs = malloc(sizeof(double) * (N + 1) * no); Q->Zs = malloc(sizeof(double) * (N + 1) * no);
-    Q->s_stage = malloc(sizeof(int) * (N + 1) * no); Q->n_s = 0;
-    double *alpha = malloc(sizeof(double) * (N + 1));
-    double *h = malloc(sizeof(double) * no), *dh = malloc(sizeof(double) * 2 * no);
+    Q->it = WS_ALLOC(sizeof(item_t) * max_items); Q->n_items = 0;
+    Q->zs = WS_ALLOC(sizeof(double) * (N + 1) * no); Q->Zs = WS_ALLOC(sizeof(double) * (N + 1) * no);
+    Q->s_stage = WS_ALLOC(sizeof(int) * (N + 1) * no); Q->n_s = 0;
+    double *alpha = WS_ALLOC(sizeof(double) * (N + 1));
+    double *h = WS_ALLOC(sizeof(double) * no), *dh = WS_ALLOC(sizeof(double) * 2 * no);
     if (alpha_in) memcpy(alpha, alpha_in, sizeof(double) * (N + 1)); else orc_slack_alpha(c, x0, goal, alpha);
     for (int k = 0; k < 5; k++) Q->d0[k] = x0[k] - X[k];    /* lbx_0 = ubx_0 = x0, robot_ocp_problem.py:191-192 */
     for (int i = 0; i < N; i++) {
@@ -487,7 +520,7 @@ static void build_qp(const orc_config *c, const double *x0, const double *P, con
             }
         }
     }
-    free(alpha); free(h); free(dh);
+    WS_FREE(alpha); WS_FREE(h); WS_FREE(dh);
 }
 
 /* dense helpers, row-major */
@@ -652,20 +685,20 @@ void orc_set_trace(double *buf, int cap) { g_trace = buf; g_trace_cap = cap; }
 static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, double *kkt)
 {
     int N = Q->N, ni = Q->n_items, ns = Q->n_s;
-    double (*rg)[NZ] = malloc(sizeof(double[NZ]) * (N + 1));
-    double (*rb)[NX] = malloc(sizeof(double[NX]) * (N + 1));
-    double *rs = malloc(sizeof(double) * (ns + 1));
-    double (*Ht)[49] = malloc(sizeof(double[49]) * (N + 1));
-    double (*gt)[NZ] = malloc(sizeof(double[NZ]) * (N + 1));
-    double (*dz)[NZ] = malloc(sizeof(double[NZ]) * (N + 1));
-    double (*dpi)[NX] = malloc(sizeof(double[NX]) * (N + 1));
-    double *ds = malloc(sizeof(double) * (ns + 1)), *yds = malloc(sizeof(double) * (ns + 1));
-    double *w1 = malloc(sizeof(double) * (ns + 1)), *w2 = malloc(sizeof(double) * (ns + 1));
-    double *be1 = malloc(sizeof(double) * (ns + 1)), *be2 = malloc(sizeof(double) * (ns + 1));
-    int *soft_row = malloc(sizeof(int) * (ns + 1)), *soft_pos = malloc(sizeof(int) * (ns + 1));
+    double (*rg)[NZ] = WS_ALLOC(sizeof(double[NZ]) * (N + 1));
+    double (*rb)[NX] = WS_ALLOC(sizeof(double[NX]) * (N + 1));
+    double *rs = WS_ALLOC(sizeof(double) * (ns + 1));
+    double (*Ht)[49] = WS_ALLOC(sizeof(double[49]) * (N + 1));
+    double (*gt)[NZ] = WS_ALLOC(sizeof(double[NZ]) * (N + 1));
+    double (*dz)[NZ] = WS_ALLOC(sizeof(double[NZ]) * (N + 1));
+    double (*dpi)[NX] = WS_ALLOC(sizeof(double[NX]) * (N + 1));
+    double *ds = WS_ALLOC(sizeof(double) * (ns + 1)), *yds = WS_ALLOC(sizeof(double) * (ns + 1));
+    double *w1 = WS_ALLOC(sizeof(double) * (ns + 1)), *w2 = WS_ALLOC(sizeof(double) * (ns + 1));
+    double *be1 = WS_ALLOC(sizeof(double) * (ns + 1)), *be2 = WS_ALLOC(sizeof(double) * (ns + 1));
+    int *soft_row = WS_ALLOC(sizeof(int) * (ns + 1)), *soft_pos = WS_ALLOC(sizeof(int) * (ns + 1));
     ricc_t R;
-    R.P = malloc(sizeof(double[25]) * (N + 1)); R.p = malloc(sizeof(double[NX]) * (N + 1));
-    R.K = malloc(sizeof(double[10]) * N); R.k = malloc(sizeof(double[NU]) * N); R.L = malloc(sizeof(double[4]) * N); R.Mxu = malloc(sizeof(double[10]) * N);
+    R.P = WS_ALLOC(sizeof(double[25]) * (N + 1)); R.p = WS_ALLOC(sizeof(double[NX]) * (N + 1));
+    R.K = WS_ALLOC(sizeof(double[10]) * N); R.k = WS_ALLOC(sizeof(double[NU]) * N); R.L = WS_ALLOC(sizeof(double[4]) * N); R.Mxu = WS_ALLOC(sizeof(double[10]) * N);
     double re0[5], res[4];
     int status = 2, it = 0;
 
@@ -688,7 +721,8 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
         /* divergence (an infeasible QP: the hard boxes cannot be met): the complementarity measure of a healthy solve never leaves [~0, 1e2 mu0]
          * (measured: <= 7e5 at mu0 = 1e4), that of an infeasible one grows without bound -- stop at 1e8 mu0 instead of iterating until the step
          * collapses or the cap; shared with the HIP kernels (status 4, iterate untouched) */
-        if (mu > MU_DIVERGED * c->mu0) { status = 4; break; }
+        if (c->qp_fail_policy == 0 && mu > MU_DIVERGED * c->mu0) { status = 4; break; }
+        if (!(fabs(mu) <= 1e300)) { status = 4; break; }      /* (qp_fail_policy 1: only an overflow ends a diverging solve early) */
         /* Termination (shared spec with the HIP kernel): linear residuals (dynamics, initial condition, rho - t; they
          * all decay by the same factor prod(1 - alpha_k)) and the largest complementarity product below qp_tol.
          * The stationarity residual res[0] is REPORTED, not gated: late in the iteration its rounding floor is
@@ -699,7 +733,7 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
          * otherwise: max-iter, step applied.  From iteration MU_CAP_SETTLED on the bar is mu0 itself: a healthy solve is three orders of
          * magnitude below its starting value by then (measured: <= 12 at iteration 20, but up to 1.01e4 at iteration 10), a stalled infeasible one orders above --
          * with the single bar at 1e4 mu0 the stalled ones straddled it (scripts/fuzz_parity.py, hard obstacle rows) */
-        if (it >= c->qp_iter_max) { status = (mu > MU_CAP_FAILED * c->mu0 || (it >= MU_CAP_SETTLED && mu > c->mu0)) ? 4 : 2; break; }
+        if (it >= c->qp_iter_max) { status = (c->qp_fail_policy == 0 && (mu > MU_CAP_FAILED * c->mu0 || (it >= MU_CAP_SETTLED && mu > c->mu0))) ? 4 : 2; break; }
 
         double sigma = 0.0; double alpha = 1.0, alphad = 1.0;
         for (int pass = 0; pass < 2; pass++) {
@@ -781,8 +815,8 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
     }
     if (iters_out) *iters_out = it;
     if (kkt) for (int a = 0; a < 4; a++) kkt[a] = res[a];
-    free(rg); free(rb); free(rs); free(Ht); free(gt); free(dz); free(dpi); free(ds); free(yds); free(w1); free(w2); free(be1); free(be2); free(soft_row); free(soft_pos);
-    free(R.P); free(R.p); free(R.K); free(R.k); free(R.L); free(R.Mxu);
+    WS_FREE(rg); WS_FREE(rb); WS_FREE(rs); WS_FREE(Ht); WS_FREE(gt); WS_FREE(dz); WS_FREE(dpi); WS_FREE(ds); WS_FREE(yds); WS_FREE(w1); WS_FREE(w2); WS_FREE(be1); WS_FREE(be2); WS_FREE(soft_row); WS_FREE(soft_pos);
+    WS_FREE(R.P); WS_FREE(R.p); WS_FREE(R.K); WS_FREE(R.k); WS_FREE(R.L); WS_FREE(R.Mxu);
     return status;
 }
 
@@ -791,6 +825,7 @@ int orc_rti_solve_alpha(const orc_config *c, const double *x0, const double *P, 
                         double *X, double *U, double *u0, double *cost, int *iters, double *kkt)
 {
     int N = c->N;
+    ws_enter();
     {   /* non-finite inputs fail at once (status 4, iterate untouched): shared specification with the HIP kernels, which would otherwise
          * lose a NaN in the fmax() of their residual norms */
         double fin = goal[0] + goal[1];
@@ -803,12 +838,13 @@ int orc_rti_solve_alpha(const orc_config *c, const double *x0, const double *P, 
             if (cost) *cost = NAN;
             if (iters) *iters = 0;
             if (kkt) for (int a = 0; a < 4; a++) kkt[a] = NAN;
+            ws_leave();
             return 4;
         }
     }
     qp_t Q; build_qp(c, x0, P, goal, X, U, &Q, alpha);
     iter_t I;
-    I.z = malloc(sizeof(double[NZ]) * (N + 1)); I.pi = malloc(sizeof(double[NX]) * (N + 1)); I.s = malloc(sizeof(double) * (Q.n_s + 1));
+    I.z = WS_ALLOC(sizeof(double[NZ]) * (N + 1)); I.pi = WS_ALLOC(sizeof(double[NX]) * (N + 1)); I.s = WS_ALLOC(sizeof(double) * (Q.n_s + 1));
     int status = ipm_solve(c, &Q, &I, iters, kkt);
     if (status != 4) { /* full step; a max-iter QP still has its step applied (3.2-6) */
         for (int i = 0; i <= N; i++) for (int k = 0; k < 5; k++) X[5 * i + k] += I.z[i][2 + k];
@@ -816,7 +852,8 @@ int orc_rti_solve_alpha(const orc_config *c, const double *x0, const double *P, 
     }
     if (u0) { u0[0] = U[0]; u0[1] = U[1]; }
     if (cost) *cost = cost_with_alpha(c, x0, P, goal, X, U, alpha);
-    free(I.z); free(I.pi); free(I.s); qp_free(&Q);
+    WS_FREE(I.z); WS_FREE(I.pi); WS_FREE(I.s); qp_free(&Q);
+    ws_leave();
     return status;
 }
 

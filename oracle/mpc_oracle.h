@@ -65,6 +65,13 @@ typedef struct orc_config {
     /* interior-point start (cold start every call, as HPIPM with warm_start=0)          */
     double mu0;
     double thr0;
+    /* What a QP that does not converge does (round 4; shared with the HIP kernels, mpc_config.qp_fail_policy):
+     *   0  the divergence tests are on: mu > 1e8 mu0 ends the solve at once (status 4, iterate untouched), and a solve that reaches qp_iter_max
+     *      with mu > 1e4 mu0 -- or, from iteration 20 on, above mu0 -- is a failure (4), not a slow solve (2);
+     *   1  "truncate": no divergence test -- the interior point runs to qp_iter_max and its step is applied (status 2), as acados' SQP_RTI did with a
+     *      HPIPM solve that returned MAX_ITER (robot_ocp_problem.py:131, :203-205 only reacts to status 4); NaN / overflow / step collapse stay 4.
+     * The default is the one the reference's recorded tables select (profiles/r04_fail_policy_replay.json). */
+    int qp_fail_policy;
 } orc_config;
 
 void orc_default_config(orc_config *c, int N, int n_obst, double Tf);

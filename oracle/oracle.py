@@ -28,6 +28,7 @@ class OrcConfig(C.Structure):
         ("bx_terminal", C.c_int), ("soft_h", C.c_int),
         ("arena", _d * 4), ("bug_compat_predict", C.c_int),
         ("mu0", _d), ("thr0", _d),
+        ("qp_fail_policy", C.c_int),
     ]
 
 

@@ -47,22 +47,69 @@ def qp_merit(orc, cfg, x0, P, goal, X, U, Xn, Un):
     return float(f), eq, bnd
 
 
-def judge_against_oracle(orc, cfg, x0, P, goal, X0, U0, g, Xg, Ug, o, tol_x=1e-6, tol_u=8e-6, alpha=None):
+# ---- the adjudication of an instance beyond the parity tolerance ----
+# A converged instance whose GPU and oracle iterates differ by more than 1e-6 is settled against the EXACT solution of the QP both sides solved
+# (exact_qp: active-set iteration on the exported QP, KKT conditions verified -- it owes neither interior point anything):
+#   * the GPU's distance from the exact solution is at most EXACT_FACTOR times the oracle's (or 1e-6): both sides stop an interior point at the same
+#     complementarity tolerance, and what that leaves is a distance ~ qp_tol / (smallest multiplier) x conditioning that either side may hold the
+#     larger share of -- but not a different order of magnitude;
+#   * and it is below EXACT_CAP outright, whatever the oracle did.
+# Where the active-set iteration does not verify (cycling on a degenerate vertex: rare) the fallback is the QP objective with an ABSOLUTE slack --
+# max(1e-9 |f|, 1e-6), not the 1e-7 |f| of rounds 2-3, which at |f| ~ 1e7 accepted errors of order 1 -- plus the same hard cap on |GPU - oracle|.
+EXACT_FACTOR = 10.0
+EXACT_CAP = 1e-4
+
+
+def adjudicate(orc, cfg, x0, P, goal, X0, U0, Xg, Ug, Xo, Uo, factor=EXACT_FACTOR, cap=EXACT_CAP):
+    """One instance, one RTI step from (X0, U0): GPU step (Xg, Ug) and oracle step (Xo, Uo) against the exact solution of the exported QP.
+    Returns dict(kind 'exact' | 'merit', passed, d_gpu, d_oracle, ...); the caller asserts."""
+    N = cfg.N
+    q = orc.export_qp(cfg, x0, P, goal, X0, U0)
+    vg, vo = step_vector(N, X0, U0, Xg, Ug), step_vector(N, X0, U0, Xo, Uo)
+    vex, ok, info = exact_qp(q, vo)
+    if not ok:
+        vex, ok, info = exact_qp(q, vg)
+    d_go = float(np.abs(vg - vo).max())
+    if ok:
+        dg, do = float(np.abs(vg - vex).max()), float(np.abs(vo - vex).max())
+        return dict(kind="exact", passed=bool(dg <= max(factor * do, 1e-6) and dg <= cap), d_gpu=dg, d_oracle=do, d_gpu_oracle=d_go,
+                    active=info.get("active"), lam_min=info.get("lam_min"))
+    fg, eqg, bg = qp_merit(orc, cfg, x0, P, goal, X0, U0, Xg, Ug)
+    fo, _, _ = qp_merit(orc, cfg, x0, P, goal, X0, U0, Xo, Uo)
+    return dict(kind="merit", passed=bool(eqg <= 1e-7 and bg <= 1e-7 and fg <= fo + max(1e-9 * abs(fo), 1e-6) and d_go <= cap), d_gpu=None, d_oracle=None,
+                d_gpu_oracle=d_go, f_gpu=fg, f_oracle=fo, eq=eqg, box=bg, why=info.get("why"))
+
+
+def allowed_adjudications(cfg, B):
+    """How many instances of a batch may take the adjudication at all: the measured fraction beyond 1e-6 (profiles/r04_parity_sweep.json) with a margin --
+    0.1 % of a batch at N <= 31 with up to 5 obstacles (measured <= 0.03 %), 0.5 % with more obstacles or longer horizons, 3 % at C5's size
+    (N >= 40 with >= 8 obstacles: measured 0.7 % on first solves) -- and never fewer than 2 (small test batches)."""
+    if cfg.N >= 40 and cfg.n_obst >= 8:
+        frac = 0.03
+    elif cfg.N > 31 or cfg.n_obst > 5:
+        frac = 0.005
+    else:
+        frac = 0.001
+    return max(2, int(np.ceil(frac * B)))
+
+
+def judge_against_oracle(orc, cfg, x0, P, goal, X0, U0, g, Xg, Ug, o, tol_x=1e-6, tol_u=8e-6, alpha=None, max_adjudicated=None):
     """GPU result (g, Xg, Ug) against the oracle's (o) for one RTI step of a batch from the iterate (X0, U0), instance by instance -- no "at most k
     instances may differ" clauses.  Per instance:
       * the statuses are equal, or the difference is an at-the-cap borderline: both sides ran to the iteration cap or one short of it (one meets the
         tolerance at iteration cap where the other is a rounding error above it; or the at-the-cap rule separates 2 from 4);
       * status 4 leaves the iterate untouched;
-      * a converged instance (status 0 on both sides) is within the tolerance of the oracle -- or, where the QP is ill-conditioned at the float64 floor of an
-        interior point, it is judged by the QP itself (qp_merit): the GPU's step satisfies the linearised dynamics and the boxes to 1e-7 and its QP objective
-        does not exceed the oracle's;
+      * a converged instance (status 0 on both sides) is within the tolerance of the oracle -- or it is ADJUDICATED against the exact solution of the QP
+        (adjudicate(): GPU within EXACT_FACTOR of the oracle's distance from it and below EXACT_CAP), and the number of instances that need this is bounded
+        (allowed_adjudications(), or max_adjudicated);
       * the iteration counts are equal, or they differ by at most 2 AND the oracle's own record shows the end-game: where the earlier side stopped, the
         oracle's largest complementarity product was already below 1e-4 (the last, superlinear iterations: from there ONE step takes it to ~1e-10, and a
         rounding difference decides whether that step lands under the tolerance or just above it).
-    Returns the numbers of instances that took each escape, for the caller to bound or report."""
+    Returns the numbers of instances that took each escape and the worst distances seen."""
     B = x0.shape[0]
     cap, tol = cfg.qp_iter_max, cfg.qp_tol
-    n = dict(status_borderline=0, judged_by_qp=0, iter_borderline=0, converged=0)
+    n = dict(status_borderline=0, judged_by_qp=0, judged_exact=0, judged_merit=0, iter_borderline=0, converged=0, worst_d_gpu_exact=0.0, worst_d_oracle_exact=0.0,
+             worst_d_gpu_oracle=0.0)
     for b in range(B):
         sg, so, ig, io = int(g["status"][b]), int(o["status"][b]), int(g["iters"][b]), int(o["iters"][b])
         if sg != so:
@@ -75,13 +122,15 @@ def judge_against_oracle(orc, cfg, x0, P, goal, X0, U0, g, Xg, Ug, o, tol_x=1e-6
             continue
         n["converged"] += 1
         dx, du = np.abs(Xg[b] - o["X"][b]).max(), np.abs(Ug[b] - o["U"][b]).max()
+        n["worst_d_gpu_oracle"] = max(n["worst_d_gpu_oracle"], float(max(dx, du)))
         if dx > tol_x or du > tol_u:
-            al = None if alpha is None else alpha[b]
-            fg, eqg, bg = qp_merit(orc, cfg, x0[b], P[b], goal[b], X0[b], U0[b], Xg[b], Ug[b]) if al is None else (None, None, None)
-            assert al is None, f"instance {b}: |dX| {dx:.2e} beyond the tolerance with an explicit slack schedule (no QP export for it)"
-            fo, _, _ = qp_merit(orc, cfg, x0[b], P[b], goal[b], X0[b], U0[b], o["X"][b], o["U"][b])
-            assert eqg <= 1e-7 and bg <= 1e-7 and fg <= fo + 1e-7 * max(1.0, abs(fo)), f"instance {b}: |dX| {dx:.2e}, QP objective {fg} vs oracle {fo}, eq {eqg:.1e}, box {bg:.1e}"
+            assert alpha is None, f"instance {b}: |dX| {dx:.2e} beyond the tolerance with an explicit slack schedule (no QP export for it)"
+            a = adjudicate(orc, cfg, x0[b], P[b], goal[b], X0[b], U0[b], Xg[b], Ug[b], o["X"][b], o["U"][b])
+            assert a["passed"], f"instance {b}: |GPU - oracle| {max(dx, du):.2e}; adjudication {a}"
             n["judged_by_qp"] += 1
+            n["judged_exact" if a["kind"] == "exact" else "judged_merit"] += 1
+            if a["kind"] == "exact":
+                n["worst_d_gpu_exact"] = max(n["worst_d_gpu_exact"], a["d_gpu"]); n["worst_d_oracle_exact"] = max(n["worst_d_oracle_exact"], a["d_oracle"])
         else:
             assert abs(g["cost"][b] - o["cost"][b]) <= 1e-8 * max(1.0, abs(o["cost"][b])), (b, g["cost"][b], o["cost"][b])
             assert np.abs(g["u0"][b] - o["u0"][b]).max() <= tol_u
@@ -91,6 +140,8 @@ def judge_against_oracle(orc, cfg, x0, P, goal, X0, U0, g, Xg, Ug, o, tol_x=1e-6
             m = min(ig, io)
             assert m >= 1 and tr[min(m, len(tr) - 1), 3] <= max(1e4 * tol, 1e-4), f"instance {b}: iteration counts {ig} / {io} differ away from the end-game (oracle cmax {tr[min(m, len(tr) - 1), 3]:.2e} at iteration {m})"
             n["iter_borderline"] += 1
+    limit = allowed_adjudications(cfg, B) if max_adjudicated is None else max_adjudicated
+    assert n["judged_by_qp"] <= limit, f"{n['judged_by_qp']} of {B} instances beyond the tolerance (allowed {limit}): {n}"
     return n
 
 
@@ -199,6 +250,23 @@ class OraclePlant:
         return self.x.copy()
 
 
+def _kkt_solver(Ks):
+    """x = Ks^-1 r for the equilibrated KKT matrix: one LU factorisation (partial pivoting), or the minimum-norm least-squares solution when the active rows are
+    linearly dependent (LU pivot at rounding level)"""
+    import scipy.linalg as sla
+    try:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            lu = sla.lu_factor(Ks)
+        if np.abs(np.diag(lu[0])).min() > 1e-11 * np.abs(np.diag(lu[0])).max():
+            return lambda r: sla.lu_solve(lu, r)
+    except Exception:
+        pass
+    pinv = np.linalg.pinv(Ks, rcond=1e-15)
+    return lambda r: pinv @ r
+
+
 def exact_from_active_set(q, v0, tol=1e-7):
     """The solution of an exported QP (oracle.export_qp) that owes the interior point nothing but the GUESS of the active set: the active rows are read off the
     candidate v0 (bounds, soft rows h + C v + s >= 0, s >= 0 within `tol`), the equality-constrained QP on them is solved by one dense KKT system (equilibrated,
@@ -235,10 +303,11 @@ def exact_from_active_set(q, v0, tol=1e-7):
     dsc = 1.0 / np.sqrt(np.maximum(np.abs(K).max(axis=1), 1e-300))
     Ks = K * dsc[:, None] * dsc[None, :]
     Kl, bl = K.astype(np.longdouble), b.astype(np.longdouble)
-    sol = dsc * np.linalg.lstsq(Ks, dsc * b, rcond=1e-15)[0]
+    solve = _kkt_solver(Ks)
+    sol = dsc * solve(dsc * b)
     for _ in range(6):
         r = (bl - Kl @ sol.astype(np.longdouble)).astype(np.float64)
-        sol = sol + dsc * np.linalg.lstsq(Ks, dsc * r, rcond=1e-15)[0]
+        sol = sol + dsc * solve(dsc * r)
     x, lam = sol[:n], sol[n:]
     lam_in = lam[len(rows):]
     # verification of the KKT conditions on the full QP
@@ -246,3 +315,72 @@ def exact_from_active_set(q, v0, tol=1e-7):
     feas = min(np.min(v - q["lb"]), np.min(q["ub"] - v), np.min(q["hs"] + q["Cs"] @ v + s) if ns else 0.0, np.min(s) if ns else 0.0)
     res = float(np.abs((bl - Kl @ sol.astype(np.longdouble)).astype(np.float64)[:n]).max())      # stationarity residual of the refined solve
     return v, float(lam_in.min()) if len(lam_in) else 0.0, float(feas), len(ineq), res
+
+
+def exact_qp(q, v0, tol=1e-7, rounds=30, kkt_tol=1e-9):
+    """The exact solution of an exported QP by a primal-dual active-set iteration started from the active set of the candidate v0 (exact_from_active_set's guess):
+    solve the equality-constrained QP on the working set (one dense KKT solve, equilibrated, refined with the residual in extended precision), drop the rows whose
+    multiplier came back negative, add the rows the solution violates, repeat until nothing changes -- then multipliers >= 0, constraints >= 0 and stationarity
+    hold together: the unique minimiser of the strictly convex QP, owing the interior point nothing but the starting guess.  Hard obstacle rows (soft_h = 0:
+    exported with an infinite penalty) are plain inequality rows without a slack variable.
+    Returns (v, verified, info).  Test infrastructure."""
+    nv, nrows = q["H"].shape[0], len(q["hs"])
+    soft = np.nonzero(np.isfinite(q["zs"]))[0] if nrows else np.zeros(0, int)
+    hard = np.nonzero(~np.isfinite(q["zs"]))[0] if nrows else np.zeros(0, int)
+    ns = len(soft)
+    n = nv + ns
+    H = np.zeros((n, n)); H[:nv, :nv] = q["H"]; H[nv:, nv:] = np.diag(q["Zs"][soft])
+    g = np.concatenate([q["g"], q["zs"][soft]])
+    me = q["Aeq"].shape[0]
+    Eeq = np.zeros((me, n)); Eeq[:, :nv] = q["Aeq"]
+    # candidate inequality rows a x >= b: lower / upper bounds of v, soft rows h + C v + s >= 0 and s >= 0, hard rows h + C v >= 0
+    cand_a, cand_b = [], []
+    for v in range(nv):
+        if np.isfinite(q["lb"][v]):
+            a = np.zeros(n); a[v] = 1.0; cand_a.append(a); cand_b.append(q["lb"][v])
+        if np.isfinite(q["ub"][v]):
+            a = np.zeros(n); a[v] = -1.0; cand_a.append(a); cand_b.append(-q["ub"][v])
+    for k, j in enumerate(soft):
+        a = np.zeros(n); a[:nv] = q["Cs"][j]; a[nv + k] = 1.0; cand_a.append(a); cand_b.append(-q["hs"][j])
+        a = np.zeros(n); a[nv + k] = 1.0; cand_a.append(a); cand_b.append(0.0)
+    for j in hard:
+        a = np.zeros(n); a[:nv] = q["Cs"][j]; cand_a.append(a); cand_b.append(-q["hs"][j])
+    Ain, bin_ = np.array(cand_a).reshape(-1, n), np.array(cand_b)
+    rho = q["hs"][soft] + q["Cs"][soft] @ v0 if ns else np.zeros(0)
+    xx = np.concatenate([v0, np.maximum(0.0, -rho)])
+    act = (Ain @ xx - bin_) < tol
+    seen = set()
+    for rnd in range(rounds):
+        key = act.tobytes()
+        if key in seen:
+            return v0, False, dict(why="cycling", rounds=rnd)
+        seen.add(key)
+        E = np.vstack([Eeq, Ain[act]]); e = np.concatenate([q["beq"], bin_[act]])
+        m = E.shape[0]
+        K = np.block([[H, -E.T], [E, np.zeros((m, m))]])
+        b = np.concatenate([-g, e])
+        dsc = 1.0 / np.sqrt(np.maximum(np.abs(K).max(axis=1), 1e-300))
+        Ks = K * dsc[:, None] * dsc[None, :]
+        Kl, bl = K.astype(np.longdouble), b.astype(np.longdouble)
+        solve = _kkt_solver(Ks)
+        sol = dsc * solve(dsc * b)
+        for _ in range(6):
+            r = (bl - Kl @ sol.astype(np.longdouble)).astype(np.float64)
+            sol = sol + dsc * solve(dsc * r)
+        res = float(np.abs((bl - Kl @ sol.astype(np.longdouble)).astype(np.float64)).max())
+        x, lam = sol[:n], sol[n + me:]
+        val = Ain @ x - bin_
+        idx_act = np.nonzero(act)[0]
+        drop = idx_act[lam < -kkt_tol]
+        add = np.nonzero(~act & (val < -kkt_tol))[0]
+        if len(drop) == 0 and len(add) == 0:
+            return x[:nv], res <= 1e-8, dict(rounds=rnd + 1, active=int(act.sum()), residual=res, lam_min=float(lam.min()) if len(lam) else 0.0,
+                                              weakly_active=int((np.abs(lam) < 1e-6).sum()), nearly_active=int((~act & (val < 1e-6)).sum()))
+        act = act.copy(); act[drop] = False; act[add] = True
+    return v0, False, dict(why="rounds")
+
+
+def step_vector(N, X0, U0, X, U):
+    """the RTI step (X, U) - (X0, U0) in the variable order of orc_export_qp: (du_i, dx_{i+1}) per stage"""
+    dX, dU = X - X0, U - U0
+    return np.concatenate([np.concatenate([dU[i], dX[i + 1]]) for i in range(N)])
