@@ -18,7 +18,10 @@ Workloads (BASELINE.json configs):
   c5 (configs[4]): N = 50, 10 obstacles, one global batch of 32768, sharded the same way (4096 per GPU on 8 GPUs)
 Multi-GPU: one process per GPU; `--gpus N` without a torchrun environment starts the N ranks itself (torch.distributed.run, before
 anything touches the GPU) and relays rank 0's JSON line.  No data-path collective; the per-scenario costs of 50 consecutive control
-steps travel in one all-gather (mpc_gpu.sharding.gather_costs: RCCL over xGMI) on a side stream.
+steps travel in one all-gather on a side stream -- through the library's own C-ABI collective (--exchange capi, the default: rank 0's
+mpc_comm_unique_id is broadcast over the torch.distributed group that the launcher set up anyway, every rank calls mpc_comm_init, and each
+message is one mpc_allgather_cost_dev = RCCL ncclAllGather over xGMI, issued by libmpcgpu itself) or through torch.distributed
+(--exchange torch: mpc_gpu.sharding.gather_costs).
 """
 import argparse
 import json
@@ -36,7 +39,12 @@ for p in (ROOT, PKG):
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FP64_VALU_PEAK_TF = 78.6     # MI355X FP64 vector peak; the FP64 matrix peak is the same number
+FP64_VALU_PEAK_TF = 78.6     # MI355X FP64 vector peak.  MI355X_MICROARCH.md tabulates the FP32 vector peak only (157.3 TFLOP/s = 256 CUs x 4 SIMDs x 16 lanes
+                             # x 2 flop x 2 (packed) x 2.4 GHz); the FP64 row it lacks is AMD's public specification for the part, 78.6 TFLOP/s vector AND matrix
+                             # (= the same product without packing: one wave64 FP64 FMA occupies a SIMD for 4 cycles)
+SIMDS = 1024                 # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4              # nominal engine clock the cycle figures are converted with
+VALU_CYCLES_PER_INST = 4     # a wave64 VALU instruction holds its 16-lane SIMD for 4 cycles: the issue roof of one SIMD is 1 instruction per 4 cycles
 EPISODE = 100                # control steps per episode = per bench step
 GATHER_EVERY = 50            # control steps per cost all-gather message
 EVENT_EVERY = 7              # HIP events around every 7th launch (coprime with EPISODE: the samples visit every position of an episode)
@@ -67,9 +75,27 @@ def algorithmic_flops_per_solve(N, n_obst, k_iters):
     return N * 200.0 + k_iters * per_iter
 
 
-def measured_traffic(kernel_name, batch):
-    """HBM bytes per launch of the solve kernel from the newest committed rocprofv3 PMC summary for this kernel and batch
-    (profiles/*_pmc_summary.json, scripts/profile_passes.sh; a launch moves the same bytes whatever the iteration count); else None."""
+def lanes_useful(kernel_name, N, n_obst):
+    """Lanes of a wavefront that carry data, averaged over the VALU instructions of one interior-point iteration (see roofline.lanes_note).
+    Per iteration and wavefront: row phases R instructions on `stage_lanes` lanes, factor sweep F on 8 lanes per instance, vector sweeps V on 5 lanes per instance."""
+    k = kernel_name.replace(" ", "")
+    if k.startswith("rti_split_kernel<"):            # one instance per wavefront, LPS lanes per stage; per-stage counts from profiles/r01_split_phase_timing.txt
+        lps = int(k.split("<")[1].split(",")[1])
+        R, F, V, inst, stage_lanes = 830.0, 112.0 * N, 3 * 13.0 * N, 1, min(64, lps * (N + 1))
+    elif k.startswith("rti_solve_kernel<"):          # one lane per stage; G lanes per instance; profiles/r03_solve_*_phase_instruction_counts.txt
+        g = int(k.split("<")[1].split(",")[1])
+        inst = 3 if g == 21 else 64 // g
+        R = 2910.0 if n_obst <= 5 else 7000.0
+        F, V, stage_lanes = 125.0 * N, 3 * 15.0 * N, inst * (N + 1)
+    else:
+        return None
+    return (R * stage_lanes + F * 8 * inst + V * 5 * inst) / (R + F + V)
+
+
+def measured_pmc(kernel_name, batch):
+    """What the newest committed rocprofv3 PMC summary for this kernel and batch holds (profiles/*_pmc_summary.json, scripts/profile_passes.sh):
+    HBM bytes per launch (a launch moves the same bytes whatever the iteration count), VALU instructions per launch with the kernel duration of
+    that profile (-> the issue-slot fraction), and the mean number of active lanes per VALU instruction; else None."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
@@ -77,7 +103,10 @@ def measured_traffic(kernel_name, batch):
             d = json.load(open(f))
             if d["batch"] == batch and kernel_name.replace(" ", "") in d["kernel"].replace(" ", ""):
                 t = d["hbm_traffic_bytes_per_launch"]
-                best = (t["fetch_raw_kb"] * 1024 + t["write_bytes"], os.path.basename(f))
+                c = d["counters"]
+                best = dict(traffic=t["fetch_raw_kb"] * 1024 + t["write_bytes"], file=os.path.basename(f),
+                            valu_insts=c.get("SQ_INSTS_VALU", {}).get("mean_per_launch"), avg_ns=(d.get("kernel_stats") or {}).get("avg_ns"),
+                            lanes_active=(d.get("derived") or {}).get("valu_lanes_active"))
         except Exception:
             pass
     return best
@@ -173,6 +202,41 @@ class CostExchange:
         return self.out.view(self.world, GATHER_EVERY, -1)
 
 
+class CApiCostExchange(CostExchange):
+    """The same double-buffered exchange through the library's own collective (include/mpc_gpu.h: mpc_comm_init, mpc_allgather_cost_dev = RCCL's
+    ncclAllGather issued by libmpcgpu on the side stream) -- the path a host without torch.distributed takes."""
+
+    def __init__(self, torch, world, batch, dev, solver):
+        super().__init__(torch, world, batch, dev, None)
+        self.m = solver
+        self.done = torch.cuda.Event()
+        self.pending = False
+
+    def stepped(self):
+        buf = (self.n // GATHER_EVERY) % 2
+        self.n += 1
+        if self.n % GATHER_EVERY:
+            return
+        self.wait()
+        self.side.wait_stream(self.torch.cuda.current_stream())
+        self.m.allgather_cost_dev(GATHER_EVERY * self.hist.shape[2], self.hist[buf], self.out, stream=self.side.cuda_stream)
+        self.done.record(self.side)
+        self.pending = True
+
+    def wait(self):
+        if self.pending:
+            self.done.synchronize()
+            self.pending = False
+
+
+def exchange_comm_id(dist, rank, make_id):
+    """Rank 0 draws the communicator's unique id (mpc_comm_unique_id: 128 bytes) and every rank receives it over the process group the launcher
+    has initialised anyway -- the only thing torch.distributed does for the C-ABI exchange."""
+    box = [bytes(make_id()) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
 # ------------------------------------------------------------------------------------------------------------------ CPU baseline
 
 class _OracleAsAcados:
@@ -221,6 +285,24 @@ class _OraclePlant:
         return self.x.copy()
 
 
+def cpu_budget():
+    """(hardware threads this process may run on, CPU quota of its cgroup in cores or None).  A GPU box of this pool shows 256 hardware threads but gives a
+    one-GPU lease a quota of about 16 cores: OpenMP threads beyond the quota only time-slice (round 3's "15x on 128 cores" was this quota, not the allocator)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else int(t.split()[0]) / int(t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: None if int(t) <= 0 else int(t) / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))):
+        try:
+            quota = parse(open(path).read().strip())
+            break
+        except (OSError, ValueError, IndexError, ZeroDivisionError):
+            continue
+    return n, quota
+
+
 def cpu_baseline(N, n_obst, x0, goal, obst, budget_s=24.0):
     """The oracle (CPU restatement of the same RTI step; acados itself cannot run on this box) timed on this box's host cores on a
     bounded sample of the same workload: closed-loop control steps of the first S scenarios (a few untimed, then timed until the budget
@@ -230,7 +312,8 @@ def cpu_baseline(N, n_obst, x0, goal, obst, budget_s=24.0):
     from oracle import oracle as orc
     orc.use_bench_build()
     cfg = orc.config(N, n_obst, 0.1 * N)      # the library's defaults (qp_tol 1e-10)
-    ncpu = os.cpu_count() or 1
+    ncpu, quota = cpu_budget()
+    cores_avail = max(1, min(ncpu, int(np.ceil(quota)))) if quota else ncpu      # threads that can actually run at once
     dt = 0.1
 
     def closed_loop_rate(S, nthreads, budget, warm=5):
@@ -258,8 +341,9 @@ def cpu_baseline(N, n_obst, x0, goal, obst, budget_s=24.0):
 
     S_all = min(len(x0), max(64, 8 * ncpu))
     rates = {}
-    for n in sorted({ncpu, max(1, ncpu // 2)}, reverse=True):
-        rates[n] = closed_loop_rate(S_all, n, budget_s / 4)
+    # as many OpenMP threads as cores are available to this process (the cgroup quota when there is one), and twice / half that for the neighbourhood
+    for n in sorted({cores_avail, min(ncpu, 2 * cores_avail), max(1, cores_avail // 2)}, reverse=True):
+        rates[n] = closed_loop_rate(S_all, n, budget_s / 6)
     best = max(rates, key=lambda n: rates[n][0])
     one, one_steps = closed_loop_rate(min(len(x0), 16), 1, budget_s / 4)
     # reference call pattern: ONE scenario, the reference's per-step solver calls (ShimLoop) on oracle-backed objects, wall time of
@@ -275,15 +359,18 @@ def cpu_baseline(N, n_obst, x0, goal, obst, budget_s=24.0):
         loop.control_step(st); loop.shift_warm_start(); n_py += 1
     py_rate = n_py / (time.perf_counter() - t0)
     return {"value": rates[best][0], "unit": "solves/s", "cores": best, "kind": "port", "host_cpu": orc._cpu_model(), "host_threads": ncpu,
-            "one_thread": one, "python_call_pattern_one_thread": py_rate,
+            "cpu_quota_cores": quota, "cores_available": cores_avail,
+            "one_thread": one, "per_core": rates[best][0] / best, "scaling_efficiency": rates[best][0] / (best * one),
+            "python_call_pattern_one_thread": py_rate,
             "threads": {str(n): r[0] for n, r in rates.items()},
             "sample": f"first {S_all} scenarios x {rates[best][1]} closed-loop control steps (after 5 untimed) of the same workload, oracle "
                       f"(C, f64, -O3 -march=native, OpenMP over instances), solve calls only; one_thread: 16 scenarios x {one_steps} steps; "
                       f"python_call_pattern: 1 scenario x {n_py} control steps through the reference's ~{8 * N + 12} solver calls per step "
                       "(whole loop timed); acados itself cannot run here, so this is a restatement, not the reference's solver",
-            "note": "a reported baseline, not a target: the oracle is a dense, generic checker (malloc per solve, no structure exploitation); "
-                    "with SMT siblings as extra OpenMP threads its rate falls (shared FP pipes and allocator contention), hence `cores` is the "
-                    "faster of all / half the hardware threads"}
+            "note": "a reported baseline, not a target: the oracle is a dense, generic checker (no structure exploitation; per-thread workspace since round 4). "
+                    "`cores` = the OpenMP thread count of `value`, chosen around the number of cores this process may actually use (cpu_quota_cores: the cgroup "
+                    "quota of the lease, ~16 on a one-GPU box with 256 hardware threads; threads beyond it only time-slice); scaling_efficiency = value / "
+                    "(cores x one_thread)"}
 
 
 # ------------------------------------------------------------------------------------------------------------------ measurement
@@ -347,12 +434,29 @@ def roofline(loop, N, no, r):
     wall_per_launch = r["elapsed"] / (r["steps"] * EPISODE)
     flops = algorithmic_flops_per_solve(N, no, r["mean_iters"]) * batch
     abytes = algorithmic_bytes_per_solve(N, no) * batch
-    tr = measured_traffic(kname, batch)
+    pm = measured_pmc(kname, batch)
+    issue = None
+    if pm and pm["valu_insts"] and pm["avg_ns"]:
+        # the roof that binds: VALU issue slots.  SQ_INSTS_VALU x 4 cycles / (SIMDs x kernel cycles), instructions and duration from the SAME profile
+        issue = pm["valu_insts"] * VALU_CYCLES_PER_INST / (SIMDS * pm["avg_ns"] * CLOCK_GHZ)
     return {"bound": "fp64_valu", "achieved": flops / avg_s / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
             "frac": flops / avg_s / 1e12 / FP64_VALU_PEAK_TF,
-            "traffic": tr[0] if tr else None,
-            "traffic_source": (f"HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE passes of this command, profiles/{tr[1]} "
-                               "(FETCH_SIZE uncorrected: 8-byte-per-lane loads)") if tr else None,
+            "peak_source": "AMD public specification of MI355X (FP64 vector = FP64 matrix = 78.6 TFLOP/s); MI355X_MICROARCH.md lists the FP32 vector peak (157.3) only",
+            "issue": issue,
+            "issue_note": ("fraction of the chip's VALU issue slots this kernel uses: SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz), both from "
+                           f"profiles/{pm['file']} -- the resource that binds (one or two wavefronts per SIMD, dependent FP64 chains), next to which `frac` is small "
+                           "because few lanes of an instruction carry data") if issue is not None else None,
+            "lanes_active": lanes_useful(kname, N, no),
+            "lanes_exec": pm["lanes_active"] if pm else None,
+            "lanes_note": ("lanes_active: lanes (of 64) that carry DATA per VALU instruction, a static model -- per interior-point iteration the row phases run on "
+                           "every stage lane of the wavefront's instances, the Riccati factor sweep on 8 and the three vector sweeps on 5 lanes of a 16-lane DPP row "
+                           "per instance, weighted with the phases' VALU instruction counts (profiles/r03_*_phase_instruction_counts.txt, r01_split_phase_timing.txt); "
+                           "lanes_exec: lanes ENABLED per VALU instruction, SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU of the same profile as `issue` (the ratio reads "
+                           "exactly K on a kernel with K lanes enabled: profiles/r04_lanes_counter_calibration.json) -- the sweeps keep EXEC full on purpose "
+                           "(unconditional arithmetic, dead stores: no EXEC manipulation in the loops), so it bounds lanes_active from above"),
+            "traffic": pm["traffic"] if pm else None,
+            "traffic_source": (f"HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE passes of this command, profiles/{pm['file']} "
+                               "(FETCH_SIZE uncorrected: 8-byte-per-lane loads)") if pm else None,
             "kernel": kname, "avg_launch_us": avg_s * 1e6, "avg_launch_us_raw": raw_s * 1e6, "event_pair_overhead_us": r["pair_ms"] * 1e3,
             "kernel_time_over_wall": avg_s / wall_per_launch, "launches_timed": r["launches"],
             "launch_timing": (f"HIP events on the launch stream around every {EVENT_EVERY}th launch of the timed region, minus the duration an empty event pair "
@@ -420,7 +524,23 @@ def dry_run(args, world, rank):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cpu")
     ok = True
+    comm_id_sha1 = None
     if world > 1:
+        # the id plumbing of --exchange capi: rank 0's unique id reaches every rank (without a GPU mpc_comm_unique_id refuses, as everything in the
+        # library does; the rehearsal then ships 128 random bytes through the same function)
+        import hashlib
+        from mpc_gpu import BatchedMpc, MpcError
+
+        def make_id():
+            try:
+                return BatchedMpc.comm_unique_id()
+            except (MpcError, OSError):
+                return os.urandom(128)
+        uid = exchange_comm_id(dist, rank, make_id)
+        digests = [None] * world
+        dist.all_gather_object(digests, hashlib.sha1(uid).hexdigest())
+        ok = ok and len(uid) == 128 and all(d == digests[0] for d in digests)
+        comm_id_sha1 = digests[0]
         exch = CostExchange(torch, world, hi - lo, dev, gather_costs)
         idx = torch.arange(lo, hi, dtype=torch.float64)
         for k in range(2 * GATHER_EVERY):
@@ -434,7 +554,7 @@ def dry_run(args, world, rank):
         flag = torch.tensor([1.0 if ok else 0.0]); dist.all_reduce(flag, op=dist.ReduceOp.MIN); ok = bool(flag.item() == 1.0)
     if rank == 0:
         print(json.dumps({"metric": "MPC solves/sec (N=20, 3 obstacles)", "value": 0.0, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "dry_run": True, "scaling": scaling, "gather_check": ok,
+                          "warmup": args.warmup, "dry_run": True, "scaling": scaling, "gather_check": ok, "exchange": args.exchange, "comm_id_sha1": comm_id_sha1,
                           "config": {"workload": desc, "global_batch": G, "rank0_slice": [lo, hi], "x0_shape": list(x0.shape)}}))
     if world > 1:
         dist.destroy_process_group()
@@ -448,6 +568,12 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default: c2 on one GPU (BASELINE configs[1], the configuration the metric is quoted on); with --gpus N > 1 the sharded "
                          "global batch c4 (configs[3]: 262144 scenarios over the ranks)")
+    ap.add_argument("--exchange", default="capi", choices=["capi", "torch"],
+                    help="multi-rank cost all-gather: capi = the library's own C-ABI collective (mpc_comm_init + mpc_allgather_cost_dev, RCCL called by "
+                         "libmpcgpu; default), torch = torch.distributed.all_gather_into_tensor")
+    ap.add_argument("--share", type=int, default=0,
+                    help="single-GPU run of ONE rank's share of a K-way sharded workload (rank 0's slice of shard_slice(total, r, K)): the per-GPU work of "
+                         "`--gpus K` without the other K - 1 GPUs (profiles/r04_c5_share_*: --workload c5 --share 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the supplementary C3, C5 and C1 measurements")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the multi-rank plumbing (gloo), no kernels")
@@ -494,9 +620,27 @@ def main():
 
     N, no, _, _, scaling = WORKLOADS[args.workload]
     x0, goal, obst, desc, (lo, hi), G = make_workload(args.workload, world, rank, shard_slice)
+    if args.share > 1 and world == 1:
+        x0, goal, obst, desc, (lo, hi), _ = make_workload(args.workload, args.share, 0, shard_slice)
+        G = hi - lo
+        desc += f" -- rank 0's slice of {args.share} ({G} instances) on this one GPU"
     loop = Loop(mpc_gpu, torch, N, no, x0, goal, obst, dev)
-    exch = CostExchange(torch, world, hi - lo, dev, gather_costs) if world > 1 and (hi - lo) * world == G else None
+    exch, exchange = None, None
+    if world > 1 and (hi - lo) * world == G:
+        exchange = args.exchange
+        if exchange == "capi" and os.environ.get("MPC_BENCH_ONE_GPU") == "1":
+            exchange = "torch"                    # RCCL refuses two ranks on one device: the one-GPU rehearsal keeps the gloo transport
+        if exchange == "capi":
+            uid = exchange_comm_id(dist, rank, mpc_gpu.BatchedMpc.comm_unique_id)
+            loop.m.comm_init(rank, world, uid)
+            exch = CApiCostExchange(torch, world, hi - lo, dev, loop.m)
+        else:
+            exch = CostExchange(torch, world, hi - lo, dev, gather_costs)
     r = measure(torch, dist, loop, world, exch, args.steps, args.warmup, dev)
+    gather_ok = None
+    if exch is not None:         # the last completed message: every rank's row of the final control step must be that rank's own costs (rank 0 checks its own)
+        got = exch.gathered()
+        gather_ok = bool(torch.equal(got[rank], exch.hist[((exch.n - 1) // GATHER_EVERY) % 2]))
 
     value = G * EPISODE * args.steps / r["elapsed"]
     out = {"metric": "MPC solves/sec (N=20, 3 obstacles)" if N == 20 and no == 3 else f"MPC solves/sec (N={N}, {no} obstacles)",
@@ -512,6 +656,7 @@ def main():
                                        if args.workload == "c2" else None,
                       "parallelism": (f"batch slices over {world} ranks (mpc_gpu.sharding.shard_slice), no data-path collective; per-scenario costs "
                                       f"all-gathered over RCCL, {GATHER_EVERY} control steps per message") if world > 1 else "single GPU"},
+           "exchange": exchange, "rccl_ranks": loop.m.comm_world() if exchange == "capi" else None, "gather_check": gather_ok,
            "ms_per_control_step": r["elapsed"] / (args.steps * EPISODE) * 1e3,
            "mean_ipm_iters": r["mean_iters"], "qp_failure_frac": r["fail"], "qp_iter_cap_frac": r["cap"],
            "lanes_per_instance": loop.m.lanes_per_instance(loop.B), "lanes_per_stage": loop.m.lanes_per_stage(loop.B),
@@ -538,6 +683,19 @@ def main():
                            "ms_per_step": r5["elapsed"] / 2 * 1e3, "ms_per_control_step": r5["elapsed"] / (2 * EPISODE) * 1e3,
                            "mean_ipm_iters": r5["mean_iters"], "qp_failure_frac": r5["fail"], "roofline": roofline(l5, N5, no5, r5)}
         del l5
+        # ... and the PER-GPU SHARES of the two 8-GPU configurations on this one GPU: what one rank of `--gpus 8 --workload c4 / c5` solves
+        # (32768 resp. 4096 instances) -- the strong-scaling predictor: 8 x these against `extra` / `extra_c5` is the efficiency to expect
+        for key, wl, share in (("extra_c4_share", "c4", 32768), ("extra_c5_share", "c5", 4096)):
+            Ns, nos = WORKLOADS[wl][:2]
+            xs, gs, os_, ds, _, _ = make_workload(wl, 8, 0, shard_slice)
+            assert len(xs) == share
+            ls = Loop(mpc_gpu, torch, Ns, nos, xs, gs, os_, dev)
+            rs = measure(torch, None, ls, 1, None, 3, 1, dev)
+            out[key] = {"workload": ds + f" -- rank 0's slice of 8 ({share} instances) on this one GPU", "value": share * EPISODE * 3 / rs["elapsed"], "unit": "solves/s",
+                        "steps": 3, "warmup": 1, "ms_per_control_step": rs["elapsed"] / (3 * EPISODE) * 1e3, "mean_ipm_iters": rs["mean_iters"],
+                        "qp_failure_frac": rs["fail"], "roofline": roofline(ls, Ns, nos, rs),
+                        "predicted_8gpu_value": 8 * share * EPISODE * 3 / rs["elapsed"]}
+            del ls
         # ... and C2 at the tolerance rounds 1-2 ran (1e-8), for continuity with their lines: same kernel, 3-5 % fewer iterations
         l8 = Loop(mpc_gpu, torch, N, no, x0, goal, obst, dev, qp_tol=1e-8)
         r8 = measure(torch, None, l8, 1, None, 5, 1, dev)

@@ -7,11 +7,22 @@
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>      // types and enums only: the functions are resolved from librccl.so.1 on first use (no link-time dependency)
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+
+// RCCL's ABI for the five entry points of the cost exchange, declared here: they are resolved from librccl.so.1 with dlopen on first use, so the
+// library has neither a link-time nor a build-time dependency on RCCL (a ROCm install without the RCCL development headers still builds the solver;
+// mpc_comm_* then fails loudly at run time if the shared object is absent too).  Values as in rccl/rccl.h (= NCCL's): ncclSuccess 0, ncclFloat64 8,
+// a 128-byte unique id (tests/test_abi.py compares them with the installed header when there is one).
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[MPC_COMM_ID_BYTES]; } ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+static constexpr ncclResult_t ncclSuccess = 0;
+static constexpr ncclDataType_t ncclDouble = 8;
 
 namespace {
 
@@ -820,21 +831,26 @@ struct Rccl {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
+std::once_flag g_rccl_once;
+char g_rccl_err[256] = "";
 
 int rccl_load()
 {
-    if (g_rccl.lib) return MPC_OK;
-    void *lib = nullptr;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
-    if (!lib) return fail(MPC_ERR_HIP, "librccl.so.1 not found (%s): the cost exchange has no other transport", dlerror());
-    Rccl r; r.lib = lib;
-    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
-    r.CommInitRank = (decltype(r.CommInitRank))dlsym(lib, "ncclCommInitRank");
-    r.AllGather = (decltype(r.AllGather))dlsym(lib, "ncclAllGather");
-    r.CommDestroy = (decltype(r.CommDestroy))dlsym(lib, "ncclCommDestroy");
-    r.GetErrorString = (decltype(r.GetErrorString))dlsym(lib, "ncclGetErrorString");
-    if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString) { dlclose(lib); return fail(MPC_ERR_HIP, "librccl lacks an entry point of the cost exchange"); }
-    g_rccl = r;
+    // handles on different threads may reach this together: one of them loads, the others wait (g_rccl is written once, before any reader returns)
+    std::call_once(g_rccl_once, [] {
+        void *lib = nullptr;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+        if (!lib) { const char *e = dlerror(); snprintf(g_rccl_err, sizeof(g_rccl_err), "librccl.so.1 not found (%s): the cost exchange has no other transport", e ? e : "?"); return; }
+        Rccl r; r.lib = lib;
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(lib, "ncclCommInitRank");
+        r.AllGather = (decltype(r.AllGather))dlsym(lib, "ncclAllGather");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(lib, "ncclCommDestroy");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString) { dlclose(lib); snprintf(g_rccl_err, sizeof(g_rccl_err), "librccl lacks an entry point of the cost exchange"); return; }
+        g_rccl = r;
+    });
+    if (!g_rccl.lib) return fail(MPC_ERR_HIP, "%s", g_rccl_err);
     return MPC_OK;
 }
 #define RCCLCHK(expr)                                                                                   \
@@ -878,13 +894,12 @@ int mpc_comm_destroy(mpc_handle *h)
     if (!h) return fail(MPC_ERR_ARG, "null handle");
     if (!h->comm) return MPC_OK;
     (void)hipSetDevice(h->device);
-    ncclComm_t c = h->comm;
-    h->comm = nullptr; h->comm_world = 0; h->comm_rank = 0;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    RCCLCHK(g_rccl.CommDestroy(h->comm));       // on failure the handle keeps the communicator: the caller may retry, nothing leaks silently
+    h->comm = nullptr; h->comm_world = 0; h->comm_rank = 0;
     if (h->d_gather_in) { (void)hipFree(h->d_gather_in); h->d_gather_in = nullptr; }          // sized for this communicator's world
     if (h->d_gather_out) { (void)hipFree(h->d_gather_out); h->d_gather_out = nullptr; }
     h->gather_cap = 0;
-    RCCLCHK(g_rccl.CommDestroy(c));
     return MPC_OK;
 }
 

@@ -749,7 +749,12 @@ struct Blk2Lds {
     static constexpr int RS = RowLds::HS;            // result blocks: the layout and stride of the dense stage blocks, so that the vector sweeps are the same code
     static constexpr int KROW = 8;                   // K^[u][j] at [u * 8 + j] (u < 4, j < 6: gains and feed-forward), L D L' factors at [FAC .. FAC + 9]
     static constexpr int FAC = 32;                   // 1/d0 1/d1 1/d2 1/d3 l10 l20 l30 l21 l31 l32
-    static constexpr int DEAD = 48;                  // dead-store word of idle lanes (beyond everything the vector sweeps use: RowVec 0..44)
+    // dead stores of idle lanes, inside the lane's OWN result block and apart from everything the sweep's workers store (as RowLds::DEADK / DEADF):
+    // the four K^ values go to column 6 of the K^ rows (words 6, 14, 22, 30: workers fill columns 0..5, nothing reads column 6 during the factor
+    // sweep), the ten factors to words 42..51 (behind FAC; the corrector's hand-off words kKK / kGX of rti_split_kernel.hpp are written after the sweep)
+    static constexpr int DEADK = 6, DEADF = 42;
+    static_assert(DEADK >= 6 && DEADK < KROW && DEADK + 3 * KROW < FAC, "dead K^ stores stay in the unused columns of the K^ rows");
+    static_assert(DEADF >= FAC + 10 && DEADF + 10 <= RowLds::HS, "dead factor stores stay behind the factors and inside the block");
     static __host__ __device__ constexpr int blocks(int N) { return N / 2; }
     static __host__ __device__ constexpr int pad_front() { return HS; }                                  // the factor sweep requests one block ahead of block 0
     static __host__ __device__ constexpr int pad_rear() { return RowLds::AHEAD * RS; }                   // the vector sweeps request three blocks ahead
@@ -766,7 +771,7 @@ __device__ __forceinline__ void rowpar_factor2(int lane, int M, const Blk2Lds L,
     const int l15 = lane & 15, j = l15 < 10 ? l15 : 9;      // column; lanes 10..15 of a row shadow column 9 and store nothing
     const bool storeK = worker_row && l15 < 6, store0 = worker_row && l15 == 0;
     const double d5 = (j == 5) ? 1.0 : 0.0;
-    double *kp = L.R + (storeK ? j : Blk2Lds::DEAD), *fp = L.R + (store0 ? Blk2Lds::FAC : Blk2Lds::DEAD);
+    double *kp = L.R + (storeK ? j : Blk2Lds::DEADK), *fp = L.R + (store0 ? Blk2Lds::FAC : Blk2Lds::DEADF);
     const double *wp = L.W + j, *hp = L.H + 10 * j;
     auto fetch = [&](int m, double Wc[5], double Hc[10]) {
 #pragma unroll

@@ -41,9 +41,16 @@ def run_episodes(x0, goal, obst, N=20, Tf=2.0, max_iter=400, random_move=True, i
     import torch
     x0 = np.ascontiguousarray(x0, dtype=np.float64); B = x0.shape[0]
     scenario_name = obst if isinstance(obst, str) else None
+    if interpolate_init and bug_compat_alias:
+        import warnings
+        warnings.warn("interpolate_init with bug_compat_alias=True: the straight-line guess is built from a plant state whose v, omega the aliasing defect has "
+                      "zeroed; the two recorded `interpolate_init` tables replay with bug_compat_alias=False (tests/test_gpu_replay.py)", stacklevel=2)
     if scenario_name is not None:
         if noise is None and random_move:
             noise = "reference"
+            if seed != 0:
+                raise ValueError("`seed` selects torch's generator, which a scenario name does not use: the obstacle noise is the reference's own numpy stream "
+                                 "per instance (first_seed + s).  Vary first_seed, or pass noise='torch' to draw from torch's generator with this seed")
         with BatchedMpc(N, n_obst, Tf, max_batch=B, device=device) as g:
             obst = g.generate_scenarios(obst, B, seed0=first_seed)
     obst = np.ascontiguousarray(obst, dtype=np.float64); n_obst = obst.shape[1]

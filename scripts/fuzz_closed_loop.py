@@ -9,12 +9,12 @@ import numpy as np
 import mpc_gpu
 from mpc_gpu import _lib
 from oracle import oracle as orc
-from helpers import OracleLoop, qp_merit, random_batch
+from helpers import OracleLoop, adjudicate, random_batch
 from test_gpu_closed_loop import GpuLoop
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
-t0 = time.time(); log = []; fails = []
+t0 = time.time(); log = []; fails = []; adjudicated = []
 while time.time() - t0 < budget:
     N = int(rng.choice([3, 9, 10, 15, 20, 21, 31, 40, 50])); no = int(rng.integers(1, 11)); B = int(rng.choice([1, 3, 8, 21, 40]))
     if N > 31: B = min(B, 12)
@@ -51,9 +51,9 @@ while time.time() - t0 < budget:
                     if d > 1e-6:
                         Xn = np.vstack([before["x0"][b][None], after["X"][b][:N]]); Un = np.vstack([after["u0"][b][None], after["U"][b][:N - 1]])
                         P = orc.predict_params(cfg, before["obst"][b])
-                        fg, eqg, bg = qp_merit(orc, cfg, before["x0"][b], P, goal[b], before["X"][b], before["U"][b], Xn, Un)
-                        fo, _, _ = qp_merit(orc, cfg, before["x0"][b], P, goal[b], before["X"][b], before["U"][b], r["X"], r["U"])
-                        if not (eqg <= 1e-7 and bg <= 1e-7 and fg <= fo + 1e-7 * max(1.0, abs(fo))): why = f"iterate d={d:.2e} f_gpu={fg} f_oracle={fo}"
+                        a = adjudicate(orc, cfg, before["x0"][b], P, goal[b], before["X"][b], before["U"][b], Xn, Un, r["X"], r["U"])      # against the exact QP solution
+                        adjudicated.append(dict(N=N, n_obst=no, kernel=rec["kernel"], **a))
+                        if not a["passed"]: why = f"iterate d={d:.2e} adjudication {a}"
                     else:
                         worst = max(worst, d)
                         if abs(after["margin"][b] - L.min_margin) > 1e-6: why = "margin"
@@ -66,7 +66,10 @@ while time.time() - t0 < budget:
     if len(log) % 100 == 0: print(f"{len(log)} configurations, {len(fails)} findings, {time.time() - t0:.0f} s", flush=True)      # (a silent GPU job is taken for hung)
 mpc_gpu.BatchedMpc.default_lanes_per_stage = 0
 kernels = sorted({r.get("kernel", "?") for r in log})
-out = dict(configurations=len(log), distinct_kernels=len(kernels), kernels=kernels, failures=fails, worst=max((r.get("worst", 0.0) for r in log), default=0.0))
-print(json.dumps({k: out[k] for k in ("configurations", "distinct_kernels", "failures", "worst")}, indent=1)[:5000])
+ex = [a for a in adjudicated if a["kind"] == "exact"]
+out = dict(configurations=len(log), distinct_kernels=len(kernels), kernels=kernels, failures=fails, worst=max((r.get("worst", 0.0) for r in log), default=0.0),
+           adjudicated=len(adjudicated), adjudicated_exact=len(ex), worst_d_gpu_exact=max((a["d_gpu"] for a in ex), default=0.0), worst_d_oracle_exact=max((a["d_oracle"] for a in ex), default=0.0),
+           worst_d_gpu_oracle_adjudicated=max((a["d_gpu_oracle"] for a in adjudicated), default=0.0), adjudications=sorted(adjudicated, key=lambda a: -a["d_gpu_oracle"])[:40])
+print(json.dumps({k: out[k] for k in ("configurations", "distinct_kernels", "failures", "worst", "adjudicated", "adjudicated_exact", "worst_d_gpu_exact", "worst_d_oracle_exact", "worst_d_gpu_oracle_adjudicated")}, indent=1)[:5000])
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "fuzz_closed_loop.json"), "w"), indent=1)
 sys.exit(1 if fails else 0)

@@ -8,12 +8,12 @@ import numpy as np
 import mpc_gpu
 from mpc_gpu import _lib
 from oracle import oracle as orc
-from helpers import oracle_P, oracle_guess, qp_merit, random_batch
+from helpers import adjudicate, oracle_P, oracle_guess, random_batch
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
 BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
-t0 = time.time(); log = []; fails = []
+t0 = time.time(); log = []; fails = []; adjudicated = []
 while time.time() - t0 < budget:
     N = int(rng.choice([2, 3, 5, 9, 10, 14, 15, 17, 19, 20, 21, 25, 30, 31, 32, 40, 47, 50, 62]))
     no = int(rng.integers(1, 11))
@@ -62,10 +62,10 @@ while time.time() - t0 < budget:
                     if use_alpha:          # (qp_merit assembles the QP with the built-in schedule: a plain bound instead)
                         if d[b] > 1e-4: fails.append(dict(rec, step=k, why="iterate (explicit slack schedule)", inst=int(b), d=float(d[b])))
                         continue
-                    fg, eqg, bg = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xo[b], Uo[b], X[b], U[b])
-                    fo, _, _ = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xo[b], Uo[b], o["X"][b], o["U"][b])
-                    if not (eqg <= 1e-7 and bg <= 1e-7 and fg <= fo + 1e-7 * max(1.0, abs(fo))):
-                        fails.append(dict(rec, step=k, why="qp", inst=int(b), d=float(d[b]), f_gpu=fg, f_oracle=fo))
+                    a = adjudicate(orc, cfg, x0[b], P[b], goal[b], Xo[b], Uo[b], X[b], U[b], o["X"][b], o["U"][b])      # against the exact QP solution
+                    adjudicated.append(dict(N=N, n_obst=no, B=B, soft_h=soft, kernel=rec["kernel"], **a))
+                    if not a["passed"]:
+                        fails.append(dict(rec, step=k, why="adjudication", inst=int(b), d=float(d[b]), verdict=a))
                 if ok.any(): worst = max(worst, float(d[ok].max()))
                 Xo, Uo = o["X"].copy(), o["U"].copy()
                 for b in range(B): Xo[b], Uo[b] = orc.shift(cfg, Xo[b], Uo[b])
@@ -76,7 +76,13 @@ while time.time() - t0 < budget:
     log.append(rec)
     if len(log) % (5 if BIG else 100) == 0: print(f"{len(log)} configurations, {len(fails)} findings, {time.time() - t0:.0f} s", flush=True)      # (a silent GPU job is taken for hung)
 kernels = sorted({r.get("kernel", "?") for r in log})
-out = dict(configurations=len(log), distinct_kernels=len(kernels), kernels=kernels, failures=fails, worst_dX=max((r.get("worst_dX", 0.0) for r in log), default=0.0), seconds=time.time() - t0)
-print(json.dumps({k: out[k] for k in ("configurations", "distinct_kernels", "failures", "worst_dX")}, indent=1)[:6000])
+ex = [a for a in adjudicated if a["kind"] == "exact"]
+worst_cfg = max(log, key=lambda r: r.get("worst_dX", 0.0)) if log else None
+out = dict(configurations=len(log), distinct_kernels=len(kernels), kernels=kernels, failures=fails, worst_dX=max((r.get("worst_dX", 0.0) for r in log), default=0.0), worst_dX_configuration=worst_cfg,
+           adjudicated=len(adjudicated), adjudicated_exact=len(ex), adjudicated_by_merit=len(adjudicated) - len(ex), solves_compared=int(sum(2 * r["B"] for r in log)),
+           worst_d_gpu_exact=max((a["d_gpu"] for a in ex), default=0.0), worst_d_oracle_exact=max((a["d_oracle"] for a in ex), default=0.0),
+           gpu_farther_than_oracle=int(sum(a["d_gpu"] > a["d_oracle"] for a in ex)), adjudications=sorted(adjudicated, key=lambda a: -a["d_gpu_oracle"])[:60], seconds=time.time() - t0)
+print(json.dumps({k: out[k] for k in ("configurations", "distinct_kernels", "failures", "worst_dX", "worst_dX_configuration", "adjudicated", "adjudicated_exact", "adjudicated_by_merit", "solves_compared",
+                                      "worst_d_gpu_exact", "worst_d_oracle_exact", "gpu_farther_than_oracle")}, indent=1)[:6000])
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "fuzz_parity.json"), "w"), indent=1)
 sys.exit(1 if fails else 0)

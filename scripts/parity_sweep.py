@@ -58,7 +58,8 @@ for N, no, B, lps, waves, lanes in CONFIGS:
                        gpu_farther_than_oracle=int(sum(a["d_gpu"] > a["d_oracle"] for a in ex)),
                        worst_d_gpu_exact=max((a["d_gpu"] for a in ex), default=0.0), worst_d_oracle_exact=max((a["d_oracle"] for a in ex), default=0.0),
                        median_d_gpu_exact=float(np.median([a["d_gpu"] for a in ex])) if ex else 0.0, median_d_oracle_exact=float(np.median([a["d_oracle"] for a in ex])) if ex else 0.0,
-                       worst_ratio_gpu_over_oracle=max((a["d_gpu"] / max(a["d_oracle"], 1e-7) for a in ex), default=0.0))
+                       worst_ratio_gpu_over_oracle=max((a["ratio"] for a in ex), default=0.0), within_factor_of_oracle=int(sum(a["within_factor"] for a in ex)),
+                       adjudications=adj[:20])
             if step == 0:      # the interior point's own floor: agreeing instances against the exact solution
                 pick = np.random.default_rng(7).choice(np.nonzero(ok & (dall <= 1e-6))[0], size=min(N_SAMPLE, int((ok & (dall <= 1e-6)).sum())), replace=False)
                 dd = []

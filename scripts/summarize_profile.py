@@ -38,6 +38,14 @@ if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CYCLES" in c and "SQ_WAVE_CYCLES" in 
     d["valu_active_fraction_of_wave_cycles"] = c["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] / c["SQ_WAVE_CYCLES"]["mean_per_launch"]
 if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c:
     d["valu_instructions_per_wave"] = c["SQ_INSTS_VALU"]["mean_per_launch"] / c["SQ_WAVES"]["mean_per_launch"]
+if "SQ_THREAD_CYCLES_VALU" in c and "SQ_INSTS_VALU" in c:
+    # lanes enabled (EXEC) per VALU instruction: SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU reads exactly K on a kernel that runs with K of 64 lanes enabled
+    # (scripts/bin_src/lanes_counter_test.hip -> profiles/r04_lanes_counter_calibration.json: 64.0, 32.0, 16.0, 8.0, 1.0).  The sweeps of these kernels keep EXEC
+    # full on purpose (unconditional arithmetic, dead stores), so this is an upper bound on the lanes that carry data: bench.py's lanes_useful models those.
+    d["valu_lanes_active"] = c["SQ_THREAD_CYCLES_VALU"]["mean_per_launch"] / c["SQ_INSTS_VALU"]["mean_per_launch"]
+if "SQ_INSTS_VALU" in c and summary.get("kernel_stats"):
+    # fraction of the chip's VALU issue slots: one wave64 VALU instruction holds a SIMD for 4 cycles; 1024 SIMDs; 2.4 GHz nominal
+    d["valu_issue_fraction"] = c["SQ_INSTS_VALU"]["mean_per_launch"] * 4.0 / (1024 * summary["kernel_stats"]["avg_ns"] * 2.4)
 if "SQ_VALU_MFMA_BUSY_CYCLES" in c and summary.get("kernel_stats"):
     # SQ_VALU_MFMA_BUSY_CYCLES counts cycles (MI355X_MICROARCH.md: 64 per v_mfma_f64_16x16x4, 16 per v_mfma_f64_4x4x4_4b -- checked against SQ_INSTS_MFMA),
     # summed over the SIMDs the launch ran on; utilisation = that / (SIMDs x kernel duration in cycles at the 2.4 GHz nominal clock)

@@ -4,7 +4,7 @@ sub-goal hook (set_subgoal, :279-284; x_N read-back, :232) and the explicit slac
 import numpy as np
 import pytest
 
-from helpers import OracleLoop, oracle_P, oracle_guess, qp_merit, random_batch
+from helpers import OracleLoop, adjudicate, allowed_adjudications, oracle_P, oracle_guess, random_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -115,15 +115,14 @@ def test_fused_step_against_the_oracle_loop_with_resync(env):
                 continue                                            # capped / failed QPs: iterates need not agree (the statuses did)
             d = max(np.abs(after["X"][b] - L.X).max(), np.abs(after["U"][b] - L.U).max())
             if d > 1e-6:
-                # an ill-conditioned QP at the float64 floor of the interior point (0.03-0.1 % of the solves at this size):
-                # judged by the QP itself -- the GPU's step, un-shifted, must satisfy the linearised dynamics and the boxes of the QP the
-                # oracle assembles from the same inputs, with an objective not above the oracle's
+                # an ill-conditioned QP at the float64 floor of the interior point: adjudicated against the EXACT solution of the
+                # QP the oracle assembles from the same inputs (helpers.adjudicate) -- the GPU's step, un-shifted, is within a factor of the oracle's
+                # distance from it and below the hard cap
                 n_out += 1
                 Xn = np.vstack([before["x0"][b][None], after["X"][b][:N]]); Un = np.vstack([after["u0"][b][None], after["U"][b][:N - 1]])
                 P = orc.predict_params(cfg, before["obst"][b])
-                fg, eqg, bg = qp_merit(orc, cfg, before["x0"][b], P, goal[b], before["X"][b], before["U"][b], Xn, Un)
-                fo, _, _ = qp_merit(orc, cfg, before["x0"][b], P, goal[b], before["X"][b], before["U"][b], r["X"], r["U"])
-                assert eqg <= 1e-7 and bg <= 1e-7 and fg <= fo + 1e-7 * max(1.0, abs(fo)) and d < 2e-2, (k, b, d, fg, fo, eqg, bg)
+                a = adjudicate(orc, cfg, before["x0"][b], P, goal[b], before["X"][b], before["U"][b], Xn, Un, r["X"], r["U"])
+                assert a["passed"], (k, b, d, a)
                 continue
             worst["X"] = max(worst["X"], d)
             worst["x"] = max(worst["x"], np.abs(after["x0"][b] - L.x).max())
@@ -131,7 +130,7 @@ def test_fused_step_against_the_oracle_loop_with_resync(env):
             worst["margin"] = max(worst["margin"], abs(after["margin"][b] - L.min_margin))
             assert abs(after["iters"][b] - r["iters"]) <= 1, (k, b)
     g.close()
-    assert n_cmp > 0.7 * B * K and n_out <= 0.01 * n_cmp, (n_cmp, n_out)
+    assert n_cmp > 0.7 * B * K and n_out <= max(2, 0.002 * n_cmp), (n_cmp, n_out)
     assert worst["X"] <= 1e-6 and worst["u"] <= 8e-6 and worst["x"] <= 1e-6 and worst["margin"] <= 1e-6, worst
 
 
@@ -244,12 +243,10 @@ def test_outliers_are_judged_by_the_qp_not_by_a_count(env):
             if d <= 1e-6:
                 continue
             n_out += 1
-            fg, eqg, bg = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xin[b], Uin[b], Xa[b], Ua[b])
-            fo, eqo, bo = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xin[b], Uin[b], oo["X"][b], oo["U"][b])
-            assert eqg <= 1e-7 and bg <= 1e-7, (b, d, eqg, bg)
-            assert fg <= fo + 1e-7 * max(1.0, abs(fo)), (b, d, fg, fo)
-            assert d < 5e-3
-    print("outliers judged by the QP:", n_out)
+            a = adjudicate(orc, cfg, x0[b], P[b], goal[b], Xin[b], Uin[b], Xa[b], Ua[b], oo["X"][b], oo["U"][b])
+            assert a["passed"], (b, d, a)
+    assert n_out <= 2 * allowed_adjudications(cfg, B), n_out
+    print("outliers adjudicated against the exact QP solution:", n_out)
 
 
 def test_interpolate_init_guess(env):

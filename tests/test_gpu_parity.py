@@ -7,7 +7,7 @@ qp_tol = 1e-10 (the library's and the oracle's default) and cap QP_ITER = 50, so
 import numpy as np
 import pytest
 
-from helpers import judge_against_oracle, oracle_P, oracle_guess, qp_merit, random_batch
+from helpers import adjudicate_batch, judge_against_oracle, oracle_P, oracle_guess, qp_merit, random_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -163,7 +163,7 @@ def test_permutation_invariance_large_batch(env):
         same = g1["status"][perm] == g2["status"]
         assert same.mean() > 0.999
         d = np.abs(X1[perm] - X2).reshape(B, -1).max(1)[same & (g2["status"] == 0)]
-        assert np.median(d) < 1e-12 and np.quantile(d, 0.999) < 1e-6 and d.max() < 1e-3
+        assert np.median(d) < 1e-12 and np.quantile(d, 0.999) < 1e-6 and d.max() < 1e-4
     # spot-check 64 of them against the oracle
     cfg = orc.config(N, no, 2.0)
     idx = perm[:64]
@@ -294,7 +294,7 @@ def test_row_parallel_factorisation_matches_systolic_and_oracle(env, N, no, B, l
         # both paths are equally close to the oracle (debug_rowpar.py); ill-conditioned long horizons move by ~1e-5 under rounding
         # (the second solves start from iterates that already differ by that much; one sensitive instance is allowed at N = 50)
         assert np.median(d) < 1e-10 and np.quantile(d, 0.95) < (1e-7 if N <= 20 else 2e-6)
-        assert d.max() < 1e-6 if N <= 20 else (np.sort(d)[-2] < 1e-4 and d.max() < 1e-3)
+        assert d.max() < 1e-6 if N <= 20 else (np.sort(d)[-2] < 1e-5 and d.max() < 1e-4)
     # against the oracle on the first solve
     cfg = orc.config(N, no, 0.1 * N)
     P = oracle_P(orc, cfg, obst); Xg, Ug = oracle_guess(orc, cfg, x0)
@@ -378,15 +378,11 @@ def test_stage_split_matches_one_lane_per_stage_and_oracle(env, N, no, B):
         assert nj["status_borderline"] == 0, nj
         tol = 1e-6 if N <= 20 else 5e-5           # longer horizons: an ill-conditioned instance or two sit at 1e-6 on either mapping
         d = np.abs(X - o["X"]).reshape(B, -1).max(1)[ok]; dU = np.abs(U - o["U"]).reshape(B, -1).max(1)[ok]
-        # an ill-conditioned QP or two per batch (10 obstacles, long horizons) sit at the float64 floor of the interior point on EVERY
-        # mapping.  Such an instance is judged by the QP itself, not by a count: the GPU's step must satisfy the
-        # linearised dynamics and the boxes and its QP objective must not exceed the oracle's (helpers.qp_merit, orc_export_qp)
-        assert d.max() < 1e-3 and np.quantile(d, 0.9) < 1e-8
+        # an ill-conditioned QP per batch (10 obstacles, long horizons) may sit at the float64 floor of the interior point on EVERY mapping (DESIGN.md
+        # section 2): judge_against_oracle above has adjudicated it against the exact solution of the QP and bounded how many there are
+        assert d.max() < 1e-4 and np.quantile(d, 0.9) < 1e-8
         for b in np.nonzero(ok)[0][(d > tol) | (dU > 8 * tol)]:
             assert no == 10 or N > 20, (b, d.max())
-            fg, eqg, bg = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xg[b], Ug[b], X[b], U[b])
-            fo, _, _ = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xg[b], Ug[b], o["X"][b], o["U"][b])
-            assert eqg <= 1e-7 and bg <= 1e-7 and fg <= fo + 1e-7 * max(1.0, abs(fo)), (b, fg, fo, eqg, bg)
         rel = np.abs(g["cost"] - o["cost"])[ok] / np.maximum(1.0, np.abs(o["cost"][ok]))
         assert np.sort(rel)[-3 if no == 10 else -1] < (1e-8 if N <= 20 else 1e-6)
         if lps > 1:
@@ -486,17 +482,14 @@ def test_three_instances_per_wavefront(env, N, no, B):
         ok = (ga["status"] == 0) & (gb["status"] == 0)
         assert (ga["iters"][ok] == gb["iters"][ok]).mean() >= 0.95
         d = np.abs(Xa - Xb).reshape(B, -1).max(1)[ok]
-        assert np.median(d) < 1e-10 and np.quantile(d, 0.95) < 1e-6 and d.max() < 1e-3
+        assert np.median(d) < 1e-10 and np.quantile(d, 0.95) < 1e-6 and d.max() < 1e-4
     o = orc.rti_solve_batch(cfg, x0, P, goal, Xg, Ug)
     g, X, U = res[21][0]
     assert (g["status"] == o["status"]).all()
     ok = o["status"] == 0
     d = np.abs(X - o["X"]).reshape(B, -1).max(1)[ok]
-    assert np.quantile(d, 0.9) < 1e-8 and d.max() < 1e-3
-    for b in np.nonzero(ok)[0][d > 1e-6]:       # judged by the QP (helpers.qp_merit), as everywhere
-        fg, eqg, bg = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xg[b], Ug[b], X[b], U[b])
-        fo, _, _ = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xg[b], Ug[b], o["X"][b], o["U"][b])
-        assert eqg <= 1e-7 and bg <= 1e-7 and fg <= fo + 1e-7 * max(1.0, abs(fo)), (b, fg, fo)
+    assert np.quantile(d, 0.9) < 1e-8 and d.max() < 1e-4
+    adjudicate_batch(orc, cfg, x0, P, goal, Xg, Ug, X, U, o, np.nonzero(ok)[0][d > 1e-6], what="three instances per wavefront")       # against the exact QP solution, as everywhere
     with mpc_gpu.BatchedMpc(21, 3, 2.1, max_batch=4) as s:
         from mpc_gpu import _lib
         assert _lib.lib().mpc_set_lanes_per_instance(s._h, 21) == _lib.MPC_ERR_ARG      # 22 stages do not fit 21 lanes
@@ -531,12 +524,8 @@ def test_full_size_batches_c3_and_c4_share(env, B):
     assert (o["status"] == h1["status"][idx]).all()
     ok = o["status"] == 0
     d = np.abs(o["X"] - X1[idx]).reshape(256, -1).max(1)[ok]
-    assert np.quantile(d, 0.98) < 1e-8 and d.max() < 1e-3
-    for k in np.nonzero(ok)[0][d > TOL_X]:
-        b = idx[k]
-        fg, eqg, bg = qp_merit(orc, cfg, x0[b], P[k], goal[b], Xs[b], Us[b], X1[b], U1[b])
-        fo, _, _ = qp_merit(orc, cfg, x0[b], P[k], goal[b], Xs[b], Us[b], o["X"][k], o["U"][k])
-        assert eqg <= 1e-7 and bg <= 1e-7 and fg <= fo + 1e-7 * max(1.0, abs(fo)), (b, fg, fo)
+    assert np.quantile(d, 0.98) < 1e-8 and d.max() < 1e-4
+    adjudicate_batch(orc, cfg, x0[idx], P, goal[idx], Xs[idx], Us[idx], X1[idx], U1[idx], o, np.nonzero(ok)[0][d > TOL_X], what="permuted batch")
 
 
 @pytest.mark.gpu
@@ -760,10 +749,7 @@ def test_any_obstacle_count(built, N, no, B):
             ok = o["status"] == 0
             assert (g["iters"][ok] == o["iters"][ok]).mean() >= 0.9
             d = np.abs(X - o["X"]).reshape(B, -1).max(1)
-            for b in np.nonzero(ok & (d > 1e-6))[0]:
-                fg, eqg, bg = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xo[b], Uo[b], X[b], U[b])
-                fo, _, _ = qp_merit(orc, cfg, x0[b], P[b], goal[b], Xo[b], Uo[b], o["X"][b], o["U"][b])
-                assert eqg <= 1e-7 and bg <= 1e-7 and fg <= fo + 1e-7 * max(1.0, abs(fo)), (k, b, fg, fo)
+            adjudicate_batch(orc, cfg, x0, P, goal, Xo, Uo, X, U, o, np.nonzero(ok & (d > 1e-6))[0], what=f"{no} obstacles, step {k}")
             assert np.median(d[ok]) < 1e-9
             rel = np.abs(g["cost"][ok] - o["cost"][ok]) / np.maximum(1.0, np.abs(o["cost"][ok]))
             assert np.median(rel) < 1e-10

@@ -79,13 +79,13 @@ def test_cost_allgather_world_size_2_gloo(built, tmp_path):
     assert r.stdout.count("ok") == 2
 
 
-@pytest.mark.parametrize("workload,total", [("c4", 262144), ("c5", 32768), ("c2", 2048)])
-def test_bench_multi_rank_path_world_size_2_gloo(built, workload, total):
-    """`python bench.py --gpus 2` starts its two ranks itself (torch.distributed.run), every rank takes its shard_slice of the
-    workload's ONE global batch and the per-scenario costs of 50 control steps are exchanged with sharding.gather_costs -- rehearsed
-    on CPU with gloo (--dry-run: the same plumbing, no kernels; each cost is the instance's global index, so a wrong slice or a
-    wrong gather order is visible)."""
+_DRY = {}
+
+
+def _bench_dry_run(workload, fresh=False):
     import json
+    if workload in _DRY and not fresh:
+        return _DRY[workload]
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
@@ -93,8 +93,26 @@ def test_bench_multi_rank_path_world_size_2_gloo(built, workload, total):
                         "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    _DRY.setdefault(workload, line)
+    return line
+
+
+@pytest.mark.parametrize("workload,total", [("c4", 262144), ("c5", 32768), ("c2", 2048)])
+def test_bench_multi_rank_path_world_size_2_gloo(built, workload, total):
+    """`python bench.py --gpus 2` starts its two ranks itself (torch.distributed.run), every rank takes its shard_slice of the
+    workload's ONE global batch and the per-scenario costs of 50 control steps are exchanged with sharding.gather_costs -- rehearsed
+    on CPU with gloo (--dry-run: the same plumbing, no kernels; each cost is the instance's global index, so a wrong slice or a
+    wrong gather order is visible)."""
+    line = _bench_dry_run(workload)
     assert line["n_gpus"] == 2 and line["gather_check"] is True and line["config"]["global_batch"] == total
     assert line["config"]["rank0_slice"] == [0, total // 2] and line["scaling"] == ("weak" if workload == "c2" else "strong")
+    # the id plumbing of the C-ABI exchange (--exchange capi, the default): every rank ended with rank 0's 128 bytes (gather_check covers it)
+    assert line["exchange"] == "capi" and isinstance(line["comm_id_sha1"], str) and len(line["comm_id_sha1"]) == 40
+
+
+def test_comm_unique_id_differs_between_runs(built):
+    """... and a fresh id per run: two launches never share a communicator id"""
+    assert _bench_dry_run("c2")["comm_id_sha1"] != _bench_dry_run("c2", fresh=True)["comm_id_sha1"]
 
 
 def test_step_counts_per_call_for_the_subgoal_hook(built):
