@@ -135,13 +135,25 @@ def make_workload(name, world, rank, shard_slice):
     return x0, goal, obst, desc, (lo, hi), G
 
 
+def pick_streams(batch):
+    """sub-batches pipelined on separate streams (mpc_gpu.pipeline.PipelinedMpc): two once the batch is at least two rounds of wavefronts deep on the chip's 1024
+    wavefront slots (measured: 4096 x (N = 50, 10 obstacles) +27 %, 32768 x (N = 20, 3 obstacles) +6 %, 65536 +2.4 %; four lose -- profiles/r04_streams_probe_*.json);
+    one for the 1024 instances of C2, which are a single round"""
+    return 2 if batch >= 2048 else 1
+
+
 class Loop:
     """closed-loop state of one rank's slice on one GPU"""
 
-    def __init__(self, mpc_gpu, torch, N, n_obst, x0, goal, obst, dev, **cfg):
+    def __init__(self, mpc_gpu, torch, N, n_obst, x0, goal, obst, dev, streams=1, **cfg):
         batch = x0.shape[0]
         self.torch = torch
-        self.m = mpc_gpu.BatchedMpc(N, n_obst, 0.1 * N, max_batch=batch, device=dev.index or 0, **cfg)
+        self.streams = streams
+        if streams > 1:
+            from mpc_gpu.pipeline import PipelinedMpc
+            self.m = PipelinedMpc(N, n_obst, 0.1 * N, max_batch=batch, device=dev.index or 0, streams=streams, **cfg)
+        else:
+            self.m = mpc_gpu.BatchedMpc(N, n_obst, 0.1 * N, max_batch=batch, device=dev.index or 0, **cfg)
         self.B, self.N, self.no = batch, N, n_obst
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         z = lambda *s, dt=torch.float64: torch.zeros(*s, dtype=dt, device=dev)
@@ -153,15 +165,30 @@ class Loop:
         self.stream = torch.cuda.current_stream().cuda_stream   # the caller runs us under an explicit torch stream
         assert self.stream != 0, "run under an explicit torch stream so torch ops and library kernels share one queue"
 
+    def join(self):
+        """the current stream waits for the sub-batch streams (a no-op with one stream)"""
+        if self.streams > 1:
+            self.m.join()
+
     def reset(self):
         """start an episode: initial scenario, set_initial_guess() (two device-to-device copies + one small kernel)"""
+        if self.streams > 1:
+            self.m.join()           # the copies below run on the current stream: behind the last control steps of every sub-batch ...
         self.x0.copy_(self.x0_init); self.obst.copy_(self.obst_init)
-        self.m.reset_guess_dev(self.B, self.x0, self.X, self.U, stream=self.stream)
+        if self.streams > 1:
+            self.m.fork()           # ... and the sub-batch streams continue behind them
+            self.m.reset_guess_dev(self.B, self.x0, self.X, self.U)
+        else:
+            self.m.reset_guess_dev(self.B, self.x0, self.X, self.U, stream=self.stream)
 
     def control_step(self, cost_out=None):
-        """one control step of the whole batch = ONE kernel launch; cost_out: where the kernel writes this step's per-scenario costs"""
-        self.m.closed_loop_step_dev(self.B, self.x0, self.obst, self.goal, self.X, self.U, self.u0,
-                                    self.cost if cost_out is None else cost_out, self.status, self.iters, None, stream=self.stream)
+        """one control step of the whole batch = ONE kernel launch per sub-batch stream; cost_out: where the kernels write this step's per-scenario costs"""
+        if self.streams > 1:
+            self.m.closed_loop_step_dev(self.B, self.x0, self.obst, self.goal, self.X, self.U, self.u0,
+                                        self.cost if cost_out is None else cost_out, self.status, self.iters, None)
+        else:
+            self.m.closed_loop_step_dev(self.B, self.x0, self.obst, self.goal, self.X, self.U, self.u0,
+                                        self.cost if cost_out is None else cost_out, self.status, self.iters, None, stream=self.stream)
 
 
 class CostExchange:
@@ -169,8 +196,9 @@ class CostExchange:
     history is in flight while the next fills).  Not every control step: at batch 1024 the solve kernel fills every SIMD with exactly
     one 512-register wavefront, so any kernel beside it (the collective's) holds back the workgroups of the CUs it occupies."""
 
-    def __init__(self, torch, world, batch, dev, gather_costs):
+    def __init__(self, torch, world, batch, dev, gather_costs, join=None):
         self.torch, self.world, self.gather = torch, world, gather_costs
+        self.join = join or (lambda: None)      # makes the current stream wait for the solver's sub-batch streams (Loop.join)
         self.hist = torch.zeros(2, GATHER_EVERY, batch, dtype=torch.float64, device=dev)
         self.out = torch.zeros(world * GATHER_EVERY * batch, dtype=torch.float64, device=dev)
         self.side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
@@ -185,6 +213,7 @@ class CostExchange:
         if self.n % GATHER_EVERY:
             return
         self.wait()                                              # the previous message left the other history two fills ago
+        self.join()
         if self.side is not None:
             self.side.wait_stream(self.torch.cuda.current_stream())
             with self.torch.cuda.stream(self.side):
@@ -206,8 +235,8 @@ class CApiCostExchange(CostExchange):
     """The same double-buffered exchange through the library's own collective (include/mpc_gpu.h: mpc_comm_init, mpc_allgather_cost_dev = RCCL's
     ncclAllGather issued by libmpcgpu on the side stream) -- the path a host without torch.distributed takes."""
 
-    def __init__(self, torch, world, batch, dev, solver):
-        super().__init__(torch, world, batch, dev, None)
+    def __init__(self, torch, world, batch, dev, solver, join=None):
+        super().__init__(torch, world, batch, dev, None, join=join)
         self.m = solver
         self.done = torch.cuda.Event()
         self.pending = False
@@ -218,6 +247,7 @@ class CApiCostExchange(CostExchange):
         if self.n % GATHER_EVERY:
             return
         self.wait()
+        self.join()
         self.side.wait_stream(self.torch.cuda.current_stream())
         self.m.allgather_cost_dev(GATHER_EVERY * self.hist.shape[2], self.hist[buf], self.out, stream=self.side.cuda_stream)
         self.done.record(self.side)
@@ -432,6 +462,10 @@ def roofline(loop, N, no, r):
     raw_s = r["kern_ms"] / max(1, r["launches"]) * 1e-3
     avg_s = max(raw_s - r["pair_ms"] * 1e-3, 1e-9)          # event-bracketed duration minus what an empty bracket measures
     wall_per_launch = r["elapsed"] / (r["steps"] * EPISODE)
+    if loop.streams > 1:
+        # sub-batches pipelined on several streams: their launches overlap in time, so an event-bracketed launch duration is not the time the chip spent
+        # on that launch's work.  The per-control-step wall time of the whole batch (all sub-launches) is -- `kernel_time_over_wall` is 1 by construction
+        avg_s = wall_per_launch
     flops = algorithmic_flops_per_solve(N, no, r["mean_iters"]) * batch
     abytes = algorithmic_bytes_per_solve(N, no) * batch
     pm = measured_pmc(kname, batch)
@@ -457,7 +491,7 @@ def roofline(loop, N, no, r):
             "traffic": pm["traffic"] if pm else None,
             "traffic_source": (f"HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE passes of this command, profiles/{pm['file']} "
                                "(FETCH_SIZE uncorrected: 8-byte-per-lane loads)") if pm else None,
-            "kernel": kname, "avg_launch_us": avg_s * 1e6, "avg_launch_us_raw": raw_s * 1e6, "event_pair_overhead_us": r["pair_ms"] * 1e3,
+            "kernel": kname, "streams": loop.streams, "avg_launch_us": avg_s * 1e6, "avg_launch_us_raw": raw_s * 1e6, "event_pair_overhead_us": r["pair_ms"] * 1e3,
             "kernel_time_over_wall": avg_s / wall_per_launch, "launches_timed": r["launches"],
             "launch_timing": (f"HIP events on the launch stream around every {EVENT_EVERY}th launch of the timed region, minus the duration an empty event pair "
                               "measures on the same stream (median of 64); kernel_time_over_wall = that per-launch time / wall time per control step (one launch "
@@ -571,6 +605,8 @@ def main():
     ap.add_argument("--exchange", default="capi", choices=["capi", "torch"],
                     help="multi-rank cost all-gather: capi = the library's own C-ABI collective (mpc_comm_init + mpc_allgather_cost_dev, RCCL called by "
                          "libmpcgpu; default), torch = torch.distributed.all_gather_into_tensor")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="sub-batches pipelined on separate HIP streams per GPU (mpc_gpu.pipeline.PipelinedMpc); 0 = automatic: two from 2048 instances per GPU on, else one")
     ap.add_argument("--share", type=int, default=0,
                     help="single-GPU run of ONE rank's share of a K-way sharded workload (rank 0's slice of shard_slice(total, r, K)): the per-GPU work of "
                          "`--gpus K` without the other K - 1 GPUs (profiles/r04_c5_share_*: --workload c5 --share 8)")
@@ -624,7 +660,7 @@ def main():
         x0, goal, obst, desc, (lo, hi), _ = make_workload(args.workload, args.share, 0, shard_slice)
         G = hi - lo
         desc += f" -- rank 0's slice of {args.share} ({G} instances) on this one GPU"
-    loop = Loop(mpc_gpu, torch, N, no, x0, goal, obst, dev)
+    loop = Loop(mpc_gpu, torch, N, no, x0, goal, obst, dev, streams=args.streams or pick_streams(hi - lo))
     exch, exchange = None, None
     if world > 1 and (hi - lo) * world == G:
         exchange = args.exchange
@@ -633,9 +669,9 @@ def main():
         if exchange == "capi":
             uid = exchange_comm_id(dist, rank, mpc_gpu.BatchedMpc.comm_unique_id)
             loop.m.comm_init(rank, world, uid)
-            exch = CApiCostExchange(torch, world, hi - lo, dev, loop.m)
+            exch = CApiCostExchange(torch, world, hi - lo, dev, loop.m, join=loop.join)
         else:
-            exch = CostExchange(torch, world, hi - lo, dev, gather_costs)
+            exch = CostExchange(torch, world, hi - lo, dev, gather_costs, join=loop.join)
     r = measure(torch, dist, loop, world, exch, args.steps, args.warmup, dev)
     gather_ok = None
     if exch is not None:         # the last completed message: every rank's row of the final control step must be that rank's own costs (rank 0 checks its own)
@@ -657,6 +693,7 @@ def main():
                       "parallelism": (f"batch slices over {world} ranks (mpc_gpu.sharding.shard_slice), no data-path collective; per-scenario costs "
                                       f"all-gathered over RCCL, {GATHER_EVERY} control steps per message") if world > 1 else "single GPU"},
            "exchange": exchange, "rccl_ranks": loop.m.comm_world() if exchange == "capi" else None, "gather_check": gather_ok,
+           "streams_per_gpu": loop.streams,
            "ms_per_control_step": r["elapsed"] / (args.steps * EPISODE) * 1e3,
            "mean_ipm_iters": r["mean_iters"], "qp_failure_frac": r["fail"], "qp_iter_cap_frac": r["cap"],
            "lanes_per_instance": loop.m.lanes_per_instance(loop.B), "lanes_per_stage": loop.m.lanes_per_stage(loop.B),
@@ -664,38 +701,35 @@ def main():
            "roofline": roofline(loop, N, no, r)}
 
     if rank == 0 and world == 1 and not args.no_extra and args.workload == "c2":
-        # supplementary: the large-batch configuration (configs[2]) and the single-scenario latency (configs[0]) on the same GPU
-        xb, gb, ob, d3, _, G3 = make_workload("c3", 1, 0, shard_slice)
-        l3 = Loop(mpc_gpu, torch, N, no, xb, gb, ob, dev)
-        r3 = measure(torch, None, l3, 1, None, 3, 1, dev)
-        out["extra"] = {"workload": d3, "value": G3 * EPISODE * 3 / r3["elapsed"], "unit": "solves/s", "steps": 3, "warmup": 1,
-                        "ms_per_step": r3["elapsed"] / 3 * 1e3, "ms_per_control_step": r3["elapsed"] / (3 * EPISODE) * 1e3,
-                        "mean_ipm_iters": r3["mean_iters"], "qp_failure_frac": r3["fail"], "roofline": roofline(l3, N, no, r3)}
+        # supplementary: the other BASELINE configurations on this one GPU.  Each is measured twice: on ONE stream (the kernel alone on the chip: `roofline`,
+        # `value_one_stream`) and with its sub-batches pipelined on two streams (`value`: what `--workload` of that name reports; mpc_gpu.pipeline)
+        def extra(wl, share, steps, what):
+            Ne, noe = WORKLOADS[wl][:2]
+            xe, ge, oe, de, _, _ = make_workload(wl, share, 0, shard_slice)
+            Be = len(xe)
+            l1 = Loop(mpc_gpu, torch, Ne, noe, xe, ge, oe, dev)
+            r1 = measure(torch, None, l1, 1, None, steps, 1, dev)
+            roof = roofline(l1, Ne, noe, r1)
+            del l1
+            K = pick_streams(Be)
+            lK = Loop(mpc_gpu, torch, Ne, noe, xe, ge, oe, dev, streams=K)
+            rK = measure(torch, None, lK, 1, None, steps, 1, dev)
+            del lK
+            e = {"workload": de + (f" -- rank 0's slice of {share} ({Be} instances) on this one GPU" if share > 1 else ""), "what": what,
+                 "value": Be * EPISODE * steps / rK["elapsed"], "unit": "solves/s", "streams": K, "value_one_stream": Be * EPISODE * steps / r1["elapsed"],
+                 "steps": steps, "warmup": 1, "ms_per_step": rK["elapsed"] / steps * 1e3, "ms_per_control_step": rK["elapsed"] / (steps * EPISODE) * 1e3,
+                 "mean_ipm_iters": rK["mean_iters"], "qp_failure_frac": rK["fail"], "roofline": roof}
+            if share > 1:
+                e["predicted_value_on_%d_gpus" % share] = share * e["value"]
+            return e
+        out["extra"] = extra("c3", 1, 3, "BASELINE configs[2]: 65536 randomized scenarios on this GPU")
         out["value_throughput"] = out["extra"]["value"]
         out["value_throughput_config"] = "C3 (BASELINE configs[2]): 65536 randomized scenarios on this GPU -- `value` is the latency-shaped C2 (1024 scenarios = one wavefront per SIMD); `extra` has the details"
-        del l3
-        # ... and the long-horizon configuration (configs[4]: N = 50, 10 obstacles, 32768 scenarios) on this one GPU, two episodes
-        N5, no5 = WORKLOADS["c5"][:2]
-        x5, g5, o5, d5, _, G5 = make_workload("c5", 1, 0, shard_slice)
-        l5 = Loop(mpc_gpu, torch, N5, no5, x5, g5, o5, dev)
-        r5 = measure(torch, None, l5, 1, None, 2, 1, dev)
-        out["extra_c5"] = {"workload": d5, "value": G5 * EPISODE * 2 / r5["elapsed"], "unit": "solves/s", "steps": 2, "warmup": 1,
-                           "ms_per_step": r5["elapsed"] / 2 * 1e3, "ms_per_control_step": r5["elapsed"] / (2 * EPISODE) * 1e3,
-                           "mean_ipm_iters": r5["mean_iters"], "qp_failure_frac": r5["fail"], "roofline": roofline(l5, N5, no5, r5)}
-        del l5
-        # ... and the PER-GPU SHARES of the two 8-GPU configurations on this one GPU: what one rank of `--gpus 8 --workload c4 / c5` solves
-        # (32768 resp. 4096 instances) -- the strong-scaling predictor: 8 x these against `extra` / `extra_c5` is the efficiency to expect
-        for key, wl, share in (("extra_c4_share", "c4", 32768), ("extra_c5_share", "c5", 4096)):
-            Ns, nos = WORKLOADS[wl][:2]
-            xs, gs, os_, ds, _, _ = make_workload(wl, 8, 0, shard_slice)
-            assert len(xs) == share
-            ls = Loop(mpc_gpu, torch, Ns, nos, xs, gs, os_, dev)
-            rs = measure(torch, None, ls, 1, None, 3, 1, dev)
-            out[key] = {"workload": ds + f" -- rank 0's slice of 8 ({share} instances) on this one GPU", "value": share * EPISODE * 3 / rs["elapsed"], "unit": "solves/s",
-                        "steps": 3, "warmup": 1, "ms_per_control_step": rs["elapsed"] / (3 * EPISODE) * 1e3, "mean_ipm_iters": rs["mean_iters"],
-                        "qp_failure_frac": rs["fail"], "roofline": roofline(ls, Ns, nos, rs),
-                        "predicted_8gpu_value": 8 * share * EPISODE * 3 / rs["elapsed"]}
-            del ls
+        out["extra_c5"] = extra("c5", 1, 2, "BASELINE configs[4] on ONE GPU: N = 50, 10 obstacles, 32768 scenarios")
+        # the PER-GPU SHARES of the two 8-GPU configurations on this one GPU: what one rank of `--gpus 8 --workload c4 / c5` solves -- the strong-scaling
+        # predictor (no data-path collective: 8 x the share rate is what 8 GPUs deliver if nothing else interferes)
+        out["extra_c4_share"] = extra("c4", 8, 3, "BASELINE configs[3]: one rank's 32768 of 262144 scenarios")
+        out["extra_c5_share"] = extra("c5", 8, 3, "BASELINE configs[4]: one rank's 4096 of 32768 scenarios (N = 50, 10 obstacles)")
         # ... and C2 at the tolerance rounds 1-2 ran (1e-8), for continuity with their lines: same kernel, 3-5 % fewer iterations
         l8 = Loop(mpc_gpu, torch, N, no, x0, goal, obst, dev, qp_tol=1e-8)
         r8 = measure(torch, None, l8, 1, None, 5, 1, dev)

@@ -111,6 +111,7 @@ mpc::KParams make_params(const mpc_config &c, int batch)
     p.r2 = c.r_safe * c.r_safe;
     p.slack_a = c.slack_a; p.slack_b = c.slack_b; p.ss = c.slack_scale_dt ? p.dt : 1.0;
     p.tol = c.qp_tol; p.mu0 = c.mu0; p.thr0 = c.thr0;
+    p.tl_min = mpc::kTLMin < 0.1 * c.qp_tol ? mpc::kTLMin : 0.1 * c.qp_tol;      // oracle/mpc_oracle.c tl_min()
     const bool truncate = c.qp_fail_policy == 1;      // oracle/mpc_oracle.c ipm_solve: the same three tests
     p.mu_div = truncate ? 1e300 : mpc::kMuDiverged * c.mu0;
     p.mu_cap = truncate ? INFINITY : mpc::kMuCapFailed * c.mu0;

@@ -70,6 +70,7 @@ struct KParams {
     double r2;                // r_safe^2
     double slack_a, slack_b, ss;  // ss: penalty scale for stages < N (dt or 1)
     double tol, mu0, thr0;
+    double tl_min;                       // floor of t and lam: min(kTLMin, qp_tol / 10) (the floor must stay below the tolerance: an active row's rho - t is the floor)
     double mu_div, mu_cap, mu_settled;   // the divergence tests of the interior point as thresholds on mu (mpc_api.hip::make_params): kMuDiverged mu0, kMuCapFailed mu0, mu0 --
                                          // or, mpc_config.qp_fail_policy = 1 ("truncate"), 1e300 / inf / inf: a diverging solve runs to the iteration cap and ends as status 2
     const double *x0, *P, *goal;
@@ -2203,8 +2204,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             for (int k = 0; k < NB; k++) {
                 const double a = ll[k] * tl[k], b = lh[k] * th[k];
                 sg += a + b;
-                cg = fmax(cg, (tl[k] <= 2 * kTLMin || ll[k] <= 2 * kTLMin) ? 0.0 : a);
-                cg = fmax(cg, (th[k] <= 2 * kTLMin || lh[k] <= 2 * kTLMin) ? 0.0 : b);
+                cg = fmax(cg, (tl[k] <= 2 * p.tl_min || ll[k] <= 2 * p.tl_min) ? 0.0 : a);
+                cg = fmax(cg, (th[k] <= 2 * p.tl_min || lh[k] <= 2 * p.tl_min) ? 0.0 : b);
                 if (k == 1 || k == NB - 1) { msum = fma(MPC_MK(k), sg, msum); cmax = fmax(cmax, MPC_MK(k) * cg); sg = 0.0; cg = 0.0; }
             }
 #pragma unroll
@@ -2212,11 +2213,11 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 if (ROW_OFF(j)) continue;
                 const double a = l1[j] * t1[j];
                 sg += a;
-                cg = fmax(cg, (t1[j] <= 2 * kTLMin || l1[j] <= 2 * kTLMin) ? 0.0 : a);
+                cg = fmax(cg, (t1[j] <= 2 * p.tl_min || l1[j] <= 2 * p.tl_min) ? 0.0 : a);
                 if (soft) {
                     const double b = l2[j] * t2[j];
                     sg += b;
-                    cg = fmax(cg, (t2[j] <= 2 * kTLMin || l2[j] <= 2 * kTLMin) ? 0.0 : b);
+                    cg = fmax(cg, (t2[j] <= 2 * p.tl_min || l2[j] <= 2 * p.tl_min) ? 0.0 : b);
                 }
             }
             msum = fma(m_s, sg, msum); cmax = fmax(cmax, m_s * cg);
@@ -2722,8 +2723,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #pragma unroll
                 for (int k = 0; k < NB; k++) {
                     const int g = k < 2 ? 0 : 1;
-                    tl[k] = fmax(fma(aeg[g], dtl_[k], tl[k]), kTLMin); th[k] = fmax(fma(aeg[g], dth_[k], th[k]), kTLMin);
-                    ll[k] = fmax(fma(adg[g], dll_[k], ll[k]), kTLMin); lh[k] = fmax(fma(adg[g], dlh_[k], lh[k]), kTLMin);
+                    tl[k] = fmax(fma(aeg[g], dtl_[k], tl[k]), p.tl_min); th[k] = fmax(fma(aeg[g], dth_[k], th[k]), p.tl_min);
+                    ll[k] = fmax(fma(adg[g], dll_[k], ll[k]), p.tl_min); lh[k] = fmax(fma(adg[g], dlh_[k], lh[k]), p.tl_min);
                     if constexpr (!LEAN) { rtl[k] = rcp_nr(tl[k]); rth[k] = rcp_nr(th[k]); }
                 }
                 const double pz2 = phase_zero();
@@ -2733,11 +2734,11 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                     ObstStep q;
                     if constexpr (TWOPASS) q = obst_step(j, pz2);      // (its ratio outputs are dead here)
                     else { q.dt1 = dt1_[j]; q.dl1 = dl1_[j]; q.dt2 = dt2_[j]; q.dl2 = dl2_[j]; q.ds = ds_[j]; }
-                    t1[j] = fmax(fma(aeg[2], q.dt1, t1[j]), kTLMin); l1[j] = fmax(fma(adg[2], q.dl1, l1[j]), kTLMin);
+                    t1[j] = fmax(fma(aeg[2], q.dt1, t1[j]), p.tl_min); l1[j] = fmax(fma(adg[2], q.dl1, l1[j]), p.tl_min);
                     if constexpr (!LEAN) rt1[j] = rcp_nr(t1[j]);
                     if (soft) {
                         sv[j] = fma(aeg[2], q.ds, sv[j]);
-                        t2[j] = fmax(fma(aeg[2], q.dt2, t2[j]), kTLMin); l2[j] = fmax(fma(adg[2], q.dl2, l2[j]), kTLMin);
+                        t2[j] = fmax(fma(aeg[2], q.dt2, t2[j]), p.tl_min); l2[j] = fmax(fma(adg[2], q.dl2, l2[j]), p.tl_min);
                         if constexpr (!LEAN) rt2[j] = rcp_nr(t2[j]);
                     }
                 }
@@ -2754,8 +2755,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         for (int k = 0; k < NB; k++) if ((k < 2) ? vbu : vbx) {
             const double a = ll[k] * tl[k], b = lh[k] * th[k];
             msum += a + b;
-            if (!(tl[k] <= 2 * kTLMin || ll[k] <= 2 * kTLMin)) cmax = fmax(cmax, a);
-            if (!(th[k] <= 2 * kTLMin || lh[k] <= 2 * kTLMin)) cmax = fmax(cmax, b);
+            if (!(tl[k] <= 2 * p.tl_min || ll[k] <= 2 * p.tl_min)) cmax = fmax(cmax, a);
+            if (!(th[k] <= 2 * p.tl_min || lh[k] <= 2 * p.tl_min)) cmax = fmax(cmax, b);
         }
         if (vs) {
 #pragma unroll
@@ -2763,11 +2764,11 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 if (ROW_OFF(j)) continue;
                 const double a = l1[j] * t1[j];
                 msum += a;
-                if (!(t1[j] <= 2 * kTLMin || l1[j] <= 2 * kTLMin)) cmax = fmax(cmax, a);
+                if (!(t1[j] <= 2 * p.tl_min || l1[j] <= 2 * p.tl_min)) cmax = fmax(cmax, a);
                 if (soft) {
                     const double b = l2[j] * t2[j];
                     msum += b;
-                    if (!(t2[j] <= 2 * kTLMin || l2[j] <= 2 * kTLMin)) cmax = fmax(cmax, b);
+                    if (!(t2[j] <= 2 * p.tl_min || l2[j] <= 2 * p.tl_min)) cmax = fmax(cmax, b);
                 }
             }
         }
@@ -3239,19 +3240,19 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 for (int c = 0; c < 7; c++) z[c] += alpha * dz[c];
 #pragma unroll
                 for (int k = 0; k < NB; k++) if ((k < 2) ? vbu : vbx) {
-                    tl[k] = fmax(tl[k] + alpha * dtl_[k], kTLMin); th[k] = fmax(th[k] + alpha * dth_[k], kTLMin);
-                    ll[k] = fmax(ll[k] + alphad * dll_[k], kTLMin); lh[k] = fmax(lh[k] + alphad * dlh_[k], kTLMin);
+                    tl[k] = fmax(tl[k] + alpha * dtl_[k], p.tl_min); th[k] = fmax(th[k] + alpha * dth_[k], p.tl_min);
+                    ll[k] = fmax(ll[k] + alphad * dll_[k], p.tl_min); lh[k] = fmax(lh[k] + alphad * dlh_[k], p.tl_min);
                     if constexpr (!LEAN) { rtl[k] = rcp_nr(tl[k]); rth[k] = rcp_nr(th[k]); }
                 }
                 if (vs) {
 #pragma unroll
                     for (int j = 0; j < NOBST; j++) {
                         if (ROW_OFF(j)) continue;
-                        t1[j] = fmax(t1[j] + alpha * dt1_[j], kTLMin); l1[j] = fmax(l1[j] + alphad * dl1_[j], kTLMin);
+                        t1[j] = fmax(t1[j] + alpha * dt1_[j], p.tl_min); l1[j] = fmax(l1[j] + alphad * dl1_[j], p.tl_min);
                         if constexpr (!LEAN) rt1[j] = rcp_nr(t1[j]);
                         if (soft) {
                             sv[j] += alpha * ds_[j];
-                            t2[j] = fmax(t2[j] + alpha * dt2_[j], kTLMin); l2[j] = fmax(l2[j] + alphad * dl2_[j], kTLMin);
+                            t2[j] = fmax(t2[j] + alpha * dt2_[j], p.tl_min); l2[j] = fmax(l2[j] + alphad * dl2_[j], p.tl_min);
                             if constexpr (!LEAN) rt2[j] = rcp_nr(t2[j]);
                         }
                     }

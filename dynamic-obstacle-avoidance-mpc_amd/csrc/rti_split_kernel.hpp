@@ -374,18 +374,18 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
         for (int s = 0; s < NBL; s++) if (bp[s]) {
             const double a = ll[s] * tl[s], b = lh[s] * th[s];
             msum += a + b;
-            if (!(tl[s] <= 2 * kTLMin || ll[s] <= 2 * kTLMin)) cmax = fmax(cmax, a);
-            if (!(th[s] <= 2 * kTLMin || lh[s] <= 2 * kTLMin)) cmax = fmax(cmax, b);
+            if (!(tl[s] <= 2 * p.tl_min || ll[s] <= 2 * p.tl_min)) cmax = fmax(cmax, a);
+            if (!(th[s] <= 2 * p.tl_min || lh[s] <= 2 * p.tl_min)) cmax = fmax(cmax, b);
         }
 #pragma unroll
         for (int s = 0; s < NSL; s++) if (sp[s]) {
             const double a = l1[s] * t1[s];
             msum += a;
-            if (!(t1[s] <= 2 * kTLMin || l1[s] <= 2 * kTLMin)) cmax = fmax(cmax, a);
+            if (!(t1[s] <= 2 * p.tl_min || l1[s] <= 2 * p.tl_min)) cmax = fmax(cmax, a);
             if (soft) {
                 const double b = l2[s] * t2[s];
                 msum += b;
-                if (!(t2[s] <= 2 * kTLMin || l2[s] <= 2 * kTLMin)) cmax = fmax(cmax, b);
+                if (!(t2[s] <= 2 * p.tl_min || l2[s] <= 2 * p.tl_min)) cmax = fmax(cmax, b);
             }
         }
         seg_reduce2<64, true>(msum, cmax, lane);
@@ -988,18 +988,18 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
                 for (int s = 0; s < NBL; s++) {
                     zs[s] += alpha * dzs[s];
                     if (bp[s]) {
-                        tl[s] = fmax(tl[s] + alpha * dtl_[s], kTLMin); th[s] = fmax(th[s] + alpha * dth_[s], kTLMin);
-                        ll[s] = fmax(ll[s] + alphad * dll_[s], kTLMin); lh[s] = fmax(lh[s] + alphad * dlh_[s], kTLMin);
+                        tl[s] = fmax(tl[s] + alpha * dtl_[s], p.tl_min); th[s] = fmax(th[s] + alpha * dth_[s], p.tl_min);
+                        ll[s] = fmax(ll[s] + alphad * dll_[s], p.tl_min); lh[s] = fmax(lh[s] + alphad * dlh_[s], p.tl_min);
                         rtl[s] = rcp_nr(tl[s]); rth[s] = rcp_nr(th[s]);
                     }
                 }
 #pragma unroll
                 for (int s = 0; s < NSL; s++) if (sp[s]) {
-                    t1[s] = fmax(t1[s] + alpha * dt1_[s], kTLMin); l1[s] = fmax(l1[s] + alphad * dl1_[s], kTLMin);
+                    t1[s] = fmax(t1[s] + alpha * dt1_[s], p.tl_min); l1[s] = fmax(l1[s] + alphad * dl1_[s], p.tl_min);
                     rt1[s] = rcp_nr(t1[s]);
                     if (soft) {
                         sv[s] += alpha * ds_[s];
-                        t2[s] = fmax(t2[s] + alpha * dt2_[s], kTLMin); l2[s] = fmax(l2[s] + alphad * dl2_[s], kTLMin);
+                        t2[s] = fmax(t2[s] + alpha * dt2_[s], p.tl_min); l2[s] = fmax(l2[s] + alphad * dl2_[s], p.tl_min);
                         rt2[s] = rcp_nr(t2[s]);
                     }
                 }

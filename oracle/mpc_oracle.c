@@ -25,9 +25,10 @@
 /* floor of t and lam.  1e-13 until round 3; 1e-11 since round 4: a pair that collapses to the floor enters the reduced Hessian with the weight
  * lam / t, and at 1e-13 those weights (1e15 and more) cost the Newton step of the end-game its last digits -- measured against the EXACT solution of
  * the QP (tests/helpers.py::exact_qp) on first solves of C5's problem: worst 7.3e-4 -> 7.5e-6, 2.7 % -> 1.0 % of the instances beyond 1e-6, same
- * iteration counts (scripts/tail_scan_cpu.py).  Shared with the HIP kernels (rti_kernel.hpp kTLMin).  Must stay below qp_tol:
- * an active row's residual rho - t is the floor itself. */
-#define TL_MIN 1e-11
+ * iteration counts (scripts/tail_scan_cpu.py).  Shared with the HIP kernels (rti_kernel.hpp kTLMin, KParams::tl_min).  It must stay
+ * below qp_tol -- an active row's residual rho - t is the floor itself -- so the floor in effect is min(1e-11, qp_tol / 10). */
+#define TL_MIN_MAX 1e-11
+static _Thread_local double TL_MIN = TL_MIN_MAX;      /* the floor in effect: min(1e-11, qp_tol / 10), set per solve (ipm_solve) */
 
 /* Per-thread workspace of the solve path (round 4): the ~35 arrays of one solve come from a thread-local arena that is reset, not freed, when the
  * outermost solve returns -- the batch driver's OpenMP threads used to malloc / free each of them per solve, and the all-core cpu_baseline of
@@ -701,6 +702,7 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
     R.K = WS_ALLOC(sizeof(double[10]) * N); R.k = WS_ALLOC(sizeof(double[NU]) * N); R.L = WS_ALLOC(sizeof(double[4]) * N); R.Mxu = WS_ALLOC(sizeof(double[10]) * N);
     double re0[5], res[4];
     int status = 2, it = 0;
+    TL_MIN = TL_MIN_MAX < 0.1 * c->qp_tol ? TL_MIN_MAX : 0.1 * c->qp_tol;
 
     for (int e = 0; e < ni; e++) { if (Q->it[e].kind == 1) soft_row[Q->it[e].sidx] = e; if (Q->it[e].kind == 2) soft_pos[Q->it[e].sidx] = e; }
 

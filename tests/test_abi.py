@@ -80,6 +80,28 @@ def test_argument_validation_without_device(lib):
     assert L.mpc_comm_world(None) == 0
 
 
+def test_rccl_abi_constants_declared_locally_match_the_installed_header():
+    """mpc_api.hip declares RCCL's types and the two enum values it uses itself (no build-time dependency on the RCCL headers); where the header is installed,
+    they must be the header's"""
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr):
+        pytest.skip("no RCCL header on this machine")
+    h = open(hdr).read()
+    api = open(os.path.join(ROOT, "dynamic-obstacle-avoidance-mpc_amd", "csrc", "mpc_api.hip")).read()
+    assert "#include <rccl" not in api
+    assert int(re.search(r"#define\s+NCCL_UNIQUE_ID_BYTES\s+(\d+)", h).group(1)) == 128 == int(re.search(r"#define\s+MPC_COMM_ID_BYTES\s+(\d+)", open(os.path.join(ROOT, "include", "mpc_gpu.h")).read()).group(1))
+    assert int(re.search(r"ncclSuccess\s*=\s*(\d+)", h).group(1)) == int(re.search(r"ncclResult_t ncclSuccess = (\d+)", api).group(1))
+    assert int(re.search(r"ncclDouble\s*=\s*(\d+)", h).group(1)) == int(re.search(r"ncclDataType_t ncclDouble = (\d+)", api).group(1))
+
+
+def test_qp_fail_policy_is_validated(lib):
+    L = lib.lib()
+    h = C.c_void_p()
+    c2 = lib.default_config(20, 3, 2.0, qp_fail_policy=2)
+    assert L.mpc_create(C.byref(c2), 0, 1, C.byref(h)) == lib.MPC_ERR_ARG and b"qp_fail_policy" in L.mpc_last_error()
+    assert lib.default_config(20, 3, 2.0).qp_fail_policy == 0
+
+
 def test_product_does_not_touch_the_oracle():
     """the shipped package must not import, link or load anything under oracle/"""
     pkg = os.path.join(ROOT, "dynamic-obstacle-avoidance-mpc_amd")

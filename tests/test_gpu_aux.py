@@ -462,3 +462,60 @@ def test_compaction_of_finished_episodes_changes_nothing(env):
     same = np.all(e == f, axis=1)
     assert same.mean() >= 0.99, same.mean()
     assert np.abs(e[:, [0, 1, 5]].mean(axis=0) - f[:, [0, 1, 5]].mean(axis=0)).max() < 0.005 and abs(e[:, 4].mean() - f[:, 4].mean()) < 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,no,B,K", [(20, 3, 300, 2), (50, 10, 130, 2), (20, 3, 301, 3)])
+def test_pipelined_sub_batches_are_the_whole_batch(env, N, no, B, K):
+    """mpc_gpu.pipeline.PipelinedMpc -- the batch cut into K sub-batches on K streams, each with its own handle, launches joined only at the end -- gives the
+    closed loop of ONE handle on the whole batch bit for bit (one instance per wavefront at these sizes: an instance's arithmetic does not depend on its
+    neighbours), including the running episode bookkeeping; and the first step equals the oracle."""
+    import torch
+    from mpc_gpu import _lib
+    from mpc_gpu.pipeline import PipelinedMpc
+    mpc_gpu, orc = env
+    x0, goal, obst = random_batch(B, no, seed=900 + N)
+    dev = torch.device("cuda:0")
+    fl = _lib.STEP_SHIFT | _lib.STEP_PLANT | _lib.STEP_OBSTACLES | _lib.STEP_METRICS | _lib.STEP_RESET_ON_FAIL
+    outs = []
+    for pipelined in (False, True):
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            t = lambda a: torch.from_numpy(a.copy()).to(dev)
+            dx, dg, do = t(x0), t(goal), t(obst)
+            X = torch.zeros(B, N + 1, 5, dtype=torch.float64, device=dev); U = torch.zeros(B, N, 2, dtype=torch.float64, device=dev)
+            u0 = torch.zeros(B, 2, dtype=torch.float64, device=dev); cost = torch.zeros(B, dtype=torch.float64, device=dev)
+            status = torch.zeros(B, dtype=torch.int32, device=dev); iters = torch.zeros(B, dtype=torch.int32, device=dev)
+            margin = torch.full((B,), float("inf"), dtype=torch.float64, device=dev)
+            flags = torch.zeros(B, dtype=torch.int32, device=dev); steps = torch.zeros(B, dtype=torch.int32, device=dev)
+            first = None
+            if pipelined:
+                m = PipelinedMpc(N, no, 0.1 * N, max_batch=B, streams=K)
+                m.fork(); m.reset_guess_dev(B, dx, X, U)
+                for k in range(6):
+                    m.closed_loop_step_dev(B, dx, do, dg, X, U, u0, cost, status, iters, None, flags=fl, min_margin=margin, ep_flags=flags, ep_steps=steps)
+                    if k == 0:
+                        m.join(); first = (u0.cpu().numpy().copy(), status.cpu().numpy().copy()); m.fork()
+                m.join()
+            else:
+                m = mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B)
+                m.reset_guess_dev(B, dx, X, U, stream=st.cuda_stream)
+                for k in range(6):
+                    m.closed_loop_step_dev(B, dx, do, dg, X, U, u0, cost, status, iters, None, flags=fl, min_margin=margin, ep_flags=flags, ep_steps=steps, stream=st.cuda_stream)
+                    if k == 0:
+                        first = (u0.cpu().numpy().copy(), status.cpu().numpy().copy())
+            st.synchronize()
+            outs.append(dict(first=first, **{k: v.cpu().numpy() for k, v in dict(x=dx, o=do, X=X, U=U, u0=u0, cost=cost, status=status, iters=iters, margin=margin, flags=flags, steps=steps).items()}))
+            m.close()
+    a, b = outs
+    for k in ("x", "o", "X", "U", "u0", "cost", "status", "iters", "margin", "flags", "steps"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    assert np.array_equal(a["first"][0], b["first"][0]) and np.array_equal(a["first"][1], b["first"][1])
+    # ... and the first control of the pipelined run against the oracle
+    cfg = orc.config(N, no, 0.1 * N)
+    P = oracle_P(orc, cfg, obst)
+    Xg = np.stack([orc.initial_guess(cfg, x)[0] for x in x0]); Ug = np.zeros((B, N, 2))
+    o = orc.rti_solve_batch(cfg, x0, P, goal, Xg, Ug)
+    assert (o["status"] == b["first"][1]).all()
+    ok = o["status"] == 0
+    assert np.abs(o["u0"][ok] - b["first"][0][ok]).max() < 8e-6
