@@ -145,10 +145,12 @@ def pick_streams(batch):
 class Loop:
     """closed-loop state of one rank's slice on one GPU"""
 
-    def __init__(self, mpc_gpu, torch, N, n_obst, x0, goal, obst, dev, streams=1, **cfg):
+    def __init__(self, mpc_gpu, torch, N, n_obst, x0, goal, obst, dev, streams=1, step_flags=None, **cfg):
         batch = x0.shape[0]
         self.torch = torch
         self.streams = streams
+        from mpc_gpu import _lib as L
+        self.flags = (L.STEP_SHIFT | L.STEP_PLANT | L.STEP_OBSTACLES) if step_flags is None else step_flags
         if streams > 1:
             from mpc_gpu.pipeline import PipelinedMpc
             self.m = PipelinedMpc(N, n_obst, 0.1 * N, max_batch=batch, device=dev.index or 0, streams=streams, **cfg)
@@ -185,10 +187,10 @@ class Loop:
         """one control step of the whole batch = ONE kernel launch per sub-batch stream; cost_out: where the kernels write this step's per-scenario costs"""
         if self.streams > 1:
             self.m.closed_loop_step_dev(self.B, self.x0, self.obst, self.goal, self.X, self.U, self.u0,
-                                        self.cost if cost_out is None else cost_out, self.status, self.iters, None)
+                                        self.cost if cost_out is None else cost_out, self.status, self.iters, None, flags=self.flags)
         else:
             self.m.closed_loop_step_dev(self.B, self.x0, self.obst, self.goal, self.X, self.U, self.u0,
-                                        self.cost if cost_out is None else cost_out, self.status, self.iters, None, stream=self.stream)
+                                        self.cost if cost_out is None else cost_out, self.status, self.iters, None, flags=self.flags, stream=self.stream)
 
 
 class CostExchange:
@@ -610,6 +612,9 @@ def main():
     ap.add_argument("--share", type=int, default=0,
                     help="single-GPU run of ONE rank's share of a K-way sharded workload (rank 0's slice of shard_slice(total, r, K)): the per-GPU work of "
                          "`--gpus K` without the other K - 1 GPUs (profiles/r04_c5_share_*: --workload c5 --share 8)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the cost exchange with a single rank too (RCCL accepts a communicator of one): rehearses on a one-GPU box exactly the code path "
+                         "`--gpus N` takes -- id exchange aside -- including the join of pipelined sub-batch streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the supplementary C3, C5 and C1 measurements")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the multi-rank plumbing (gloo), no kernels")
@@ -662,12 +667,12 @@ def main():
         desc += f" -- rank 0's slice of {args.share} ({G} instances) on this one GPU"
     loop = Loop(mpc_gpu, torch, N, no, x0, goal, obst, dev, streams=args.streams or pick_streams(hi - lo))
     exch, exchange = None, None
-    if world > 1 and (hi - lo) * world == G:
-        exchange = args.exchange
+    if (world > 1 or args.force_exchange) and (hi - lo) * world == G:
+        exchange = args.exchange if world > 1 else "capi"
         if exchange == "capi" and os.environ.get("MPC_BENCH_ONE_GPU") == "1":
             exchange = "torch"                    # RCCL refuses two ranks on one device: the one-GPU rehearsal keeps the gloo transport
         if exchange == "capi":
-            uid = exchange_comm_id(dist, rank, mpc_gpu.BatchedMpc.comm_unique_id)
+            uid = exchange_comm_id(dist, rank, mpc_gpu.BatchedMpc.comm_unique_id) if world > 1 else bytes(mpc_gpu.BatchedMpc.comm_unique_id())
             loop.m.comm_init(rank, world, uid)
             exch = CApiCostExchange(torch, world, hi - lo, dev, loop.m, join=loop.join)
         else:
@@ -736,6 +741,14 @@ def main():
         out["value_qp_tol_1e-8"] = {"value": G * EPISODE * 5 / r8["elapsed"], "unit": "solves/s", "mean_ipm_iters": r8["mean_iters"],
                                     "note": "the C2 workload with qp_tol = 1e-8, the default of rounds 1-2; `value` is at the round-3 default 1e-10 (DESIGN.md section 2)"}
         del l8
+        # ... and C2 with the reference's reaction to a failed QP (status 4 -> set_initial_guess(), robot_ocp_problem.py:203-205, what experiments.py runs with
+        # init_guess_when_error=True): `value` is the plain loop, in which an instance whose QP has become infeasible keeps failing (3 % of the solves)
+        from mpc_gpu import _lib as L
+        lr = Loop(mpc_gpu, torch, N, no, x0, goal, obst, dev, step_flags=L.STEP_SHIFT | L.STEP_PLANT | L.STEP_OBSTACLES | L.STEP_RESET_ON_FAIL | L.STEP_ALIAS_BUG)
+        rr = measure(torch, None, lr, 1, None, 5, 1, dev)
+        out["value_reset_on_fail"] = {"value": G * EPISODE * 5 / rr["elapsed"], "unit": "solves/s", "mean_ipm_iters": rr["mean_iters"], "qp_failure_frac": rr["fail"],
+                                      "note": "the C2 workload with MPC_STEP_RESET_ON_FAIL | MPC_STEP_ALIAS_BUG (the reference's own protocol on a failed QP); every instance still solved 100 times per episode"}
+        del lr
         out["c1"] = c1_latency(mpc_gpu, N, no)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, no, x0, goal, obst)
