@@ -828,3 +828,40 @@ def test_hip_path_against_the_exact_active_set_solution(env, N, no, B):
         verified += 1
         assert np.abs(v_gpu[:2] - v_ex[:2]).max() < 1e-6 and np.abs(v_gpu - v_ex).max() < 1e-5, (b, np.abs(v_gpu - v_ex).max())
     assert verified >= B // 2
+
+
+@pytest.mark.gpu
+def test_qp_fail_policy_truncate_against_the_oracle(env):
+    """mpc_config.qp_fail_policy (docs/PROBLEM.md section 2): instances whose QP is infeasible -- the robot 0.1 from the state box with 6 .. 9.9 m/s towards it:
+    x <= 7 at stage 1 cannot be met with |u| <= 8 -- next to feasible ones.  Policy 0: the divergence tests end them with status 4, iterate untouched.  Policy 1
+    ("truncate", what acados did with a HPIPM MAX_ITER): at a cap of 10 iterations they run to the cap and the truncated step is applied, status 2, GPU and oracle
+    agreeing on the iterate; at the default cap the interior point's step collapses first (status 4 on both sides, after a few iterations more than under
+    policy 0) -- which is why the recorded tables cannot tell the policies apart (profiles/r04_fail_policy_replay.json).  Feasible instances do not notice."""
+    mpc_gpu, orc = env
+    B = 64
+    x0, goal, obst = random_batch(B, 3, seed=77)
+    bad = np.arange(0, B, 4); good = np.setdiff1d(np.arange(B), bad)
+    x0[bad, 0] = 6.9; x0[bad, 2] = 0.0; x0[bad, 3] = np.linspace(6.0, 9.9, len(bad))
+    res = {}
+    for cap in (10, 50):
+        for pol in (0, 1):
+            cfg = orc.config(20, 3, 2.0, qp_fail_policy=pol, qp_iter_max=cap)
+            P = oracle_P(orc, cfg, obst); X, U = oracle_guess(orc, cfg, x0)
+            o = orc.rti_solve_batch(cfg, x0, P, goal, X, U)
+            with mpc_gpu.BatchedMpc(20, 3, 2.0, max_batch=B, qp_fail_policy=pol, qp_iter_max=cap) as s:
+                assert s.cfg.qp_fail_policy == pol
+                s.set_warmstart(X, U); g = s.solve(x0, P, goal); Xg, Ug = s.get_traj(B)
+            res[cap, pol] = (g, Xg, Ug, o)
+            assert (g["status"] == o["status"]).all(), (cap, pol, g["status"], o["status"])
+            assert (np.abs(g["iters"].astype(int) - o["iters"]) <= 1).all() and (g["iters"][good] == o["iters"][good]).all()
+            assert np.abs(Xg[good] - o["X"][good]).max() < 1e-6
+            for b in bad[g["status"][bad] == 4]:
+                assert np.array_equal(Xg[b], X[b]) and np.array_equal(Ug[b], U[b])          # a failed QP leaves the iterate untouched
+    g0, _, _, _ = res[10, 0]; g1, X1, U1, o1 = res[10, 1]
+    assert (g0["status"][bad] == 4).sum() >= len(bad) - 2              # (one of them reaches the cap of 10 before the divergence test fires)
+    assert (g1["status"][bad] == 2).all() and (g1["iters"][bad] == 10).all()
+    assert np.abs(X1[bad] - o1["X"][bad]).max() < 1e-6 and np.abs(X1[bad] - oracle_guess(orc, orc.config(20, 3, 2.0), x0[bad])[0]).max() > 1e-3      # the truncated step IS applied
+    assert (res[50, 0][0]["status"][bad] == 4).all() and (res[50, 1][0]["status"][bad] == 4).all()
+    assert (res[50, 1][0]["iters"][bad] >= res[50, 0][0]["iters"][bad]).all()      # without the divergence test the failure is noticed later (step collapse)
+    for cap in (10, 50):           # feasible instances: bit for bit the same under both policies
+        assert np.array_equal(res[cap, 0][1][good], res[cap, 1][1][good]) and np.array_equal(res[cap, 0][0]["status"][good], res[cap, 1][0]["status"][good])
