@@ -1,5 +1,7 @@
-"""CPU-only scan: distance of the oracle's interior point from the exact QP solution (helpers.exact_qp, cached) under variations of the
-interior-point constants (environment overrides of the prototype build).  usage: tail_scan_cpu.py N n_obst B"""
+"""CPU-only: distance of the oracle's interior point from the EXACT QP solution (helpers.exact_qp; cached in /tmp) on B random first solves.
+Round 4 ran it on prototype builds of the oracle with the floor of t / lam (1e-13 ... 1e-9), the fraction to the boundary, a dual-residual gate and a
+no-termination-after-a-jump gate switched through the environment (only the floor mattered; the shipped oracle has it at min(1e-11, qp_tol / 10)
+and none of the switches).  usage: tail_scan_cpu.py N n_obst B"""
 import sys, os, json, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "dynamic-obstacle-avoidance-mpc_amd"), os.path.join(ROOT, "tests")]
