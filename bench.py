@@ -666,14 +666,30 @@ def main():
         G = hi - lo
         desc += f" -- rank 0's slice of {args.share} ({G} instances) on this one GPU"
     loop = Loop(mpc_gpu, torch, N, no, x0, goal, obst, dev, streams=args.streams or pick_streams(hi - lo))
-    exch, exchange = None, None
+    exch, exchange, exchange_note = None, None, None
     if (world > 1 or args.force_exchange) and (hi - lo) * world == G:
         exchange = args.exchange if world > 1 else "capi"
         if exchange == "capi" and os.environ.get("MPC_BENCH_ONE_GPU") == "1":
             exchange = "torch"                    # RCCL refuses two ranks on one device: the one-GPU rehearsal keeps the gloo transport
+        exchange_note = None
         if exchange == "capi":
-            uid = exchange_comm_id(dist, rank, mpc_gpu.BatchedMpc.comm_unique_id) if world > 1 else bytes(mpc_gpu.BatchedMpc.comm_unique_id())
-            loop.m.comm_init(rank, world, uid)
+            # the library's own collective; if its set-up fails on ANY rank (reported, never silent) every rank takes the torch.distributed exchange instead, so
+            # that a multi-GPU measurement is not lost to the one piece of this path no single-GPU box can rehearse with more than one rank
+            ok, err = 1.0, ""
+            try:
+                uid = exchange_comm_id(dist, rank, mpc_gpu.BatchedMpc.comm_unique_id) if world > 1 else bytes(mpc_gpu.BatchedMpc.comm_unique_id())
+                loop.m.comm_init(rank, world, uid)
+            except Exception as e:      # noqa: BLE001 -- whatever went wrong is reported in the JSON line
+                ok, err = 0.0, f"{type(e).__name__}: {e}"[:200]
+            if world > 1:
+                flag = torch.tensor([ok], dtype=torch.float64, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = float(flag.item())
+            if ok < 1.0:
+                exchange, exchange_note = "torch", f"capi set-up failed on a rank ({err or 'another rank'}): fell back to torch.distributed"
+                if world == 1:
+                    raise RuntimeError(exchange_note)
+        if exchange == "capi":
             exch = CApiCostExchange(torch, world, hi - lo, dev, loop.m, join=loop.join)
         else:
             exch = CostExchange(torch, world, hi - lo, dev, gather_costs, join=loop.join)
@@ -697,7 +713,7 @@ def main():
                                        if args.workload == "c2" else None,
                       "parallelism": (f"batch slices over {world} ranks (mpc_gpu.sharding.shard_slice), no data-path collective; per-scenario costs "
                                       f"all-gathered over RCCL, {GATHER_EVERY} control steps per message") if world > 1 else "single GPU"},
-           "exchange": exchange, "rccl_ranks": loop.m.comm_world() if exchange == "capi" else None, "gather_check": gather_ok,
+           "exchange": exchange, "exchange_note": exchange_note, "rccl_ranks": loop.m.comm_world() if exchange == "capi" else None, "gather_check": gather_ok,
            "streams_per_gpu": loop.streams,
            "ms_per_control_step": r["elapsed"] / (args.steps * EPISODE) * 1e3,
            "mean_ipm_iters": r["mean_iters"], "qp_failure_frac": r["fail"], "qp_iter_cap_frac": r["cap"],
