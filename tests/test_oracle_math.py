@@ -238,3 +238,58 @@ def test_exact_active_set_solution_for_the_workload_sizes(orc, N, no, steps):
             verified += 1
             assert np.abs(v_ip[:2] - v_ex[:2]).max() < 1e-6 and np.abs(v_ip - v_ex).max() < 1e-5, (b, k, np.abs(v_ip - v_ex).max())
     assert verified >= steps
+
+
+@pytest.mark.parametrize("N,no,B,soft", [(20, 3, 60, 1), (10, 5, 40, 1), (20, 3, 30, 0)])
+def test_exact_qp_verifies_and_the_interior_point_is_within_the_tolerance_of_it(orc, N, no, B, soft):
+    """The adjudicator of the parity tests (helpers.exact_qp: an active-set iteration on the exported QP) is itself checked here: (i) what it returns satisfies the
+    KKT conditions of the FULL QP, verified independently below (stationarity with non-negative multipliers of the active rows, feasibility of all rows) -- soft and
+    hard obstacle rows; (ii) the oracle's interior point at qp_tol 1e-10 is within 1e-5 of it on every instance and within 1e-7 on 90 % (measured over 3000 instances
+    with the floor at 1e-11: worst 3.5e-6; with the floor of rounds 1-3, 1e-13: 1.6e-5 here and 7.3e-4 at N = 50 -- scripts/tail_scan_cpu.py)."""
+    from helpers import exact_qp, step_vector
+    x0, goal, obst = random_batch(B, no, seed=600 + N + no)
+    cfg = orc.config(N, no, 0.1 * N, soft_h=soft)
+    P = oracle_P(orc, cfg, obst); X, U = oracle_guess(orc, cfg, x0)
+    r = orc.rti_solve_batch(cfg, x0, P, goal, X, U)
+    d, n_ver = [], 0
+    for b in np.nonzero(r["status"] == 0)[0]:
+        q = orc.export_qp(cfg, x0[b], P[b], goal[b], X[b], U[b])
+        v_ip = step_vector(N, X[b], U[b], r["X"][b], r["U"][b])
+        v, ok, info = exact_qp(q, v_ip)
+        if not ok:
+            continue
+        n_ver += 1
+        # independent KKT check of v on the full QP: slacks in closed form, multipliers by least squares on the active rows
+        nv = len(v)
+        soft_rows = np.isfinite(q["zs"]) if len(q["hs"]) else np.zeros(0, bool)
+        rho = q["hs"] + q["Cs"] @ v if len(q["hs"]) else np.zeros(0)
+        assert np.abs(q["Aeq"] @ v - q["beq"]).max() < 1e-8 and (v >= q["lb"] - 1e-8).all() and (v <= q["ub"] + 1e-8).all()
+        if (~soft_rows).any():
+            assert rho[~soft_rows].min() > -1e-8                        # hard rows hold
+        # slack of a soft row given v: minimiser of z s + Z s^2 / 2 subject to s >= max(0, -rho)  ->  s = max(0, -rho) (z, Z > 0); its multiplier of rho + s >= 0 is z + Z s where
+        # that row is active, 0 else: gradient of the penalty with respect to v is  -Cs' lam
+        s = np.maximum(0.0, -rho) * soft_rows
+        lam_soft = np.where(soft_rows & (rho < 1e-9), np.where(soft_rows, q["zs"], 0.0) + np.where(soft_rows, q["Zs"], 0.0) * s, 0.0)
+        # rows with rho within 1e-9 of 0 may carry any multiplier in [0, z]: they and the active bounds / hard rows / equalities enter a least-squares fit of the stationarity equation
+        g = q["H"] @ v + q["g"]
+        cols = [q["Aeq"].T]
+        free_soft = np.nonzero(soft_rows & (np.abs(rho) < 1e-9))[0]
+        fixed = lam_soft.copy(); fixed[free_soft] = 0.0
+        g = g - q["Cs"].T @ fixed if len(q["hs"]) else g
+        act_lb, act_ub = np.nonzero(v - q["lb"] < 1e-9)[0], np.nonzero(q["ub"] - v < 1e-9)[0]
+        act_hard = np.nonzero(~soft_rows & (rho < 1e-9))[0] if len(q["hs"]) else np.zeros(0, int)
+        E = np.zeros((nv, len(act_lb) + len(act_ub) + len(act_hard) + len(free_soft)))
+        for k, i in enumerate(act_lb): E[i, k] = 1.0
+        for k, i in enumerate(act_ub): E[i, len(act_lb) + k] = -1.0
+        for k, j in enumerate(act_hard): E[:, len(act_lb) + len(act_ub) + k] = q["Cs"][j]
+        for k, j in enumerate(free_soft): E[:, len(act_lb) + len(act_ub) + len(act_hard) + k] = q["Cs"][j]
+        M = np.hstack([q["Aeq"].T, E])                                  # g = Aeq' nu + E mult  with mult >= 0: a certificate exists iff the bounded least squares reaches 0
+        from scipy.optimize import lsq_linear
+        me = q["Aeq"].shape[0]
+        scale = max(1.0, np.abs(g).max())
+        fit = lsq_linear(M, g / scale, bounds=(np.r_[np.full(me, -np.inf), np.zeros(E.shape[1])], np.full(M.shape[1], np.inf)), tol=1e-14, max_iter=2000)
+        assert np.abs(M @ fit.x - g / scale).max() < 1e-6, (b, np.abs(M @ fit.x - g / scale).max())
+        d.append(np.abs(v - v_ip).max())
+    assert n_ver >= 0.9 * (r["status"] == 0).sum() and n_ver >= 0.5 * B          # (with hard rows a third of these random QPs is infeasible: status 4)
+    d = np.array(d)
+    assert d.max() < 1e-5 and np.quantile(d, 0.9) < 1e-7, (d.max(), np.quantile(d, 0.9))
