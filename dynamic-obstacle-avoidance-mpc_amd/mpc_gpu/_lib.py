@@ -133,7 +133,7 @@ def audit(listing):
     return True
 
 
-def build(force=False, verbose=False, audit=True):
+def build(force=False, verbose=False, run_audit=True):
     """Compile csrc/*.hip for gfx950 into libmpcgpu.so (in-tree).  hipcc cross-compiles without a GPU.
     ONE compile (-save-temps, in a private directory): the device listing that is audited (kept as build/mpc_api-gfx950.s) is the assembler input of
     the code object that ships, not the output of a second compiler run.  A build that fails the audit is deleted and the call raises -- a library
@@ -150,7 +150,7 @@ def build(force=False, verbose=False, audit=True):
         hipcc = "hipcc"
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value"] + os.environ.get("MPC_EXTRA_HIPCC_FLAGS", "").split()
     src = os.path.join(CSRC, "mpc_api.hip")
-    do_audit = audit and not os.environ.get("MPC_SKIP_ISA_AUDIT")
+    do_audit = run_audit and not os.environ.get("MPC_SKIP_ISA_AUDIT")
     os.makedirs(os.path.dirname(ISA_PATH), exist_ok=True)
     work = tempfile.mkdtemp(prefix=f"tmp.{os.getpid()}.", dir=os.path.dirname(ISA_PATH))
     new = f"{LIB_PATH}.{os.getpid()}.new"
