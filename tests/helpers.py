@@ -51,9 +51,9 @@ def qp_merit(orc, cfg, x0, P, goal, X, U, Xn, Un):
 # A converged instance whose GPU and oracle iterates differ by more than 1e-6 is settled against the EXACT solution of the QP both sides solved
 # (exact_qp: active-set iteration on the exported QP, KKT conditions verified -- it owes neither interior point anything):
 #   * the GPU's distance from the exact solution is below EXACT_CAP outright, whatever the oracle did.  Measured (profiles/r04_parity_sweep.json, 8.8e5 solves
-#     of 15 configurations): 15 instances beyond 1e-6, the worst GPU distance from exact 4.2e-5, the worst oracle distance 1.3e-5 -- both sides stop an
+#     of 15 configurations): 14 instances beyond 1e-6, the worst GPU distance from exact 4.2e-5, the worst oracle distance 1.3e-5 -- both sides stop an
 #     interior point at the same complementarity tolerance, and what that leaves on a QP with a nearly inactive row (multiplier ~1e-4) is a distance
-#     ~ qp_tol / multiplier x conditioning on EITHER side; which side holds the larger share is rounding (GPU farther in 12 of 15, by 1.8x .. 100x), so a
+#     ~ qp_tol / multiplier x conditioning on EITHER side; which side holds the larger share is rounding (GPU farther in 10 of 14, by 1.8x .. 100x), so a
 #     per-instance "no farther than the oracle" clause would be a coin flip -- the ratio is reported (adjudicate()["ratio"]) and bounded per population
 #     in the sweep, the per-instance assertion is the absolute cap;
 #   * and the NUMBER of instances that need the adjudication at all is bounded per batch (allowed_adjudications): at most 0.1 % at the workloads' sizes.
