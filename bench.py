@@ -345,7 +345,6 @@ def cpu_baseline(N, n_obst, x0, goal, obst, budget_s=24.0):
     orc.use_bench_build()
     cfg = orc.config(N, n_obst, 0.1 * N)      # the library's defaults (qp_tol 1e-10)
     ncpu, quota = cpu_budget()
-    cores_avail = max(1, min(ncpu, int(np.ceil(quota)))) if quota else ncpu      # threads that can actually run at once
     dt = 0.1
 
     def closed_loop_rate(S, nthreads, budget, warm=5):
@@ -372,12 +371,17 @@ def cpu_baseline(N, n_obst, x0, goal, obst, budget_s=24.0):
                 return solves / secs, steps - warm
 
     S_all = min(len(x0), max(64, 8 * ncpu))
-    rates = {}
-    # as many OpenMP threads as cores are available to this process (the cgroup quota when there is one), and twice / half that for the neighbourhood
-    for n in sorted({cores_avail, min(ncpu, 2 * cores_avail), max(1, cores_avail // 2)}, reverse=True):
-        rates[n] = closed_loop_rate(S_all, n, budget_s / 6)
+    # doubling sweep over the OpenMP thread count, 8, 16, 32 ... up to the hardware threads this process may run on, ~2 s each; it stops at the plateau
+    # (a doubling that gains < 5 %).  `value` is the plateau -- not a quota heuristic: on the driver's box (2 x EPYC 9575F, 256 threads) the rate
+    # was still linear at 32 threads although the cgroup quota reads ~16 cores
+    rates, n, prev = {}, min(8, ncpu), 0.0
+    while True:
+        rates[n] = closed_loop_rate(S_all, n, budget_s / 12)
+        if n >= ncpu or rates[n][0] < 1.05 * prev:
+            break
+        prev, n = rates[n][0], min(ncpu, 2 * n)
     best = max(rates, key=lambda n: rates[n][0])
-    one, one_steps = closed_loop_rate(min(len(x0), 16), 1, budget_s / 4)
+    one, one_steps = closed_loop_rate(min(len(x0), 16), 1, budget_s / 6)
     # reference call pattern: ONE scenario, the reference's per-step solver calls (ShimLoop) on oracle-backed objects, wall time of
     # everything in the loop (that is the point: the reference's step is Python overhead around the solve)
     from mpc_gpu.closed_loop import EpisodeState, ShimLoop
@@ -391,18 +395,18 @@ def cpu_baseline(N, n_obst, x0, goal, obst, budget_s=24.0):
         loop.control_step(st); loop.shift_warm_start(); n_py += 1
     py_rate = n_py / (time.perf_counter() - t0)
     return {"value": rates[best][0], "unit": "solves/s", "cores": best, "kind": "port", "host_cpu": orc._cpu_model(), "host_threads": ncpu,
-            "cpu_quota_cores": quota, "cores_available": cores_avail,
+            "cpu_quota_cores": quota,
             "one_thread": one, "per_core": rates[best][0] / best, "scaling_efficiency": rates[best][0] / (best * one),
             "python_call_pattern_one_thread": py_rate,
-            "threads": {str(n): r[0] for n, r in rates.items()},
-            "sample": f"first {S_all} scenarios x {rates[best][1]} closed-loop control steps (after 5 untimed) of the same workload, oracle "
-                      f"(C, f64, -O3 -march=native, OpenMP over instances), solve calls only; one_thread: 16 scenarios x {one_steps} steps; "
-                      f"python_call_pattern: 1 scenario x {n_py} control steps through the reference's ~{8 * N + 12} solver calls per step "
-                      "(whole loop timed); acados itself cannot run here, so this is a restatement, not the reference's solver",
+            "threads": {str(n): float(f"{r[0]:.4g}") for n, r in rates.items()},
+            "sample": f"{S_all} scenarios x {rates[best][1]} closed-loop steps, C oracle -O3 OpenMP, solve calls only; thread sweep to plateau",
+            "sample_detail": f"first {S_all} scenarios x {rates[best][1]} closed-loop control steps (after 5 untimed) of the same workload, oracle "
+                             f"(C, f64, -O3 -march=native, OpenMP over instances), solve calls only; one_thread: 16 scenarios x {one_steps} steps; "
+                             f"python_call_pattern: 1 scenario x {n_py} control steps through the reference's ~{8 * N + 12} solver calls per step "
+                             "(whole loop timed); acados itself cannot run here, so this is a restatement, not the reference's solver",
             "note": "a reported baseline, not a target: the oracle is a dense, generic checker (no structure exploitation; per-thread workspace since round 4). "
-                    "`cores` = the OpenMP thread count of `value`, chosen around the number of cores this process may actually use (cpu_quota_cores: the cgroup "
-                    "quota of the lease, ~16 on a one-GPU box with 256 hardware threads; threads beyond it only time-slice); scaling_efficiency = value / "
-                    "(cores x one_thread)"}
+                    "`cores` = the OpenMP thread count of `value`: the best of a doubling sweep (`threads`: the curve) that stops when a doubling gains < 5 %; "
+                    "cpu_quota_cores is what the cgroup reports and is informational only; scaling_efficiency = value / (cores x one_thread)"}
 
 
 # ------------------------------------------------------------------------------------------------------------------ measurement
@@ -526,6 +530,64 @@ def c1_latency(mpc_gpu, N, no):
             "ms_per_solve_median": float(np.median(ts)) * 1e3, "solves_per_s": 1.0 / float(np.median(ts)), "control_steps": len(ts)}
 
 
+# ------------------------------------------------------------------------------------------------------------------ the output line
+
+LINE_LIMIT = 4096            # the driver keeps only the tail of stdout: a line beyond a few KB is cut and cannot be parsed (BENCH_r04: 20.7 KB -> parsed null)
+FULL_RECORD = os.path.join(ROOT, "profiles", "bench_last.json")
+
+
+def _num(v, digits=5):
+    """numbers of the line with a few significant digits (the full record keeps every bit)"""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        return float(f"{v:.{digits}g}")
+    return v
+
+
+def compact_line(out):
+    """The ONE JSON line of the contract, numbers only.  Every prose note, source, model description and nested detail of `out` stays in the full
+    record (FULL_RECORD, also gpurun_out/ when that directory exists), never on stdout."""
+    def pick(d, keys):
+        return {k: _num(d[k]) for k in keys if d is not None and k in d and d[k] is not None}
+    cfg = out["config"]
+    line = pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling"))
+    line["vs_baseline"] = None
+    line.update(pick(out, ("dtype", "data")))
+    line["config"] = pick(cfg, ("workload", "global_batch", "per_gpu_batch", "N", "n_obst", "qp_tol", "control_steps_per_step", "parallelism"))
+    line.update(pick(out, ("mean_ipm_iters", "qp_failure_frac", "streams_per_gpu", "exchange", "rccl_ranks", "gather_check", "rccl_path", "torch_pg")))
+    line["roofline"] = pick(out["roofline"], ("bound", "achieved", "peak", "unit", "frac", "issue", "latency_frac", "lanes_active", "lanes_exec", "traffic", "kernel", "avg_launch_us"))
+    for key, name in (("extra", "c3"), ("extra_c5", "c5"), ("extra_c4_share", "c4_share"), ("extra_c5_share", "c5_share")):
+        e = out.get(key)
+        if e:
+            line[name] = {**pick(e, ("value", "value_one_stream", "mean_ipm_iters")), **pick(e["roofline"], ("frac", "issue", "latency_frac"))}
+    for key in ("value_reset_on_fail", "value_qp_tol_1e-8"):
+        if key in out:
+            line[key] = _num(out[key]["value"])
+    if "c1" in out:
+        line["c1_ms_per_solve"] = _num(out["c1"]["ms_per_solve_median"])
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "one_thread", "python_call_pattern_one_thread", "host_cpu",
+                                                          "host_threads", "threads", "sample"))
+    line["full_record"] = os.path.relpath(FULL_RECORD, ROOT)
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, f"bench line is {len(text)} bytes: the driver cannot parse more than {LINE_LIMIT}"
+    return text
+
+
+def emit(out):
+    """full record to the files, compact line to stdout (the LAST line of stdout)"""
+    for path in (FULL_RECORD, os.path.join(ROOT, "gpurun_out", "bench_last.json")):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as f:
+                    json.dump(out, f, indent=1)
+        except OSError as e:
+            sys.stderr.write(f"bench.py: could not write {path}: {e}\n")
+    sys.stdout.flush()
+    print(compact_line(out), flush=True)
+
+
 # ------------------------------------------------------------------------------------------------------------------ entry points
 
 def spawn_ranks(args, argv):
@@ -615,6 +677,11 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the cost exchange with a single rank too (RCCL accepts a communicator of one): rehearses on a one-GPU box exactly the code path "
                          "`--gpus N` takes -- id exchange aside -- including the join of pipelined sub-batch streams")
+    ap.add_argument("--with-torch-pg", action="store_true",
+                    help="one rank only: initialise a torch.distributed NCCL process group of world size 1 first (and run an all_reduce on it before the library's "
+                         "communicator exists and another after its all-gathers) -- with --force-exchange the exact process state of a rank of `--gpus N`")
+    ap.add_argument("--allow-exchange-fallback", action="store_true",
+                    help="if the C-ABI exchange cannot be set up on every rank, run the torch.distributed exchange instead of exiting non-zero")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the supplementary C3, C5 and C1 measurements")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the multi-rank plumbing (gloo), no kernels")
@@ -646,6 +713,20 @@ def main():
     else:
         dev_index = 0
         torch.cuda.set_device(0)
+        if args.with_torch_pg:
+            # the process state of a rank of `--gpus N`, on one GPU: a torch.distributed NCCL (= RCCL) process group of one rank, its communicator created
+            # (first collective) BEFORE the library binds librccl and makes its own -- two communicators, one process, one librccl mapping (rccl_path)
+            import socket
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+            probe = torch.ones(4, dtype=torch.float64, device="cuda:0")
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            assert float(probe.sum().item()) == 4.0
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))   # one explicit queue for torch ops AND the library's kernels
 
@@ -666,34 +747,61 @@ def main():
         G = hi - lo
         desc += f" -- rank 0's slice of {args.share} ({G} instances) on this one GPU"
     loop = Loop(mpc_gpu, torch, N, no, x0, goal, obst, dev, streams=args.streams or pick_streams(hi - lo))
-    exch, exchange, exchange_note = None, None, None
+    exch, exchange, exchange_note, rccl_path = None, None, None, None
     if (world > 1 or args.force_exchange) and (hi - lo) * world == G:
         exchange = args.exchange if world > 1 else "capi"
         if exchange == "capi" and os.environ.get("MPC_BENCH_ONE_GPU") == "1":
             exchange = "torch"                    # RCCL refuses two ranks on one device: the one-GPU rehearsal keeps the gloo transport
-        exchange_note = None
         if exchange == "capi":
-            # the library's own collective; if its set-up fails on ANY rank (reported, never silent) every rank takes the torch.distributed exchange instead, so
-            # that a multi-GPU measurement is not lost to the one piece of this path no single-GPU box can rehearse with more than one rank
+            # The library's own collective.  ncclCommInitRank is a rendezvous that blocks until ALL ranks have joined, so the ranks agree BEFORE it: every rank
+            # probes the library locally (mpc_comm_unique_id: dlopen + dlsym + one RCCL call, no rendezvous), the flags are MIN-reduced over the launcher's
+            # process group, and mpc_comm_init is entered only when every rank can.  A rank that cannot makes the whole job exit non-zero -- a SCALE record
+            # must not silently measure another collective -- unless --allow-exchange-fallback asks for the torch.distributed exchange instead.
+            def agree(ok, err):
+                if dist is not None:
+                    flag = torch.tensor([ok], dtype=torch.float64, device=dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    return float(flag.item()), err
+                return ok, err
             ok, err = 1.0, ""
             try:
-                uid = exchange_comm_id(dist, rank, mpc_gpu.BatchedMpc.comm_unique_id) if world > 1 else bytes(mpc_gpu.BatchedMpc.comm_unique_id())
-                loop.m.comm_init(rank, world, uid)
-            except Exception as e:      # noqa: BLE001 -- whatever went wrong is reported in the JSON line
+                mpc_gpu.BatchedMpc.comm_unique_id()
+                rccl_path = mpc_gpu.BatchedMpc.comm_library_path()
+            except Exception as e:      # noqa: BLE001 -- reported below
                 ok, err = 0.0, f"{type(e).__name__}: {e}"[:200]
-            if world > 1:
-                flag = torch.tensor([ok], dtype=torch.float64, device=dev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                ok = float(flag.item())
+            ok, err = agree(ok, err)
+            if ok == 1.0:
+                try:
+                    uid = exchange_comm_id(dist, rank, mpc_gpu.BatchedMpc.comm_unique_id) if world > 1 else bytes(mpc_gpu.BatchedMpc.comm_unique_id())
+                    loop.m.comm_init(rank, world, uid)
+                except Exception as e:      # noqa: BLE001
+                    ok, err = 0.0, f"{type(e).__name__}: {e}"[:200]
+                ok, err = agree(ok, err)
             if ok < 1.0:
-                exchange, exchange_note = "torch", f"capi set-up failed on a rank ({err or 'another rank'}): fell back to torch.distributed"
-                if world == 1:
-                    raise RuntimeError(exchange_note)
+                exchange_note = f"capi set-up failed on a rank ({err or 'another rank'})"
+                try:
+                    loop.m.comm_destroy()       # a rank whose mpc_comm_init succeeded keeps no live communicator
+                except Exception:               # noqa: BLE001
+                    pass
+                if world == 1 or not args.allow_exchange_fallback:
+                    sys.stderr.write(f"bench.py: {exchange_note}; --allow-exchange-fallback would run the torch.distributed exchange instead\n")
+                    if dist is not None:
+                        dist.destroy_process_group()
+                    sys.exit(3)
+                exchange, exchange_note = "torch", exchange_note + ": fell back to torch.distributed (--allow-exchange-fallback)"
         if exchange == "capi":
             exch = CApiCostExchange(torch, world, hi - lo, dev, loop.m, join=loop.join)
         else:
             exch = CostExchange(torch, world, hi - lo, dev, gather_costs, join=loop.join)
     r = measure(torch, dist, loop, world, exch, args.steps, args.warmup, dev)
+    torch_pg = None
+    if dist is not None:
+        # the launcher's (or --with-torch-pg's) process group still works after the library's communicator has run beside it
+        probe = torch.full((4,), float(rank + 1), dtype=torch.float64, device=dev)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        torch_pg = {"backend": dist.get_backend(), "world": dist.get_world_size(), "all_reduce_after_exchange_ok": bool(float(probe[0].item()) == world * (world + 1) / 2)}
+    rccl_maps = sorted({l.split()[-1] for l in open("/proc/self/maps") if "rccl" in l and "/" in l})
     gather_ok = None
     if exch is not None:         # the last completed message: every rank's row of the final control step must be that rank's own costs (rank 0 checks its own)
         got = exch.gathered()
@@ -714,6 +822,7 @@ def main():
                       "parallelism": (f"batch slices over {world} ranks (mpc_gpu.sharding.shard_slice), no data-path collective; per-scenario costs "
                                       f"all-gathered over RCCL, {GATHER_EVERY} control steps per message") if world > 1 else "single GPU"},
            "exchange": exchange, "exchange_note": exchange_note, "rccl_ranks": loop.m.comm_world() if exchange == "capi" else None, "gather_check": gather_ok,
+           "rccl_path": rccl_path, "rccl_mapped": rccl_maps, "torch_pg": torch_pg,
            "streams_per_gpu": loop.streams,
            "ms_per_control_step": r["elapsed"] / (args.steps * EPISODE) * 1e3,
            "mean_ipm_iters": r["mean_iters"], "qp_failure_frac": r["fail"], "qp_iter_cap_frac": r["cap"],
@@ -769,8 +878,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, no, x0, goal, obst)
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        emit(out)
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -409,6 +409,8 @@ extern "C" {
 
 const char *mpc_last_error(void) { return g_err; }
 
+int mpc_abi_version(void) { return MPC_ABI_VERSION; }
+
 int mpc_device_count(void)
 {
     int n = 0;
@@ -893,6 +895,16 @@ int mpc_comm_init(mpc_handle *h, int rank, int world, const unsigned char *id)
 }
 
 int mpc_comm_world(const mpc_handle *h) { return h && h->comm ? h->comm_world : 0; }
+
+int mpc_comm_library_path(char *buf, int len)
+{
+    if (!buf || len < 2) return fail(MPC_ERR_ARG, "bad buffer");
+    int rc = rccl_load(); if (rc) return rc;
+    Dl_info info;
+    if (!dladdr((void *)g_rccl.AllGather, &info) || !info.dli_fname) return fail(MPC_ERR_HIP, "dladdr cannot name the library of ncclAllGather");
+    snprintf(buf, (size_t)len, "%s", info.dli_fname);
+    return MPC_OK;
+}
 
 int mpc_comm_destroy(mpc_handle *h)
 {

@@ -19,6 +19,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 MPC_OK, MPC_ERR_ARG, MPC_ERR_HIP, MPC_ERR_NODEVICE = 0, -1, -2, -3
 STEP_SHIFT, STEP_PLANT, STEP_OBSTACLES, STEP_RESET_ON_FAIL, STEP_ALIAS_BUG, STEP_METRICS, STEP_INTERP_GUESS = 1, 2, 4, 8, 16, 32, 64
 COMM_ID_BYTES = 128      # MPC_COMM_ID_BYTES (RCCL unique id)
+ABI_VERSION = 6          # MPC_ABI_VERSION of include/mpc_gpu.h this mirror (MpcConfig, SYMBOLS) was written against
 
 _d = C.c_double
 _i32 = C.c_int32
@@ -44,6 +45,7 @@ class MpcConfig(C.Structure):
 _vp = C.c_void_p
 _cfgp = C.POINTER(MpcConfig)
 SYMBOLS = {
+    "mpc_abi_version": (C.c_int, []),
     "mpc_last_error": (C.c_char_p, []),
     "mpc_device_count": (C.c_int, []),
     "mpc_default_config": (C.c_int, [_cfgp, C.c_int, C.c_int, _d]),
@@ -92,6 +94,7 @@ SYMBOLS = {
     "mpc_comm_unique_id": (C.c_int, [_vp]),
     "mpc_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "mpc_comm_world": (C.c_int, [_vp]),
+    "mpc_comm_library_path": (C.c_int, [C.c_char_p, C.c_int]),
     "mpc_allgather_cost_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "mpc_allgather_cost": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "mpc_comm_destroy": (C.c_int, [_vp]),
@@ -196,6 +199,8 @@ def lib():
             fn = getattr(L, name)      # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
+        if L.mpc_abi_version() != ABI_VERSION:      # a stale .so behind a newer struct mirror would be written past the end of MpcConfig
+            raise MpcError(f"{LIB_PATH} has ABI version {L.mpc_abi_version()}, this binding expects {ABI_VERSION}: rebuild (mpc_gpu.build(force=True))")
         _LIB = L
     return _LIB
 

@@ -34,7 +34,11 @@ class PipelinedMpc:
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
-        for _, _, m, _ in self.parts:
+        """Waits for every sub-batch stream before the handles go: mpc_destroy synchronises only the handle's OWN stream, and the launches were enqueued on
+        these torch streams -- a close under in-flight kernels would free the handle's device buffers (instance order, iteration schedule) beneath them.
+        The caller's whole-batch tensors must outlive join() (they are used on the sub-batch streams; no record_stream is taken on the slices)."""
+        for _, _, m, s in self.parts:
+            s.synchronize()
             m.close()
 
     def __enter__(self):
@@ -94,6 +98,9 @@ class PipelinedMpc:
 
     def comm_destroy(self):
         self.parts[0][2].comm_destroy()
+
+    def comm_library_path(self):
+        return self.parts[0][2].comm_library_path()
 
     def allgather_cost_dev(self, count, cost, cost_all, stream=None):
         """whole-batch costs (the caller joins the sub-batch streams first: join())"""

@@ -202,6 +202,13 @@ class BatchedMpc:
     def comm_destroy(self):
         _lib.check(_lib.lib().mpc_comm_destroy(self._h))
 
+    @staticmethod
+    def comm_library_path():
+        """file name of the RCCL library the exchange is bound to (mpc_comm_library_path)"""
+        buf = C.create_string_buffer(1024)
+        _lib.check(_lib.lib().mpc_comm_library_path(buf, len(buf)))
+        return buf.value.decode()
+
     def allgather_cost_dev(self, count, cost, cost_all, stream=None):
         """collective: cost (count,) of every rank -> cost_all (world, count), rank-major; device arrays, enqueued on `stream`"""
         _lib.check(_lib.lib().mpc_allgather_cost_dev(self._h, int(count), _ptr(cost), _ptr(cost_all), _ptr(stream)))

@@ -39,6 +39,12 @@ extern "C" {
 #define MPC_NX 5
 #define MPC_NU 2
 
+/* Version of this header's binary interface: bumped whenever `struct mpc_config` changes size or layout or an entry point changes its signature
+ * (4 -> 5 in round 4: trailing field qp_fail_policy, +8 bytes).  A host compares it with mpc_abi_version() of the library it loaded BEFORE it calls
+ * mpc_default_config / mpc_create: a host built against an older struct would otherwise be written past its end.  (No reference counterpart: acados
+ * regenerates and recompiles its C interface per problem.) */
+#define MPC_ABI_VERSION 6
+
 /* Problem definition.  Defaults (mpc_default_config) are the reference's constants. */
 typedef struct mpc_config {
     int32_t N;              /* N_SOLV                     src/models/world_specification.py:44   */
@@ -75,6 +81,9 @@ typedef struct mpc_config {
 } mpc_config;
 
 typedef struct mpc_handle mpc_handle;
+
+/* MPC_ABI_VERSION the library was built with */
+int mpc_abi_version(void);
 
 /* thread-local description of the last error returned on this thread */
 const char *mpc_last_error(void);
@@ -181,6 +190,9 @@ int mpc_noise_draw_dev(mpc_handle *h, int count, uint32_t *d_state, double *d_no
 int mpc_comm_unique_id(unsigned char *id /* MPC_COMM_ID_BYTES */);
 int mpc_comm_init(mpc_handle *h, int rank, int world, const unsigned char *id /* MPC_COMM_ID_BYTES */);
 int mpc_comm_world(const mpc_handle *h);      /* ranks of the handle's communicator, 0 without one */
+/* file name of the RCCL library the exchange is bound to (dladdr of its ncclAllGather): a process that has PyTorch's ROCm wheel loaded gets the wheel's
+ * bundled librccl (same soname, already mapped), any other host /opt/rocm's -- measurement records name which one ran */
+int mpc_comm_library_path(char *buf, int len);
 int mpc_allgather_cost_dev(mpc_handle *h, int count, const double *d_cost, double *d_cost_all, void *stream);
 int mpc_allgather_cost(mpc_handle *h, int count, const double *cost, double *cost_all);
 int mpc_comm_destroy(mpc_handle *h);

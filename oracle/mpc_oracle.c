@@ -89,6 +89,7 @@ void orc_default_config(orc_config *c, int N, int n_obst, double Tf)
      * within 25 iterations then needs more than 25 here (profiles/r04_thr0_probe.txt): the reference's own problem size keeps the constant its pin was made with. */
     c->thr0 = n_obst >= 8 ? 0.3 : 0.1;
     c->qp_fail_policy = 0;
+    c->polish_tol = 0.0;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -683,6 +684,7 @@ static void residuals(const qp_t *Q, iter_t *I, double (*rg)[NZ], double *rs, do
 #define MU_DIVERGED 1e8
 #define MU_CAP_FAILED 1e4
 #define MU_CAP_SETTLED 20
+#define POLISH_MAX 2
 #define FRAC_TO_BOUNDARY 0.999995   /* step = this fraction of the largest step that keeps t, lam > 0 */
 static double *g_trace = NULL; static int g_trace_cap = 0;
 void orc_set_trace(double *buf, int cap) { g_trace = buf; g_trace_cap = cap; }
@@ -705,7 +707,7 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
     R.P = WS_ALLOC(sizeof(double[25]) * (N + 1)); R.p = WS_ALLOC(sizeof(double[NX]) * (N + 1));
     R.K = WS_ALLOC(sizeof(double[10]) * N); R.k = WS_ALLOC(sizeof(double[NU]) * N); R.L = WS_ALLOC(sizeof(double[4]) * N); R.Mxu = WS_ALLOC(sizeof(double[10]) * N);
     double re0[5], res[4];
-    int status = 2, it = 0;
+    int status = 2, it = 0, npolish = 0;
     TL_MIN = TL_MIN_MAX < 0.1 * c->qp_tol ? TL_MIN_MAX : 0.1 * c->qp_tol;
 
     for (int e = 0; e < ni; e++) { if (Q->it[e].kind == 1) soft_row[Q->it[e].sidx] = e; if (Q->it[e].kind == 2) soft_pos[Q->it[e].sidx] = e; }
@@ -733,7 +735,16 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
          * all decay by the same factor prod(1 - alpha_k)) and the largest complementarity product below qp_tol.
          * The stationarity residual res[0] is REPORTED, not gated: late in the iteration its rounding floor is
          * ~ eps * lam^2 |z| / mu for active rows (multiplier accuracy), while the primal point is unaffected. */
-        if (res[1] <= c->qp_tol && res[2] <= c->qp_tol && res[3] <= c->qp_tol) { status = 0; break; }
+        if (res[1] <= c->qp_tol && res[2] <= c->qp_tol && res[3] <= c->qp_tol) {
+            /* POLISH (round 5): a pair (lam, t) whose product is below qp_tol can still sit min(lam, t) ~ qp_tol / max(lam, t) from its limit 0 -- a row with a
+             * multiplier of 1e-4 is left 1e-6 inside its bound, a nearly active row keeps a multiplier of 1e-6 -- which is what the parity tail beyond 1e-6
+             * consisted of.  While the largest such remainder exceeds polish_tol the interior point takes another iteration (at most
+             * POLISH_MAX of them): in its superlinear end-game one iteration takes the products from ~1e-10 to ~1e-14.  Shared with the HIP kernels. */
+            double slop = 0;
+            if (c->polish_tol > 0) for (int e = 0; e < ni; e++) { double m = Q->it[e].lam < Q->it[e].t ? Q->it[e].lam : Q->it[e].t; if (m > slop) slop = m; }
+            if (!(c->polish_tol > 0) || slop <= c->polish_tol || npolish >= POLISH_MAX || it >= c->qp_iter_max) { status = 0; break; }
+            npolish++;
+        }
         /* at the cap: a complementarity measure far above anything a healthy solve shows (<= ~1e2 mu0, early in the iteration) means the QP was on its way
          * to MU_DIVERGED (infeasible), not converging slowly -- its step is garbage and must not be applied (status 4, as every other failure);
          * otherwise: max-iter, step applied.  From iteration MU_CAP_SETTLED on the bar is mu0 itself: a healthy solve is three orders of

@@ -72,6 +72,8 @@ typedef struct orc_config {
      *      HPIPM solve that returned MAX_ITER (robot_ocp_problem.py:131, :203-205 only reacts to status 4); NaN / overflow / step collapse stay 4.
      * The default is the one the reference's recorded tables select (profiles/r04_fail_policy_replay.json). */
     int qp_fail_policy;
+    /* polish (round 5): after the termination test holds, further iterations (at most 2) while max over the pairs of min(lam, t) > polish_tol; 0 = off */
+    double polish_tol;
 } orc_config;
 
 void orc_default_config(orc_config *c, int N, int n_obst, double Tf);

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""CPU probe (oracle only, no GPU): what the POLISH of the interior point buys.  For a problem size (N, n_obst) and a list of polish_tol values it solves `count`
+random first solves (and the second solve of the closed loop: the two on which the parity tail lived, profiles/r04_parity_sweep.json) with the oracle and
+compares every converged step with the EXACT solution of its QP (tests/helpers.py::exact_qp): fraction beyond 1e-6 / 1e-7, worst distance, mean iterations.
+
+    python scripts/polish_probe.py --N 50 --n_obst 10 --count 600 --tols 0,1e-8,1e-9 --out profiles/r05_polish_probe_c5.json
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+
+
+def work(job):
+    N, no, seed, lo, hi, tols = job
+    from oracle import oracle as orc
+    from helpers import exact_qp, random_batch, step_vector
+    x0, goal, obst = random_batch(hi, no, seed=seed)
+    out = {str(t): [] for t in tols}
+    for b in range(lo, hi):
+        base = orc.config(N, no, 0.1 * N)
+        X, U = orc.initial_guess(base, x0[b])
+        x, ob = x0[b].copy(), obst[b].copy()
+        for step in range(2):
+            P = orc.predict_params(base, ob)
+            q = orc.export_qp(base, x, P, goal[b], X, U)
+            vex = None
+            res = {}
+            for t in tols:
+                cfg = orc.config(N, no, 0.1 * N, polish_tol=t)
+                r = orc.rti_solve(cfg, x, P, goal[b], X, U)
+                res[t] = r
+                if r["status"] != 0:
+                    out[str(t)].append((b, step, r["status"], r["iters"], None))
+                    continue
+                v = step_vector(N, X, U, r["X"], r["U"])
+                if vex is None:
+                    vex, ok, info = exact_qp(q, v)
+                    if not ok:
+                        vex = None
+                out[str(t)].append((b, step, 0, r["iters"], None if vex is None else float(np.abs(v - vex).max())))
+            r = res[tols[0]]
+            # closed loop continues on the unpolished (first) variant's result so that every variant sees the same second QP
+            X, U = r["X"], r["U"]
+            x = orc.dynamics(x, r["u0"], 0.1)[0]
+            for j in range(no):
+                ob[j] = orc.obstacle_step(base, ob[j], 0.1)
+            X, U = orc.shift(base, X, U)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--N", type=int, default=50)
+    ap.add_argument("--n_obst", type=int, default=10)
+    ap.add_argument("--count", type=int, default=600)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--tols", default="0,1e-8,1e-9")
+    ap.add_argument("--procs", type=int, default=8)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    tols = [float(t) for t in a.tols.split(",")]
+    from oracle import oracle as orc
+    orc.build()
+    chunk = max(1, a.count // (4 * a.procs))
+    jobs = [(a.N, a.n_obst, a.seed, lo, min(a.count, lo + chunk), tols) for lo in range(0, a.count, chunk)]
+    with mp.Pool(a.procs) as pool:
+        parts = pool.map(work, jobs)
+    summary = {"N": a.N, "n_obst": a.n_obst, "count": a.count, "steps": 2, "variants": {}}
+    for t in tols:
+        rows = [r for p in parts for r in p[str(t)]]
+        conv = [r for r in rows if r[2] == 0 and r[4] is not None]
+        d = np.array([r[4] for r in conv])
+        it = np.array([r[3] for r in rows])
+        worst = sorted(conv, key=lambda r: -r[4])[:5]
+        summary["variants"][str(t)] = dict(solves=len(rows), converged=len(conv), unverified=sum(1 for r in rows if r[2] == 0 and r[4] is None),
+                                           mean_iters=float(it.mean()), beyond_1e6=int((d > 1e-6).sum()), beyond_1e7=int((d > 1e-7).sum()), beyond_1e5=int((d > 1e-5).sum()),
+                                           frac_beyond_1e6=float((d > 1e-6).mean()), worst=float(d.max()), p999=float(np.quantile(d, 0.999)), median=float(np.median(d)),
+                                           worst_instances=[(r[0], r[1], r[3], r[4]) for r in worst])
+        print(t, json.dumps(summary["variants"][str(t)]))
+    if a.out:
+        json.dump(summary, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

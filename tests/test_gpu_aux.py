@@ -1,5 +1,6 @@
 """GPU tests of the kernels either side of the solve (a9, a12, a13, a14) and of the Python call surface, through the C ABI."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -519,3 +520,31 @@ def test_pipelined_sub_batches_are_the_whole_batch(env, N, no, B, K):
     assert (o["status"] == b["first"][1]).all()
     ok = o["status"] == 0
     assert np.abs(o["u0"][ok] - b["first"][0][ok]).max() < 8e-6
+
+
+@pytest.mark.gpu
+def test_torch_process_group_and_the_library_communicator_in_one_process(env):
+    """The process state every rank of `bench.py --gpus N` has and no single-rank test had (VERDICT r04 missing 2): a torch.distributed NCCL (= RCCL) process
+    group with its communicator already created, THEN the library's dlopen("librccl.so.1") + mpc_comm_init + mpc_allgather_cost_dev on a side stream, then
+    another collective of the torch group -- one process, world size 1 (RCCL refuses two ranks on one device).  Run through bench.py's own code path
+    (--force-exchange --with-torch-pg) in a child process, so this process keeps no process group.  Checks: the exchange stayed `capi` (a fallback exits
+    non-zero), the gathered costs are the rank's own, the torch group still reduces afterwards, and ONE librccl is mapped -- the one the library is bound to
+    (PyTorch's wheel bundles a librccl.so with soname librccl.so.1, already mapped when libmpcgpu asks for that soname)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    envv = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        envv.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c2", "--steps", "1", "--warmup", "0", "--no-extra", "--no-cpu-baseline",
+                        "--force-exchange", "--with-torch-pg"], env=envv, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) < 4096
+    line = json.loads(last)
+    assert line["exchange"] == "capi" and line["rccl_ranks"] == 1 and line["gather_check"] is True
+    assert line["torch_pg"] == {"backend": "nccl", "world": 1, "all_reduce_after_exchange_ok": True}
+    assert os.path.isabs(line["rccl_path"]) and "rccl" in os.path.basename(line["rccl_path"])
+    full = json.load(open(os.path.join(root, "profiles", "bench_last.json")))
+    assert full["rccl_mapped"] == [os.path.realpath(line["rccl_path"])] or full["rccl_mapped"] == [line["rccl_path"]], full["rccl_mapped"]
+    assert line["value"] > 1e6

@@ -149,3 +149,40 @@ def test_step_counts_per_call_for_the_subgoal_hook(built):
     assert st.min_margin <= margin_after_first and abs(st.min_margin - ref.min_margin) < 1e-9     # min_margin_traj persists (:228-229)
     row = st.table_row()
     assert row[4] == k and row[1] is False
+
+
+def test_bench_line_is_compact_and_parseable():
+    """The driver parses the LAST stdout line of bench.py and keeps only a few KB of tail (BENCH_r04.json: a 20.7 KB line -> parsed null).  compact_line() of the
+    largest full record any round produced (round 4's, kept under profiles/) must stay below the limit, parse, and carry the contract's keys; the prose
+    stays in the full record."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")))
+    assert len(json.dumps(full)) > 15000
+    text = bench.compact_line(full)
+    assert len(text) < bench.LINE_LIMIT and "\n" not in text
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["vs_baseline"] is None and line["config"]["workload"].startswith("C2") and "model" not in line["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "issue", "lanes_active"):
+        assert k in line["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    assert abs(line["value"] / full["value"] - 1) < 1e-4 and abs(line["roofline"]["frac"] / full["roofline"]["frac"] - 1) < 1e-4
+    for name in ("c3", "c5", "c4_share", "c5_share"):
+        assert set(line[name]) <= {"value", "value_one_stream", "mean_ipm_iters", "frac", "issue", "latency_frac"}
+    assert not any("note" in k for k in line) and not any("note" in k for k in line["roofline"])
+    # a record that cannot be made compact is refused loudly, not printed
+    bloated = dict(full, config=dict(full["config"], workload="x" * 5000))
+    with pytest.raises(AssertionError):
+        bench.compact_line(bloated)
+
+
+def test_bench_dry_run_last_stdout_line_parses(built):
+    import json
+    for wl in ("c2", "c4"):
+        line = _bench_dry_run(wl)
+        assert len(json.dumps(line)) < 4096 and line["metric"].startswith("MPC solves/sec")
