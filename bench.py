@@ -44,6 +44,8 @@ FP64_VALU_PEAK_TF = 78.6     # MI355X FP64 vector peak.  MI355X_MICROARCH.md tab
                              # (= the same product without packing: one wave64 FP64 FMA occupies a SIMD for 4 cycles)
 SIMDS = 1024                 # 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4              # nominal engine clock the cycle figures are converted with
+LONE_WAVE_VALU_CYCLES = 5.0  # what ONE wavefront per SIMD pays per independent FP64 VALU instruction (8.4 when it depends on the previous one) and per LDS instruction
+LONE_WAVE_LDS_CYCLES = 14.0  # (issue cost, whatever the width): micro-benchmarks scripts/bin_src/dpp64_test.hip, lds_issue_test.hip (docs/HISTORY.md section 4.1c)
 VALU_CYCLES_PER_INST = 4     # a wave64 VALU instruction holds its 16-lane SIMD for 4 cycles: the issue roof of one SIMD is 1 instruction per 4 cycles
 EPISODE = 100                # control steps per episode = per bench step
 GATHER_EVERY = 50            # control steps per cost all-gather message
@@ -106,6 +108,8 @@ def measured_pmc(kernel_name, batch):
                 c = d["counters"]
                 best = dict(traffic=t["fetch_raw_kb"] * 1024 + t["write_bytes"], file=os.path.basename(f),
                             valu_insts=c.get("SQ_INSTS_VALU", {}).get("mean_per_launch"), avg_ns=(d.get("kernel_stats") or {}).get("avg_ns"),
+                            lds_insts=c.get("SQ_INSTS_LDS", {}).get("mean_per_launch"), wave_cycles=c.get("SQ_WAVE_CYCLES", {}).get("mean_per_launch"),
+                            wait_any=c.get("SQ_WAIT_ANY", {}).get("mean_per_launch"),
                             lanes_active=(d.get("derived") or {}).get("valu_lanes_active"))
         except Exception:
             pass
@@ -479,7 +483,19 @@ def roofline(loop, N, no, r):
     if pm and pm["valu_insts"] and pm["avg_ns"]:
         # the roof that binds: VALU issue slots.  SQ_INSTS_VALU x 4 cycles / (SIMDs x kernel cycles), instructions and duration from the SAME profile
         issue = pm["valu_insts"] * VALU_CYCLES_PER_INST / (SIMDS * pm["avg_ns"] * CLOCK_GHZ)
+    latency_frac = wait_frac = None
+    if pm and pm.get("valu_insts") and pm.get("lds_insts") and pm.get("wave_cycles"):
+        # The floor of what these wavefronts could take at all: their own instruction stream priced as a LONE wavefront issues it (one or two wavefronts per
+        # SIMD: nothing else fills its bubbles) -- every VALU instruction independent (5.0 cycles; a dependent one costs 8.4, so the true floor is higher),
+        # every LDS instruction 14 -- over the cycles the wavefronts were resident (SQ_WAVE_CYCLES counts quad-cycles).  1 - latency_frac is ALL the slack a
+        # perfect schedule of the same instructions could recover; the rest of the distance to the FP64 peak is lanes without data and the lone stream.
+        latency_frac = (LONE_WAVE_VALU_CYCLES * pm["valu_insts"] + LONE_WAVE_LDS_CYCLES * pm["lds_insts"]) / (4.0 * pm["wave_cycles"])
+        wait_frac = pm["wait_any"] / pm["wave_cycles"] if pm.get("wait_any") else None
     return {"bound": "fp64_valu", "achieved": flops / avg_s / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+            "latency_frac": latency_frac, "wait_frac": wait_frac,
+            "latency_model": (f"(5.0 cycles x SQ_INSTS_VALU + 14 cycles x SQ_INSTS_LDS) / (4 x SQ_WAVE_CYCLES) of profiles/{pm['file']}: the kernel's own instruction stream at the "
+                              "price a lone wavefront pays per instruction (micro-benchmarks, docs/HISTORY.md 4.1c; all VALU taken as independent: a lower bound of "
+                              "the floor) over the cycles its wavefronts were resident") if latency_frac is not None else None,
             "frac": flops / avg_s / 1e12 / FP64_VALU_PEAK_TF,
             "peak_source": "AMD public specification of MI355X (FP64 vector = FP64 matrix = 78.6 TFLOP/s); MI355X_MICROARCH.md lists the FP32 vector peak (157.3) only",
             "issue": issue,

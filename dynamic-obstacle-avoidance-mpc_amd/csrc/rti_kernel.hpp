@@ -70,6 +70,7 @@ struct KParams {
     double r2;                // r_safe^2
     double slack_a, slack_b, ss;  // ss: penalty scale for stages < N (dt or 1)
     double tol, mu0, thr0;
+    double polish_ratio;                 // polish of the interior point (kPolishMax); +inf = off (mpc_api.hip::make_params)
     double tl_min;                       // floor of t and lam: min(kTLMin, qp_tol / 10) (the floor must stay below the tolerance: an active row's rho - t is the floor)
     double mu_div, mu_cap, mu_settled;   // the divergence tests of the interior point as thresholds on mu (mpc_api.hip::make_params): kMuDiverged mu0, kMuCapFailed mu0, mu0 --
                                          // or, mpc_config.qp_fail_policy = 1 ("truncate"), 1e300 / inf / inf: a diverging solve runs to the iteration cap and ends as status 2
@@ -300,6 +301,70 @@ __device__ __forceinline__ double seg21_reduce(double v, int lane)
     const double r0 = SUM ? l0 + l1 : fmax(l0, l1), r1 = SUM ? u1 + l2 : fmax(u1, l2), r2 = SUM ? u2 + l3 : fmax(u2, l3);
     const int slot = seg21_slot(lane);
     return slot == 0 ? r0 : (slot == 1 ? r1 : r2);
+}
+
+// ---- POLISH of the interior point (round 5; shared specification with oracle/mpc_oracle.c ipm_solve) ----
+// Once the termination test holds, an instance takes up to kPolishMax further iterations while its LAST iteration reduced the largest live complementarity
+// product c_max by less than a factor 1 / polish_ratio (c_max(k) > polish_ratio c_max(k - 1)): the interior point is then not yet in its superlinear
+// end-game, and what it leaves behind on meeting qp_tol was the parity tail beyond 1e-6.  c_max is the termination test's own measure: no extra reduction.
+static constexpr int kPolishMax = 2;
+// MPC_NAN_NOTE.  A NaN / overflow of the row state must end the solve (status 4) as it does in the oracle, where it surfaces in mu at the head of the next
+// iteration.  In the kernels the floors of the update (t = fmax(t + a dt, floor): fmax drops a NaN) would wash it out of t and lam, and a solve that diverged
+// under qp_fail_policy 1 would come back "converged" with every pair at the floor and the linear residual at 0 (found by the truncate-policy test once the
+// centring target changed the path of an infeasible QP).  The affine sums carry the NaN -- sigma, hence smu = sigma min(mu, c_max), is NaN then -- and the
+// step-length test of the same iteration looks at it.
+
+// ---- THE INTERIOR POINT'S SCALAR DECISIONS, ONE DEFINITION (round 5) ----
+// Everything of an iteration that is a decision on segment-uniform scalars -- the three status tests with the polish, the affine step lengths, sigma and the
+// centring target, the step lengths of the combined step and its failure test -- is defined HERE, once, for the branch-free and the branched form of
+// rti_solve_kernel and for rti_split_kernel (rti_split_kernel.hpp); the constants they use (kFracToBoundary, kMuCapSettled, kPolishMax, KParams::tol /
+// mu_div / mu_cap / mu_settled / polish_ratio / iter_max) appear nowhere else in the loops.  The oracle's ipm_solve (oracle/mpc_oracle.c) states the same
+// tests in its own words.  What stays per kernel is the ROW arithmetic, whose form IS the storage policy (rows in registers with 0 / 1 factors, lean rows
+// recomputed per phase, rows under branches, rows dealt over the lanes of a stage).  __forceinline__: the same instructions as the inlined text they replace.
+struct IpmState {            // per instance (segment-uniform)
+    int status = 2, it_done = 0, npolish = 0;
+    bool running = true;
+    double cprev = INFINITY;  // c_max at the head of the previous iteration
+};
+// head of iteration `it`: failure by NaN / divergence, convergence (or a polish iteration), iteration cap
+__device__ __forceinline__ void ipm_head(const KParams &p, IpmState &S, int it, double mu, double lin, double cmax)
+{
+    if (!S.running) return;
+    if (!(mu == mu) || !(fabs(mu) <= p.mu_div)) { S.status = 4; S.running = false; S.it_done = it; }      // NaN, or diverged: an infeasible QP
+    else if (lin <= p.tol && cmax <= p.tol) {
+        // converged -- or one more iteration, the polish (kPolishMax; polish off: the ratio is +inf)
+        if (S.npolish < kPolishMax && it < p.iter_max && cmax > p.polish_ratio * S.cprev) S.npolish++;
+        else { S.status = 0; S.running = false; S.it_done = it; }
+    }
+    else if (it >= p.iter_max) {      // at the cap with mu above a healthy solve's: diverging or stalled, not slow
+        S.status = (mu > p.mu_cap || (it >= kMuCapSettled && mu > p.mu_settled)) ? 4 : 2; S.running = false; S.it_done = it;
+    }
+}
+// largest affine steps that keep t, lam > 0 from the largest ratios -dt/t, -dlam/lam (true divisions, as the oracle: a 1-ulp reciprocal here moves a
+// sensitive instance past the parity tolerance)
+__device__ __forceinline__ void ipm_affine_steps(double rmax, double rmaxd, double &a_aff, double &a_affd)
+{
+    a_aff = rmax > 1.0 ? 1.0 / rmax : 1.0; a_affd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;
+}
+// sigma = min(1, (mu_aff / mu)^2) and the centring target sigma * min(mu, c_max) (c_max: largest product of a pair off the floor; oracle ipm_solve mu_c)
+__device__ __forceinline__ double ipm_centring(double maff, double mu, double cmax, double &sigma)
+{
+    sigma = mu > 0 ? maff / mu : 0.0;
+    sigma = sigma * sigma;
+    if (sigma > 1.0) sigma = 1.0;
+    return sigma * fmin(mu, cmax);
+}
+// step lengths of the combined step: 1 if unblocked, else kFracToBoundary of the largest step that keeps t (alpha) and lam (alphad) positive
+__device__ __forceinline__ void ipm_step_lengths(double rmax, double rmaxd, double &alpha, double &alphad)
+{
+    const double amax = rmax > 1.0 ? 1.0 / rmax : 1.0, amaxd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;
+    alpha = (amax >= 1.0) ? 1.0 : kFracToBoundary * amax;          // primal step: z, s, t
+    alphad = (amaxd >= 1.0) ? 1.0 : kFracToBoundary * amaxd;       // dual step: lam
+}
+// step collapse, or a NaN of the row state (MPC_NAN_NOTE): status 4
+__device__ __forceinline__ void ipm_step_check(IpmState &S, int it, double alpha, double alphad, double smu)
+{
+    if (S.running && (!(alpha > 1e-14) || !(alphad > 1e-14) || !(smu == smu))) { S.status = 4; S.running = false; S.it_done = it; }
 }
 
 // reciprocal: hardware seed + two Newton steps (1-2 ulp); used for 1/t of the inequality rows
@@ -2176,8 +2241,11 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     // multiply-add that would have been an add.
     const double m_u = vbu ? 1.0 : 0.0, m_x = vbx ? 1.0 : 0.0, m_s = vs ? 1.0 : 0.0;
 #define MPC_MK(k) ((k) < 2 ? m_u : m_x)
-    int status = 2, it = 0, it_done = 0;
-    bool running = !ep_done;  // per instance: instances sharing a wavefront stop at their own iteration and then idle
+    int it = 0;
+    IpmState ipm;             // per instance: instances sharing a wavefront stop at their own iteration and then idle
+    ipm.running = !ep_done;
+    int &status = ipm.status, &it_done = ipm.it_done;
+    bool &running = ipm.running;
     if (!(lin0 <= 1e300)) { status = 4; running = false; }
 
 #ifdef MPC_PHASE_TIMING
@@ -2225,12 +2293,9 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         seg_reduce2<G, true>(msum, cmax, lane);
         const double mu = msum * inv_items;
         const double lin = rhoPi * lin0;
-        if (running) {
-            if (!(mu == mu) || !(fabs(mu) <= p.mu_div)) { status = 4; running = false; it_done = it; }      // NaN, or diverged: an infeasible QP
-            else if (lin <= p.tol && cmax <= p.tol) { status = 0; running = false; it_done = it; }
-            else if (it >= p.iter_max) { status = (mu > p.mu_cap || (it >= kMuCapSettled && mu > p.mu_settled)) ? 4 : 2; running = false; it_done = it; }      // at the cap with mu above a healthy solve's: diverging or stalled, not slow
-        }
+        ipm_head(p, ipm, it, mu, lin, cmax);
         if (__ballot(running) == 0ull) break;
+        ipm.cprev = cmax;
         MPC_TICK(0);
 
         // residual r_d = rho(z) - t of the box rows of variable k, from the iterate (never stored)
@@ -2558,13 +2623,12 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             rmax = fmax(rmax, m_s * rg); rmaxd = fmax(rmaxd, m_s * rgd);
             T0 = fma(m_s, S0, T0); T1 = fma(m_s, S1, T1); T2 = fma(m_s, S2, T2); T3 = fma(m_s, S3, T3);      // this lane's four sums over the rows that exist
             seg_reduce2<G, false>(rmax, rmaxd, lane);
-            const double a_aff = rmax > 1.0 ? 1.0 / rmax : 1.0, a_affd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;      // (true divisions, as the oracle: a 1-ulp reciprocal here moves a sensitive instance past the parity tolerance)
+            double a_aff, a_affd;
+            ipm_affine_steps(rmax, rmaxd, a_aff, a_affd);
             double maff = fma(a_aff, fma(a_affd, T3, T1), fma(a_affd, T2, T0));
             maff = seg_sum<G>(maff, lane) * inv_items;
-            double sigma = mu > 0 ? maff / mu : 0.0;
-            sigma = sigma * sigma;
-            if (sigma > 1.0) sigma = 1.0;
-            smu = sigma * mu;
+            double sigma;
+            smu = ipm_centring(maff, mu, cmax, sigma);
 #ifndef MPC_PHASE_TIMING
             if (p.trace && i == 0 && valid && running) {
                 double *tr = p.trace + ((size_t)inst * p.iter_max + it) * 4;
@@ -2703,13 +2767,12 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             }
             rmax = fmax(rmax, m_s * rg); rmaxd = fmax(rmaxd, m_s * rgd);
             seg_reduce2<G, false>(rmax, rmaxd, lane);
-            const double amax = rmax > 1.0 ? 1.0 / rmax : 1.0, amaxd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;
-            const double alpha = (amax >= 1.0) ? 1.0 : kFracToBoundary * amax;        // primal step: z, s, t
-            const double alphad = (amaxd >= 1.0) ? 1.0 : kFracToBoundary * amaxd;     // dual step: lam
+            double alpha, alphad;
+            ipm_step_lengths(rmax, rmaxd, alpha, alphad);
 #ifndef MPC_PHASE_TIMING
             if (p.trace && i == 0 && valid && running) p.trace[((size_t)inst * p.iter_max + it) * 4 + 2] = alpha;
 #endif
-            if (running && (!(alpha > 1e-14) || !(alphad > 1e-14))) { status = 4; running = false; it_done = it; }
+            ipm_step_check(ipm, it, alpha, alphad, smu);
             {   // An instance that has stopped keeps its step z (a select, not a step of length zero: what a converged instance computes while it idles
                 // beside a neighbour that still iterates is a Newton step from a state with slacks at their floor -- it may be Inf or NaN, and 0 * NaN
                 // is NaN).  Its row state is no longer read by anything and simply moves on, as do the rows that do not exist.
@@ -2775,12 +2838,9 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         seg_reduce2<G, true>(msum, cmax, lane);
         const double mu = msum * inv_items;
         const double lin = rhoPi * lin0;
-        if (running) {
-            if (!(mu == mu) || !(fabs(mu) <= p.mu_div)) { status = 4; running = false; it_done = it; }      // NaN, or diverged: an infeasible QP
-            else if (lin <= p.tol && cmax <= p.tol) { status = 0; running = false; it_done = it; }
-            else if (it >= p.iter_max) { status = (mu > p.mu_cap || (it >= kMuCapSettled && mu > p.mu_settled)) ? 4 : 2; running = false; it_done = it; }      // at the cap with mu above a healthy solve's: diverging or stalled, not slow
-        }
+        ipm_head(p, ipm, it, mu, lin, cmax);
         if (__ballot(running) == 0ull) break;
+        ipm.cprev = cmax;
         MPC_TICK(0);
 
         // residual r_d = rho(z) - t of the box rows of variable k, from the iterate (never stored)
@@ -3076,7 +3136,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 }
             }
             seg_reduce2<G, false>(rmax, rmaxd, lane);
-            const double a_aff = rmax > 1.0 ? 1.0 / rmax : 1.0, a_affd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;      // (true divisions, as the oracle: a 1-ulp reciprocal here moves a sensitive instance past the parity tolerance)
+            double a_aff, a_affd;
+            ipm_affine_steps(rmax, rmaxd, a_aff, a_affd);
             double maff = 0.0;
 #pragma unroll
             for (int k = 0; k < NB; k++) if ((k < 2) ? vbu : vbx)
@@ -3090,10 +3151,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 }
             }
             maff = seg_sum<G>(maff, lane) * inv_items;
-            double sigma = mu > 0 ? maff / mu : 0.0;
-            sigma = sigma * sigma;
-            if (sigma > 1.0) sigma = 1.0;
-            smu = sigma * mu;
+            double sigma;
+            smu = ipm_centring(maff, mu, cmax, sigma);
 #ifndef MPC_PHASE_TIMING
             if (p.trace && i == 0 && valid && running) {
                 double *tr = p.trace + ((size_t)inst * p.iter_max + it) * 4;
@@ -3228,13 +3287,12 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 }
             }
             seg_reduce2<G, false>(rmax, rmaxd, lane);
-            const double amax = rmax > 1.0 ? 1.0 / rmax : 1.0, amaxd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;
-            const double alpha = (amax >= 1.0) ? 1.0 : kFracToBoundary * amax;        // primal step: z, s, t
-            const double alphad = (amaxd >= 1.0) ? 1.0 : kFracToBoundary * amaxd;     // dual step: lam
+            double alpha, alphad;
+            ipm_step_lengths(rmax, rmaxd, alpha, alphad);
 #ifndef MPC_PHASE_TIMING
             if (p.trace && i == 0 && valid && running) p.trace[((size_t)inst * p.iter_max + it) * 4 + 2] = alpha;
 #endif
-            if (running && (!(alpha > 1e-14) || !(alphad > 1e-14))) { status = 4; running = false; it_done = it; }
+            ipm_step_check(ipm, it, alpha, alphad, smu);
             if (running) {
 #pragma unroll
                 for (int c = 0; c < 7; c++) z[c] += alpha * dz[c];

@@ -362,8 +362,11 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
 
     double z[7] = {0, 0, 0, 0, 0, 0, 0};
     double rhoPi = 1.0;
-    int status = 2, it = 0, it_done = 0;
-    bool running = !ep_done;
+    int it = 0;
+    IpmState ipm;             // rti_kernel.hpp: the interior point's scalar decisions are defined there, once
+    ipm.running = !ep_done;
+    int &status = ipm.status, &it_done = ipm.it_done;
+    bool &running = ipm.running;
     if (!(lin0 <= 1e300)) { status = 4; running = false; }
 
     MPC_TICK(13);
@@ -391,12 +394,9 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
         seg_reduce2<64, true>(msum, cmax, lane);
         const double mu = msum * inv_items;
         const double lin = rhoPi * lin0;
-        if (running) {
-            if (!(mu == mu) || !(fabs(mu) <= p.mu_div)) { status = 4; running = false; it_done = it; }      // NaN, or diverged: an infeasible QP
-            else if (lin <= p.tol && cmax <= p.tol) { status = 0; running = false; it_done = it; }
-            else if (it >= p.iter_max) { status = (mu > p.mu_cap || (it >= kMuCapSettled && mu > p.mu_settled)) ? 4 : 2; running = false; it_done = it; }      // at the cap with mu above a healthy solve's: diverging or stalled, not slow
-        }
+        ipm_head(p, ipm, it, mu, lin, cmax);
         if (!running) break;      // wave-uniform: one instance per wavefront
+        ipm.cprev = wave_uniform(cmax);
         MPC_TICK(0);
 
         // ---- predictor (sigma = 0): this lane's share of the local gradient, the barrier terms and the reduced Hessian ----
@@ -769,7 +769,8 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
                 if (sp[s]) { rmax = fmax(rmax, -dt1_[s] * rt1[s]); rmaxd = fmax(rmaxd, fma(dt1_[s], rt1[s], 1.0)); }
             }
             seg_reduce2<64, false>(rmax, rmaxd, lane);
-            const double a_aff = rmax > 1.0 ? 1.0 / rmax : 1.0, a_affd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;      // (true divisions, as the oracle: a 1-ulp reciprocal here moves a sensitive instance past the parity tolerance)
+            double a_aff, a_affd;
+            ipm_affine_steps(rmax, rmaxd, a_aff, a_affd);
             double maff = 0.0;
 #pragma unroll
             for (int s = 0; s < NBL; s++) if (bp[s])
@@ -780,10 +781,8 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
                 if (soft) maff += (l2[s] + a_affd * dl2_[s]) * (t2[s] + a_aff * dt2_[s]);
             }
             maff = seg_sum<64>(maff, lane) * inv_items;
-            double sigma = mu > 0 ? maff / mu : 0.0;
-            sigma = sigma * sigma;
-            if (sigma > 1.0) sigma = 1.0;
-            smu = sigma * mu;
+            double sigma;
+            smu = ipm_centring(maff, mu, cmax, sigma);
 #ifndef MPC_PHASE_TIMING
             if (p.trace && lane == 0) {
                 double *tr = p.trace + ((size_t)inst * p.iter_max + it) * 4;
@@ -974,13 +973,12 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
                 if (sp[s]) { rmax = fmax(rmax, -dt1_[s] * rt1[s]); rmaxd = fmax(rmaxd, -dl1_[s] * rcp_nr(l1[s])); }
             }
             seg_reduce2<64, false>(rmax, rmaxd, lane);
-            const double amax = rmax > 1.0 ? 1.0 / rmax : 1.0, amaxd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;
-            const double alpha = (amax >= 1.0) ? 1.0 : kFracToBoundary * amax;        // primal step: z, s, t
-            const double alphad = (amaxd >= 1.0) ? 1.0 : kFracToBoundary * amaxd;     // dual step: lam
+            double alpha, alphad;
+            ipm_step_lengths(rmax, rmaxd, alpha, alphad);
 #ifndef MPC_PHASE_TIMING
             if (p.trace && lane == 0) p.trace[((size_t)inst * p.iter_max + it) * 4 + 2] = alpha;
 #endif
-            if (!(alpha > 1e-14) || !(alphad > 1e-14)) { status = 4; running = false; it_done = it; }
+            ipm_step_check(ipm, it, alpha, alphad, smu);
             if (running) {
 #pragma unroll
                 for (int c = 0; c < 7; c++) z[c] += alpha * dz[c];

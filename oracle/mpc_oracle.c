@@ -89,7 +89,7 @@ void orc_default_config(orc_config *c, int N, int n_obst, double Tf)
      * within 25 iterations then needs more than 25 here (profiles/r04_thr0_probe.txt): the reference's own problem size keeps the constant its pin was made with. */
     c->thr0 = n_obst >= 8 ? 0.3 : 0.1;
     c->qp_fail_policy = 0;
-    c->polish_tol = 0.0;
+    c->polish_ratio = 1e-2;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -480,6 +480,17 @@ static void add_box(qp_t *Q, int stage, int zidx, double val, double lo, double 
     memset(e, 0, sizeof(*e)); e->stage = stage; e->kind = 0; e->cz[zidx] = -1.0; e->c0 = hi - val;
 }
 
+/* INVESTIGATION switches (environment ORC_INVESTIGATE, default 0; scripts/converged_unmatched.py -- VERDICT r04 item 3): hypotheses about what acados / HPIPM
+ * kept in the QP that change the interior point's PATH, not the QP's solution:  1 = the obstacle rows of stage 0 are present (x_0 fixed: they only set sl_0),
+ * 2 = rows whose slack penalty is zero (the terminal stage of the reference's schedule) are kept as free-slack rows instead of being dropped,
+ * 4 = the stationarity residual is gated by the termination test as well (HPIPM's res_g).  Never set by tests or by the product. */
+static int orc_investigation(void)
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("ORC_INVESTIGATE"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 /* Build the QP of one RTI step */
 static void build_qp(const orc_config *c, const double *x0, const double *P, const double *goal,
                      const double *X, const double *U, qp_t *Q, const double *alpha_in)
@@ -506,13 +517,13 @@ static void build_qp(const orc_config *c, const double *x0, const double *P, con
         if (i < N) for (int k = 0; k < 2; k++) add_box(Q, i, k, U[2 * i + k], c->bu_lo[k], c->bu_hi[k]);   /* :95-97 */
         if (i >= 1 && (i < N || c->bx_terminal))                                                         /* :91-93 */
             for (int k = 0; k < 4; k++) add_box(Q, i, 2 + IDXBX[k], X[5 * i + IDXBX[k]], c->bx_lo[k], c->bx_hi[k]);
-        if (i >= 1) { /* stage 0: x_0 is fixed so its rows are decoupled */
+        if (i >= 1 || (orc_investigation() & 1)) { /* stage 0: x_0 is fixed so its rows are decoupled; investigation switch 1 keeps them */
             obstacle_h(c, X + 5 * i, P + 2 * no * i, h, dh);
             double sc = (i < N) ? stage_ss(c) : 1.0;
             for (int j = 0; j < no; j++) {
                 if (c->soft_h) {
                     double z = sc * alpha[i];
-                    if (!(z > 0.0)) continue;   /* zero penalty: the slack is free, the row is vacuous */
+                    if (!(z > 0.0) && !(orc_investigation() & 2)) continue;   /* zero penalty: the slack is free, the row is vacuous (investigation switch 2 keeps it as a free-slack row) */
                     int si = Q->n_s++;
                     Q->zs[si] = z; Q->Zs[si] = z; Q->s_stage[si] = i;   /* zl = Zl = alpha_i, :149-152 */
                     item_t *e = &Q->it[Q->n_items++];
@@ -707,7 +718,7 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
     R.P = WS_ALLOC(sizeof(double[25]) * (N + 1)); R.p = WS_ALLOC(sizeof(double[NX]) * (N + 1));
     R.K = WS_ALLOC(sizeof(double[10]) * N); R.k = WS_ALLOC(sizeof(double[NU]) * N); R.L = WS_ALLOC(sizeof(double[4]) * N); R.Mxu = WS_ALLOC(sizeof(double[10]) * N);
     double re0[5], res[4];
-    int status = 2, it = 0, npolish = 0;
+    int status = 2, it = 0, npolish = 0; double cprev = INFINITY;      /* cprev: c_max at the head of the previous iteration */
     TL_MIN = TL_MIN_MAX < 0.1 * c->qp_tol ? TL_MIN_MAX : 0.1 * c->qp_tol;
 
     for (int e = 0; e < ni; e++) { if (Q->it[e].kind == 1) soft_row[Q->it[e].sidx] = e; if (Q->it[e].kind == 2) soft_pos[Q->it[e].sidx] = e; }
@@ -735,14 +746,16 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
          * all decay by the same factor prod(1 - alpha_k)) and the largest complementarity product below qp_tol.
          * The stationarity residual res[0] is REPORTED, not gated: late in the iteration its rounding floor is
          * ~ eps * lam^2 |z| / mu for active rows (multiplier accuracy), while the primal point is unaffected. */
-        if (res[1] <= c->qp_tol && res[2] <= c->qp_tol && res[3] <= c->qp_tol) {
-            /* POLISH (round 5): a pair (lam, t) whose product is below qp_tol can still sit min(lam, t) ~ qp_tol / max(lam, t) from its limit 0 -- a row with a
-             * multiplier of 1e-4 is left 1e-6 inside its bound, a nearly active row keeps a multiplier of 1e-6 -- which is what the parity tail beyond 1e-6
-             * consisted of.  While the largest such remainder exceeds polish_tol the interior point takes another iteration (at most
-             * POLISH_MAX of them): in its superlinear end-game one iteration takes the products from ~1e-10 to ~1e-14.  Shared with the HIP kernels. */
-            double slop = 0;
-            if (c->polish_tol > 0) for (int e = 0; e < ni; e++) { double m = Q->it[e].lam < Q->it[e].t ? Q->it[e].lam : Q->it[e].t; if (m > slop) slop = m; }
-            if (!(c->polish_tol > 0) || slop <= c->polish_tol || npolish >= POLISH_MAX || it >= c->qp_iter_max) { status = 0; break; }
+        if (res[1] <= c->qp_tol && res[2] <= c->qp_tol && res[3] <= c->qp_tol && (!(orc_investigation() & 4) || res[0] <= c->qp_tol)) {
+            /* POLISH (round 5; shared with the HIP kernels).  Meeting the tolerance does not bound the distance from the QP's solution: with pairs at the floor
+             * or weakly active rows the end-game can contract by only 0.3 .. 0.8 per iteration, and what such a solve left when its products slipped under
+             * qp_tol was the parity tail beyond 1e-6 (up to 1e-5 from the exact solution on 0.5 % of the first solves of C5's problem).
+             * In its superlinear end-game one iteration takes the largest live product c_max down by four orders of magnitude and more; so the solve
+             * continues (at most POLISH_MAX further iterations) while the LAST iteration reduced c_max by less than a factor 1 / polish_ratio:
+             *     c_max(k) > polish_ratio * c_max(k - 1).
+             * Costs nothing to evaluate (c_max is the termination test's own measure) and, measured, no iterations either (+0.0 % on closed loops at N = 20,
+             * +0.1 % on C5's first solves: scripts/polish_probe.py, scripts/oracle_closed_loop_stats.py). */
+            if (!(c->polish_ratio > 0) || npolish >= POLISH_MAX || it >= c->qp_iter_max || !(res[3] > c->polish_ratio * cprev)) { status = 0; break; }
             npolish++;
         }
         /* at the cap: a complementarity measure far above anything a healthy solve shows (<= ~1e2 mu0, early in the iteration) means the QP was on its way
@@ -752,7 +765,13 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
          * with the single bar at 1e4 mu0 the stalled ones straddled it (scripts/fuzz_parity.py, hard obstacle rows) */
         if (it >= c->qp_iter_max) { status = (c->qp_fail_policy == 0 && (mu > MU_CAP_FAILED * c->mu0 || (it >= MU_CAP_SETTLED && mu > c->mu0))) ? 4 : 2; break; }
 
+        cprev = res[3];
         double sigma = 0.0; double alpha = 1.0, alphad = 1.0;
+        /* centring target sigma * min(mu, cmax), cmax = res[3] the largest product of a pair OFF the floor (round 5): pairs whose t sits at the floor keep
+         * products lam * t_floor of 1e-5 and more in the mean mu for ever, and a target sigma * mu dominated by them held the products of the live pairs at
+         * ~1e-11 instead of letting them go to zero (end-game contraction 0.3 .. 0.8 per iteration instead of superlinear).  sigma itself is the ratio of
+         * two means over ALL pairs, as before. */
+        const double mu_c = mu < res[3] ? mu : res[3];
         for (int pass = 0; pass < 2; pass++) {
             /* reduced Hessian / gradient */
             for (int i = 0; i <= N; i++) {
@@ -765,7 +784,7 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
                 double rd = q->c0; for (int a = 0; a < 7; a++) rd += q->cz[a] * I->z[q->stage][a];
                 if (q->kind) rd += I->s[q->sidx];
                 rd -= q->t;
-                double rm = q->lam * q->t - sigma * mu;
+                double rm = q->lam * q->t - sigma * mu_c;
                 if (pass == 1) rm += q->dlam_aff * q->dt_aff;
                 double w = q->lam / q->t, beta = (rm + q->lam * rd) / q->t;
                 if (q->kind == 0) {
@@ -800,7 +819,7 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
                 double dt_ = rd;
                 if (q->kind == 1) dt_ += yds[q->sidx];
                 else { for (int a = 0; a < 7; a++) dt_ += q->cz[a] * dz[q->stage][a]; if (q->kind == 2) dt_ += ds[q->sidx]; }
-                double rm = q->lam * q->t - sigma * mu; if (pass == 1) rm += q->dlam_aff * q->dt_aff;
+                double rm = q->lam * q->t - sigma * mu_c; if (pass == 1) rm += q->dlam_aff * q->dt_aff;
                 double dl = -(rm + q->lam * dt_) / q->t;
                 q->dt_ = dt_; q->dlam = dl;
                 if (dt_ < 0) { double a_ = -q->t / dt_; if (a_ < amax) amax = a_; }

@@ -72,8 +72,10 @@ typedef struct orc_config {
      *      HPIPM solve that returned MAX_ITER (robot_ocp_problem.py:131, :203-205 only reacts to status 4); NaN / overflow / step collapse stay 4.
      * The default is the one the reference's recorded tables select (profiles/r04_fail_policy_replay.json). */
     int qp_fail_policy;
-    /* polish (round 5): after the termination test holds, further iterations (at most 2) while max over the pairs of min(lam, t) > polish_tol; 0 = off */
-    double polish_tol;
+    /* polish (round 5; shared with the HIP kernels, mpc_config.polish_ratio): once the termination test holds, up to 2 further iterations while the last
+     * iteration reduced the largest live complementarity product by less than 1 / polish_ratio (c_max(k) > polish_ratio c_max(k-1): not yet the superlinear
+     * end-game); 0 = off.  Default 1e-2. */
+    double polish_ratio;
 } orc_config;
 
 void orc_default_config(orc_config *c, int N, int n_obst, double Tf);

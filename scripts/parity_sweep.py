@@ -3,7 +3,7 @@ cases use small batches).  For each configuration: B random instances, first sol
 the oracle is fed the GPU's own shifted iterate (identical inputs per solve).  Every converged instance whose GPU and oracle iterates differ by more than
 1e-6 is adjudicated against the exact solution of the exported QP (tests/helpers.py::adjudicate -> exact_qp: an active-set iteration with verified KKT
 conditions); a random sample of the instances that AGREE is measured against it too (the interior point's own floor).
-usage (GPU box): python scripts/parity_sweep.py [quick]      -> gpurun_out/parity_sweep.json (copied to profiles/r04_parity_sweep.json)"""
+usage (GPU box): python scripts/parity_sweep.py [quick]      -> gpurun_out/parity_sweep.json (copied to profiles/r05_parity_sweep.json)"""
 import sys, os, json, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "dynamic-obstacle-avoidance-mpc_amd"), os.path.join(ROOT, "tests")]
@@ -46,6 +46,18 @@ for N, no, B, lps, waves, lanes in CONFIGS:
             du = (np.abs(g["u0"] - o["u0"]).max(1))[ok]
             idx = np.nonzero(ok & (dall > 1e-6))[0]
             adj = [dict(inst=int(b), **adjudicate(orc, cfg, x0[b], P[b], goal[b], Xin[b], Uin[b], X[b], U[b], o["X"][b], o["U"][b])) for b in idx[:MAX_ADJ]]
+            # the measured reason of every instance beyond 1e-6: the same QP on the oracle at qp_tol 1e-12 (floor 1e-13) -- an instance that
+            # then lands on the exact solution was limited by the floor of (t, lam) at the default tolerance, not by the interior point's stopping rule
+            cfg_tight = orc.config(N, no, 0.1 * N, qp_tol=1e-12)
+            for a in adj:
+                b = a["inst"]
+                rt = orc.rti_solve(cfg_tight, x0[b], P[b], goal[b], Xin[b], Uin[b])
+                q = orc.export_qp(cfg, x0[b], P[b], goal[b], Xin[b], Uin[b])
+                vt = step_vector(N, Xin[b], Uin[b], rt["X"], rt["U"])
+                vex, okx, _ = exact_qp(q, vt)
+                a["d_oracle_at_qp_tol_1e-12"] = float(np.abs(vt - vex).max()) if okx and rt["status"] == 0 else None
+                a["floor_limited"] = bool(a["d_oracle_at_qp_tol_1e-12"] is not None and a["d_oracle_at_qp_tol_1e-12"] < 1e-8)
+                a["iters_gpu"], a["iters_oracle"] = int(g["iters"][b]), int(o["iters"][b])
             ex = [a for a in adj if a["kind"] == "exact"]
             rec = dict(step=step, kernel=kernel, status_equal=float((g["status"] == o["status"]).mean()), converged_both=float(ok.mean()),
                        status4_gpu=int((g["status"] == 4).sum()), status4_oracle=int((o["status"] == 4).sum()),

@@ -30,21 +30,31 @@ def work(job):
         for step in range(2):
             P = orc.predict_params(base, ob)
             q = orc.export_qp(base, x, P, goal[b], X, U)
-            vex = None
-            res = {}
+            res, vs = {}, {}
             for t in tols:
-                cfg = orc.config(N, no, 0.1 * N, polish_tol=t)
+                cfg = orc.config(N, no, 0.1 * N, polish_ratio=t)
                 r = orc.rti_solve(cfg, x, P, goal[b], X, U)
                 res[t] = r
+                if r["status"] == 0:
+                    vs[t] = step_vector(N, X, U, r["X"], r["U"])
+            # screening: the exact solution (a dense active-set iteration, seconds per QP at N = 50) only where the variants disagree by more than 2e-7;
+            # elsewhere the recorded figure is the distance from the tightest variant (an estimate, flagged by a negative sign)
+            tight = min((t for t in vs if t > 0), default=None)
+            spread = max((float(np.abs(vs[a] - vs[b2]).max()) for a in vs for b2 in vs), default=0.0)
+            vex = None
+            if spread > 2e-7:
+                vex, ok, info = exact_qp(q, vs[tight if tight is not None else next(iter(vs))])
+                if not ok:
+                    vex = None
+            for t in tols:
+                r = res[t]
                 if r["status"] != 0:
-                    out[str(t)].append((b, step, r["status"], r["iters"], None))
-                    continue
-                v = step_vector(N, X, U, r["X"], r["U"])
-                if vex is None:
-                    vex, ok, info = exact_qp(q, v)
-                    if not ok:
-                        vex = None
-                out[str(t)].append((b, step, 0, r["iters"], None if vex is None else float(np.abs(v - vex).max())))
+                    out[str(t)].append((b, step, r["status"], r["iters"], None)); continue
+                if vex is not None:
+                    d = float(np.abs(vs[t] - vex).max())
+                else:
+                    d = -float(np.abs(vs[t] - vs[tight]).max()) if tight is not None else None
+                out[str(t)].append((b, step, 0, r["iters"], d))
             r = res[tols[0]]
             # closed loop continues on the unpolished (first) variant's result so that every variant sees the same second QP
             X, U = r["X"], r["U"]
@@ -76,11 +86,12 @@ def main():
     for t in tols:
         rows = [r for p in parts for r in p[str(t)]]
         conv = [r for r in rows if r[2] == 0 and r[4] is not None]
-        d = np.array([r[4] for r in conv])
+        d = np.abs(np.array([r[4] for r in conv]))
+        verified = sum(1 for r in conv if r[4] > 0)
         it = np.array([r[3] for r in rows])
-        worst = sorted(conv, key=lambda r: -r[4])[:5]
+        worst = sorted(conv, key=lambda r: -abs(r[4]))[:5]
         summary["variants"][str(t)] = dict(solves=len(rows), converged=len(conv), unverified=sum(1 for r in rows if r[2] == 0 and r[4] is None),
-                                           mean_iters=float(it.mean()), beyond_1e6=int((d > 1e-6).sum()), beyond_1e7=int((d > 1e-7).sum()), beyond_1e5=int((d > 1e-5).sum()),
+                                           mean_iters=float(it.mean()), verified_against_exact=verified, beyond_1e6=int((d > 1e-6).sum()), beyond_1e7=int((d > 1e-7).sum()), beyond_1e5=int((d > 1e-5).sum()),
                                            frac_beyond_1e6=float((d > 1e-6).mean()), worst=float(d.max()), p999=float(np.quantile(d, 0.999)), median=float(np.median(d)),
                                            worst_instances=[(r[0], r[1], r[3], r[4]) for r in worst])
         print(t, json.dumps(summary["variants"][str(t)]))

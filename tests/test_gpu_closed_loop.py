@@ -303,3 +303,66 @@ def test_interpolate_init_guess(env):
                 loops[b].X, loops[b].U = Xh[b].copy(), Uh[b].copy()  # resynchronise: every comparison is one step on identical inputs
                 loops[b].x = dx[b].cpu().numpy().copy(); loops[b].obst = do[b].cpu().numpy().copy()
     assert resets >= 5, resets
+
+
+def test_c2_bench_workload_against_the_oracle_loop(built):
+    """The HEADLINE workload itself: bench.py's C2 scenario -- make_workload("c2"): 1024 copies of the reference generator's seed-0
+    RANDOM draw with its drawn velocities, x0 = [-6, -6, pi/4, 0, 0], goal [6, 6] -- driven exactly as bench.py's timed loop drives it (Loop.reset() +
+    100 fused control steps with the plain flags: no reset after a failed QP, no stop at the goal; the dispatcher's own kernel choice for 1024 instances),
+    and slot 0 and slot 1023 judged STEP BY STEP against tests/helpers.py::OracleLoop (robot_ocp_problem.py:184-260 on the oracle's functions, :195 the
+    solve): status, u*, plant state, obstacle states (bit for bit) and the shifted iterate after every control step.  The oracle loop is re-seeded with
+    the GPU's state before each step, so every step is one comparison on identical inputs; all 1024 slots must stay bitwise equal to slot 0."""
+    import torch
+    import bench
+    import mpc_gpu
+    from oracle import oracle as orc
+    from mpc_gpu.sharding import shard_slice
+    N, no = bench.WORKLOADS["c2"][:2]
+    x0, goal, obst, desc, (lo, hi), G = bench.make_workload("c2", 1, 0, shard_slice)
+    B = hi - lo
+    assert B == 1024 and G == 1024 and desc.startswith("C2")
+    dev = torch.device("cuda", 0)
+    cfg = orc.config(N, no, 0.1 * N)
+    slots = (0, B - 1)
+    with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+        loop = bench.Loop(mpc_gpu, torch, N, no, x0, goal, obst, dev, streams=bench.pick_streams(B))
+        assert loop.streams == 1 and loop.m.kernel_name(B).startswith("rti_split_kernel<3, 3")      # the kernel the bench line names
+        loop.reset()
+        torch.cuda.current_stream().synchronize()
+        ref = {b: OracleLoop(orc, cfg, x0[b], goal[b], obst[b], reset_on_fail=False, alias=False) for b in slots}
+        host = lambda t: t.cpu().numpy()
+        n_conv = n_fail = n_adj = 0
+        worst = 0.0
+        for k in range(bench.EPISODE):
+            before = dict(x0=host(loop.x0), obst=host(loop.obst), X=host(loop.X), U=host(loop.U))
+            loop.control_step()
+            torch.cuda.current_stream().synchronize()
+            after = dict(x0=host(loop.x0), obst=host(loop.obst), X=host(loop.X), U=host(loop.U), u0=host(loop.u0), status=host(loop.status), iters=host(loop.iters))
+            for key in ("x0", "obst", "X", "U", "u0", "status", "iters"):      # identical scenarios: identical results in every slot
+                assert (after[key] == after[key][0:1]).all(), (k, key)
+            for b, L in ref.items():
+                L.x, L.obst, L.X, L.U = before["x0"][b].copy(), before["obst"][b].copy(), before["X"][b].copy(), before["U"][b].copy()
+                L.flags = 0                                                       # the plain loop never stops at the goal
+                r = L.step()
+                assert after["status"][b] == r["status"], (k, b, after["status"][b], r["status"], after["iters"][b], r["iters"])
+                assert np.array_equal(after["obst"][b], L.obst), (k, b)
+                if r["status"] == 4:
+                    n_fail += 1
+                    assert np.array_equal(after["u0"][b], before["U"][b][0])      # a failed QP applies the stored u_0 and leaves the iterate (shifted) as it was
+                if r["status"] != 0:
+                    continue
+                n_conv += 1
+                d = max(np.abs(after["X"][b] - L.X).max(), np.abs(after["U"][b] - L.U).max(), np.abs(after["x0"][b] - L.x).max())
+                if d > 1e-6:
+                    # un-shift is not needed: adjudicate on the step itself from the common iterate
+                    P = orc.predict_params(cfg, before["obst"][b])
+                    rr = orc.rti_solve(cfg, before["x0"][b], P, goal[b], before["X"][b], before["U"][b])
+                    # GPU's un-shifted step: X rows 0..N-2 of the shifted iterate are rows 1..N-1 of the step; adjudicate what is comparable -- the applied control
+                    assert np.abs(after["u0"][b] - rr["u0"]).max() <= 1e-5, (k, b, d)
+                    n_adj += 1
+                else:
+                    assert np.abs(after["u0"][b] - r["u0"]).max() <= 8e-6, (k, b)
+                worst = max(worst, d)
+        del loop
+    assert n_conv >= 150 and n_adj <= 2, (n_conv, n_fail, n_adj, worst)
+    print(f"C2 bench workload, slots {slots}: {n_conv} converged control steps compared, {n_fail} failed QPs (status equal), {n_adj} beyond 1e-6, worst |GPU - oracle| {worst:.2e}")

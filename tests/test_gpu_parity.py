@@ -163,7 +163,7 @@ def test_permutation_invariance_large_batch(env):
         same = g1["status"][perm] == g2["status"]
         assert same.mean() > 0.999
         d = np.abs(X1[perm] - X2).reshape(B, -1).max(1)[same & (g2["status"] == 0)]
-        assert np.median(d) < 1e-12 and np.quantile(d, 0.999) < 1e-6 and d.max() < 1e-4
+        assert np.median(d) < 1e-12 and np.quantile(d, 0.999) < 1e-6 and d.max() < 1e-5
     # spot-check 64 of them against the oracle
     cfg = orc.config(N, no, 2.0)
     idx = perm[:64]
@@ -294,7 +294,7 @@ def test_row_parallel_factorisation_matches_systolic_and_oracle(env, N, no, B, l
         # both paths are equally close to the oracle (debug_rowpar.py); ill-conditioned long horizons move by ~1e-5 under rounding
         # (the second solves start from iterates that already differ by that much; one sensitive instance is allowed at N = 50)
         assert np.median(d) < 1e-10 and np.quantile(d, 0.95) < (1e-7 if N <= 20 else 2e-6)
-        assert d.max() < 1e-6 if N <= 20 else (np.sort(d)[-2] < 1e-5 and d.max() < 1e-4)
+        assert d.max() < 1e-6 if N <= 20 else (np.sort(d)[-2] < 1e-5 and d.max() < 1e-5)
     # against the oracle on the first solve
     cfg = orc.config(N, no, 0.1 * N)
     P = oracle_P(orc, cfg, obst); Xg, Ug = oracle_guess(orc, cfg, x0)
@@ -380,7 +380,7 @@ def test_stage_split_matches_one_lane_per_stage_and_oracle(env, N, no, B):
         d = np.abs(X - o["X"]).reshape(B, -1).max(1)[ok]; dU = np.abs(U - o["U"]).reshape(B, -1).max(1)[ok]
         # an ill-conditioned QP per batch (10 obstacles, long horizons) may sit at the float64 floor of the interior point on EVERY mapping (DESIGN.md
         # section 2): judge_against_oracle above has adjudicated it against the exact solution of the QP and bounded how many there are
-        assert d.max() < 1e-4 and np.quantile(d, 0.9) < 1e-8
+        assert d.max() < 1e-5 and np.quantile(d, 0.9) < 1e-8
         for b in np.nonzero(ok)[0][(d > tol) | (dU > 8 * tol)]:
             assert no == 10 or N > 20, (b, d.max())
         rel = np.abs(g["cost"] - o["cost"])[ok] / np.maximum(1.0, np.abs(o["cost"][ok]))
@@ -482,13 +482,13 @@ def test_three_instances_per_wavefront(env, N, no, B):
         ok = (ga["status"] == 0) & (gb["status"] == 0)
         assert (ga["iters"][ok] == gb["iters"][ok]).mean() >= 0.95
         d = np.abs(Xa - Xb).reshape(B, -1).max(1)[ok]
-        assert np.median(d) < 1e-10 and np.quantile(d, 0.95) < 1e-6 and d.max() < 1e-4
+        assert np.median(d) < 1e-10 and np.quantile(d, 0.95) < 1e-6 and d.max() < 1e-5
     o = orc.rti_solve_batch(cfg, x0, P, goal, Xg, Ug)
     g, X, U = res[21][0]
     assert (g["status"] == o["status"]).all()
     ok = o["status"] == 0
     d = np.abs(X - o["X"]).reshape(B, -1).max(1)[ok]
-    assert np.quantile(d, 0.9) < 1e-8 and d.max() < 1e-4
+    assert np.quantile(d, 0.9) < 1e-8 and d.max() < 1e-5
     adjudicate_batch(orc, cfg, x0, P, goal, Xg, Ug, X, U, o, np.nonzero(ok)[0][d > 1e-6], what="three instances per wavefront")       # against the exact QP solution, as everywhere
     with mpc_gpu.BatchedMpc(21, 3, 2.1, max_batch=4) as s:
         from mpc_gpu import _lib
@@ -524,7 +524,7 @@ def test_full_size_batches_c3_and_c4_share(env, B):
     assert (o["status"] == h1["status"][idx]).all()
     ok = o["status"] == 0
     d = np.abs(o["X"] - X1[idx]).reshape(256, -1).max(1)[ok]
-    assert np.quantile(d, 0.98) < 1e-8 and d.max() < 1e-4
+    assert np.quantile(d, 0.98) < 1e-8 and d.max() < 1e-5
     adjudicate_batch(orc, cfg, x0[idx], P, goal[idx], Xs[idx], Us[idx], X1[idx], U1[idx], o, np.nonzero(ok)[0][d > TOL_X], what="permuted batch")
 
 
@@ -606,7 +606,7 @@ def test_block_riccati_matches_the_oracle_and_the_stagewise_recursion(built, N, 
     assert np.array_equal(g["status"], ref[0]["status"]) and (np.abs(g["iters"].astype(int) - ref[0]["iters"]) <= 2).all()
     ok = g["status"] == 0
     d = np.abs(X - ref[1]).reshape(B, -1).max(1)[ok]
-    assert np.median(d) < 1e-10 and d.max() < (1e-6 if no < 10 else 1e-4)
+    assert np.median(d) < 1e-10 and d.max() < (1e-6 if no < 10 else 1e-5)
     with mpc_gpu.BatchedMpc(N + 1, no, 0.1 * (N + 1), max_batch=4) as s:      # odd horizon: no pairs
         s.set_lanes_per_stage(3 if N + 1 <= 20 else 2); s.set_block_riccati(True)
         assert s.kernel_name(4).endswith("false>")
