@@ -117,6 +117,7 @@ mpc::KParams make_params(const mpc_config &c, int batch)
     p.mu_cap = truncate ? INFINITY : mpc::kMuCapFailed * c.mu0;
     p.mu_settled = truncate ? INFINITY : c.mu0;
     p.polish_ratio = c.polish_ratio > 0.0 ? c.polish_ratio : INFINITY;      // off: c_max > inf * c_prev never holds (inf * 0 = NaN included)
+    p.polish_tol = c.polish_tol > 0.0 ? (float)c.polish_tol : INFINITY;     // off: no estimate exceeds inf
     return p;
 }
 
@@ -443,7 +444,7 @@ int mpc_default_config(mpc_config *c, int N, int n_obst, double Tf)
      * within 25 iterations then needs more than 25 here (profiles/r04_thr0_probe.txt): the reference's own problem size keeps the constant its pin was made with. */
     c->thr0 = n_obst >= 8 ? 0.3 : 0.1;
     c->qp_fail_policy = 0;
-    c->polish_ratio = 1e-2;      // oracle/mpc_oracle.c orc_default_config
+    c->polish_ratio = 1e-2; c->polish_tol = 1e-6;      // oracle/mpc_oracle.c orc_default_config
     return MPC_OK;
 }
 
@@ -455,7 +456,8 @@ int mpc_create(const mpc_config *cfg, int device, int max_batch, mpc_handle **ou
     if (max_batch < 1) return fail(MPC_ERR_ARG, "max_batch must be >= 1");
     if (!(cfg->Tf > 0) || !(cfg->qp_tol > 0) || cfg->qp_iter_max < 1) return fail(MPC_ERR_ARG, "Tf, qp_tol, qp_iter_max must be positive");
     if (cfg->qp_fail_policy != 0 && cfg->qp_fail_policy != 1) return fail(MPC_ERR_ARG, "qp_fail_policy must be 0 (divergence tests) or 1 (truncate at qp_iter_max)");
-    if (!(cfg->polish_ratio >= 0.0) || !(cfg->polish_ratio <= 1.0)) return fail(MPC_ERR_ARG, "polish_ratio must be in [0, 1] (0 = no polish)");
+    if (!(cfg->polish_ratio >= 0.0) || !(cfg->polish_ratio <= 1.0)) return fail(MPC_ERR_ARG, "polish_ratio must be in [0, 1] (0 = that indicator off)");
+    if (!(cfg->polish_tol >= 0.0) || !(cfg->polish_tol <= 1.0)) return fail(MPC_ERR_ARG, "polish_tol must be in [0, 1] (0 = that indicator off)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(MPC_ERR_NODEVICE, "no HIP device visible: libmpcgpu has no CPU path");

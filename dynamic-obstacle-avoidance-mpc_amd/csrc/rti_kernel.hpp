@@ -70,7 +70,8 @@ struct KParams {
     double r2;                // r_safe^2
     double slack_a, slack_b, ss;  // ss: penalty scale for stages < N (dt or 1)
     double tol, mu0, thr0;
-    double polish_ratio;                 // polish of the interior point (kPolishMax); +inf = off (mpc_api.hip::make_params)
+    double polish_ratio;                 // polish of the interior point (kPolishMax), indicator (a); +inf = off (mpc_api.hip::make_params)
+    float polish_tol;                    // ... indicator (b); +inf = off
     double tl_min;                       // floor of t and lam: min(kTLMin, qp_tol / 10) (the floor must stay below the tolerance: an active row's rho - t is the floor)
     double mu_div, mu_cap, mu_settled;   // the divergence tests of the interior point as thresholds on mu (mpc_api.hip::make_params): kMuDiverged mu0, kMuCapFailed mu0, mu0 --
                                          // or, mpc_config.qp_fail_policy = 1 ("truncate"), 1e300 / inf / inf: a diverging solve runs to the iteration cap and ends as status 2
@@ -304,9 +305,14 @@ __device__ __forceinline__ double seg21_reduce(double v, int lane)
 }
 
 // ---- POLISH of the interior point (round 5; shared specification with oracle/mpc_oracle.c ipm_solve) ----
-// Once the termination test holds, an instance takes up to kPolishMax further iterations while its LAST iteration reduced the largest live complementarity
-// product c_max by less than a factor 1 / polish_ratio (c_max(k) > polish_ratio c_max(k - 1)): the interior point is then not yet in its superlinear
-// end-game, and what it leaves behind on meeting qp_tol was the parity tail beyond 1e-6.  c_max is the termination test's own measure: no extra reduction.
+// Once the termination test holds, an instance takes up to kPolishMax further iterations while either indicator holds:
+//  (a) slow end-game: its LAST iteration reduced the largest live complementarity product c_max by less than a factor 1 / polish_ratio
+//      (c_max(k) > polish_ratio c_max(k - 1)) -- c_max is the termination test's own measure: no extra reduction;
+//  (b) a multiplier collapsed to the floor on a weakly active row (complementary, primal feasible: invisible to the termination test) but the last primal
+//      step is still long: for ANY stage, with s the max-norm of the stage's last step alpha * dz, s' of the one before and r = min(s / s', 1/2), the
+//      estimate s r min(1, 10 r) = min(s / 2, s^2 / s', 10 s^3 / s'^2) of what remains exceeds polish_tol.  FLOAT arithmetic without a division, as the oracle's
+//      polish_wanted(); a stage is a lane, so the indicator needs no cross-lane reduction: one ballot (seg_any).
+// What solves left behind when their products slipped under qp_tol was the parity tail beyond 1e-6.
 static constexpr int kPolishMax = 2;
 // MPC_NAN_NOTE.  A NaN / overflow of the row state must end the solve (status 4) as it does in the oracle, where it surfaces in mu at the head of the next
 // iteration.  In the kernels the floors of the update (t = fmax(t + a dt, floor): fmax drops a NaN) would wash it out of t and lam, and a solve that diverged
@@ -324,6 +330,7 @@ static constexpr int kPolishMax = 2;
 struct IpmState {            // per instance (segment-uniform)
     int status = 2, it_done = 0, npolish = 0;
     bool running = true;
+    bool want_step = false;   // polish indicator (b) of the step just taken (ipm_polish_step)
     double cprev = INFINITY;  // c_max at the head of the previous iteration
 };
 // head of iteration `it`: failure by NaN / divergence, convergence (or a polish iteration), iteration cap
@@ -333,7 +340,7 @@ __device__ __forceinline__ void ipm_head(const KParams &p, IpmState &S, int it, 
     if (!(mu == mu) || !(fabs(mu) <= p.mu_div)) { S.status = 4; S.running = false; S.it_done = it; }      // NaN, or diverged: an infeasible QP
     else if (lin <= p.tol && cmax <= p.tol) {
         // converged -- or one more iteration, the polish (kPolishMax; polish off: the ratio is +inf)
-        if (S.npolish < kPolishMax && it < p.iter_max && cmax > p.polish_ratio * S.cprev) S.npolish++;
+        if (S.npolish < kPolishMax && it < p.iter_max && (cmax > p.polish_ratio * S.cprev || S.want_step)) S.npolish++;
         else { S.status = 0; S.running = false; S.it_done = it; }
     }
     else if (it >= p.iter_max) {      // at the cap with mu above a healthy solve's: diverging or stalled, not slow
@@ -360,6 +367,48 @@ __device__ __forceinline__ void ipm_step_lengths(double rmax, double rmaxd, doub
     const double amax = rmax > 1.0 ? 1.0 / rmax : 1.0, amaxd = rmaxd > 1.0 ? 1.0 / rmaxd : 1.0;
     alpha = (amax >= 1.0) ? 1.0 : kFracToBoundary * amax;          // primal step: z, s, t
     alphad = (amaxd >= 1.0) ? 1.0 : kFracToBoundary * amaxd;       // dual step: lam
+}
+// polish indicator (b): est = s r min(1, 10 r) > tol with r = min(s / s', 1/2).  est is the SMALLEST of s / 2, s^2 / s' and 10 s^3 / s'^2 (r >= 1/2: the
+// first; 0.1 < r < 1/2: the second; r <= 0.1: the third), so est > tol is the conjunction of three comparisons -- no division, no case selection, float
+// arithmetic, every product left to right exactly as oracle/mpc_oracle.c::polish_wanted forms it.
+__device__ __forceinline__ bool polish_wanted(float s, float sp, float tol)
+{
+    float pa = 0.5f * s, pb = s * s, qb = tol * sp, pc = 10.0f * s * s * s, qc = tol * sp * sp;
+    asm volatile("" : "+v"(pa), "+v"(pb), "+v"(qb), "+v"(pc), "+v"(qc));      // (products pinned: what is left are three compares and two mask ANDs -- nothing to branch around)
+    return (pa > tol) & (pb > qb) & (pc > qc);
+}
+// does any lane of the calling lane's G-lane segment hold `w`?  One ballot; the segment mask is a per-lane constant.
+template <int G>
+__device__ __forceinline__ bool seg_any(bool w, int lane)
+{
+    const unsigned long long b = __ballot(w);
+    if (G == 64) return b != 0ull;
+    unsigned long long m;
+    if (G == 32) m = lane < 32 ? 0xffffffffull : 0xffffffff00000000ull;
+    else if (G == 16) m = 0xffffull << (lane & 48);
+    else m = 0x1fffffull << (21 * seg21_slot(lane));      // G = 21: lanes [0, 21), [21, 42), [42, 63)
+    return (b & m) != 0ull;
+}
+// after the step lengths are known: this lane's (stage's) step norm, its estimate against polish_tol, the segment's verdict for the next head
+template <int G>
+__device__ __forceinline__ void ipm_polish_step(const KParams &p, IpmState &S, int lane, double alpha, const double dz[7], float &stepl)
+{
+    // (float)max|dz| = max|(float)dz|: round-to-nearest is monotone, so the maximum is taken on the floats (v_max3_f32 with |.| modifiers: 3 instructions)
+    const float f0 = (float)dz[0], f1 = (float)dz[1], f2 = (float)dz[2], f3 = (float)dz[3], f4 = (float)dz[4], f5 = (float)dz[5], f6 = (float)dz[6];
+    const float dm = fmaxf(fmaxf(fmaxf(fabsf(f0), fabsf(f1)), fabsf(f2)), fmaxf(fmaxf(fmaxf(fabsf(f3), fabsf(f4)), fabsf(f5)), fabsf(f6)));
+    const float sn = (float)alpha * dm;
+    const bool w = polish_wanted(sn, stepl, p.polish_tol);      // (polish_tol = +inf: indicator off)
+    stepl = sn;
+    S.want_step = seg_any<G>(w, lane);
+}
+// A step that is not finite is not a step (MPC_NAN_NOTE): an overflow that reached z without passing through mu or sigma (the last iteration of a solve that
+// diverged under qp_fail_policy 1 takes alpha = 1 on an infinite direction, and the floors then wash the row state clean) ends as status 4, iterate untouched,
+// as in the oracle, whose measured residuals are NaN then.  Once per solve, after the loop.
+template <int G>
+__device__ __forceinline__ int ipm_finite_step(int status, const double z[7], int lane)
+{
+    const double fin = z[0] + z[1] + z[2] + z[3] + z[4] + z[5] + z[6];
+    return seg_any<G>(!(fabs(fin) <= 1e300), lane) ? 4 : status;
 }
 // step collapse, or a NaN of the row state (MPC_NAN_NOTE): status 4
 __device__ __forceinline__ void ipm_step_check(IpmState &S, int it, double alpha, double alphad, double smu)
@@ -2246,6 +2295,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     ipm.running = !ep_done;
     int &status = ipm.status, &it_done = ipm.it_done;
     bool &running = ipm.running;
+    float stepl = 0.0f;       // this lane's (stage's) last step norm, for the polish (ipm_polish_step)
     if (!(lin0 <= 1e300)) { status = 4; running = false; }
 
 #ifdef MPC_PHASE_TIMING
@@ -2773,6 +2823,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             if (p.trace && i == 0 && valid && running) p.trace[((size_t)inst * p.iter_max + it) * 4 + 2] = alpha;
 #endif
             ipm_step_check(ipm, it, alpha, alphad, smu);
+            ipm_polish_step<G>(p, ipm, lane, alpha, dz, stepl);
             {   // An instance that has stopped keeps its step z (a select, not a step of length zero: what a converged instance computes while it idles
                 // beside a neighbour that still iterates is a Newton step from a state with slacks at their floor -- it may be Inf or NaN, and 0 * NaN
                 // is NaN).  Its row state is no longer read by anything and simply moves on, as do the rows that do not exist.
@@ -3293,6 +3344,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             if (p.trace && i == 0 && valid && running) p.trace[((size_t)inst * p.iter_max + it) * 4 + 2] = alpha;
 #endif
             ipm_step_check(ipm, it, alpha, alphad, smu);
+            ipm_polish_step<G>(p, ipm, lane, alpha, dz, stepl);
             if (running) {
 #pragma unroll
                 for (int c = 0; c < 7; c++) z[c] += alpha * dz[c];
@@ -3373,6 +3425,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     const double t_Wg[6] = {pt->Wg[0], pt->Wg[1], pt->Wg[2], pt->Wg[3], pt->Wg[4], pt->Wg[5]}, t_Weg[4] = {pt->Weg[0], pt->Weg[1], pt->Weg[2], pt->Weg[3]};
     // ---- full step on the iterate; status 4 leaves it unchanged ----
     const bool store = valid && !ep_done;
+    status = ipm_finite_step<G>(status, z, lane);
     if (status != 4) {
 #pragma unroll
         for (int c = 0; c < 5; c++) xi[c] += z[2 + c];

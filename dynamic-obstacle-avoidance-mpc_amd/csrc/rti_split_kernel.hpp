@@ -367,6 +367,7 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
     ipm.running = !ep_done;
     int &status = ipm.status, &it_done = ipm.it_done;
     bool &running = ipm.running;
+    float stepl = 0.0f;       // this lane's (stage's) last step norm, for the polish (ipm_polish_step)
     if (!(lin0 <= 1e300)) { status = 4; running = false; }
 
     MPC_TICK(13);
@@ -979,6 +980,7 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
             if (p.trace && lane == 0) p.trace[((size_t)inst * p.iter_max + it) * 4 + 2] = alpha;
 #endif
             ipm_step_check(ipm, it, alpha, alphad, smu);
+            ipm_polish_step<64>(p, ipm, lane, alpha, dz, stepl);
             if (running) {
 #pragma unroll
                 for (int c = 0; c < 7; c++) z[c] += alpha * dz[c];
@@ -1017,6 +1019,7 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
     }
     // ---- full step on the iterate; status 4 leaves it unchanged ----
     const bool store = !ep_done;
+    status = ipm_finite_step<64>(status, z, lane);
     if (status != 4) {
 #pragma unroll
         for (int c = 0; c < 5; c++) xi[c] += z[2 + c];

@@ -40,7 +40,7 @@ extern "C" {
 #define MPC_NU 2
 
 /* Version of this header's binary interface: bumped whenever `struct mpc_config` changes size or layout or an entry point changes its signature
- * (round 4: trailing field qp_fail_policy, +8 bytes; round 5, version 6: trailing field polish_ratio, +8 bytes, mpc_abi_version itself).  A host compares it with mpc_abi_version() of the library it loaded BEFORE it calls
+ * (round 4: trailing field qp_fail_policy, +8 bytes; round 5, version 6: trailing fields polish_ratio, polish_tol, +16 bytes, mpc_abi_version itself).  A host compares it with mpc_abi_version() of the library it loaded BEFORE it calls
  * mpc_default_config / mpc_create: a host built against an older struct would otherwise be written past its end.  (No reference counterpart: acados
  * regenerates and recompiles its C interface per problem.) */
 #define MPC_ABI_VERSION 6
@@ -78,10 +78,13 @@ typedef struct mpc_config {
                                1: "truncate" -- no divergence test: the interior point runs to qp_iter_max and its step is applied (status 2), as acados'
                                   SQP_RTI did with a HPIPM solve that returned MAX_ITER; NaN / overflow / step collapse stay status 4.
                                default: what the reference's recorded tables select                                    */
-    double polish_ratio;    /* polish of the interior point (round 5): a solve that meets qp_tol takes up to 2 further iterations while its last iteration reduced the largest
-                               live complementarity product by less than 1 / polish_ratio (c_max(k) > polish_ratio c_max(k-1): not yet the superlinear end-game);
-                               0 = off.  Default 1e-2: removes the tail of solves that met the tolerance 1e-6 .. 1e-5 from the QP's exact solution at +0.05 %
-                               iterations.  (The qp_solver tolerances of robot_ocp_problem.py:126-132 are left at acados' defaults there.) */
+    double polish_ratio;    /* polish of the interior point (round 5): a solve that meets qp_tol takes up to 2 further iterations while (a) its last iteration reduced the largest
+                               live complementarity product by less than 1 / polish_ratio (c_max(k) > polish_ratio c_max(k-1): not yet the superlinear end-game), or */
+    double polish_tol;      /* (b) for any stage the estimate s r min(1, 10 r) of the remaining primal error exceeds polish_tol (s: max-norm of the stage's last step,
+                               r = min(s / previous s, 1/2): a multiplier that collapsed to the floor on a weakly active row leaves the termination test blind but the
+                               step long).  0 = that indicator off.  Defaults 1e-2 and 1e-6 (the stated parity tolerance): the solves that met the tolerance 1e-6 .. 2e-5
+                               from the QP's exact solution (0.7 % of the first solves of BASELINE configs[4]'s problem) are gone at +0.5 % iterations (DESIGN.md
+                               section 2).  (The qp_solver tolerances of robot_ocp_problem.py:126-132 are left at acados' defaults there.) */
 } mpc_config;
 
 typedef struct mpc_handle mpc_handle;

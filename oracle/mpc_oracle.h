@@ -74,8 +74,9 @@ typedef struct orc_config {
     int qp_fail_policy;
     /* polish (round 5; shared with the HIP kernels, mpc_config.polish_ratio): once the termination test holds, up to 2 further iterations while the last
      * iteration reduced the largest live complementarity product by less than 1 / polish_ratio (c_max(k) > polish_ratio c_max(k-1): not yet the superlinear
-     * end-game); 0 = off.  Default 1e-2. */
-    double polish_ratio;
+     * end-game), or (polish_tol) while for any stage the estimate s r min(1, 10 r) of the remaining primal error exceeds polish_tol (s: max-norm of the stage's
+     * last step, r = min(s / previous s, 1/2)); 0 = that indicator off.  Defaults 1e-2 and 1e-6 (the stated parity tolerance). */
+    double polish_ratio, polish_tol;
 } orc_config;
 
 void orc_default_config(orc_config *c, int N, int n_obst, double Tf);
