@@ -17,6 +17,7 @@ int main(int argc, char **argv)
     const int steps = argc > 1 ? atoi(argv[1]) : 40;
     mpc_config cfg;
     mpc_handle *h = NULL;
+    if (mpc_abi_version() != MPC_ABI_VERSION) { fprintf(stderr, "libmpcgpu has ABI version %d, this host was built against %d\n", mpc_abi_version(), MPC_ABI_VERSION); return 1; }
     if (mpc_default_config(&cfg, 20, N_OBST, 2.0) || mpc_create(&cfg, 0, B, &h)) { fprintf(stderr, "mpc_create: %s\n", mpc_last_error()); return 1; }
     double x[B][5], goal[B][2], obst[B][N_OBST][4], u0[B][2], cost[B], xn[B][5], total[B] = {0};
     int32_t status[B], iters[B], failed[B] = {0};
