@@ -43,7 +43,7 @@ def main():
         out.append(f"{(NAMES[k] if k < len(NAMES) else str(k)):52s}" + "".join(f"{c.get(x, 0):13d}" for x in cols))
     text = "\n".join(out)
     print(text)
-    open(os.path.join(ROOT, "profiles", f"r03_solve_{nobst}_{g}_{fact}_phase_instruction_counts.txt"), "w").write(text + "\n")
+    open(os.path.join(ROOT, "profiles", f"{os.environ.get('MPC_PROFILE_TAG', 'r05')}_solve_{nobst}_{g}_{fact}_phase_instruction_counts.txt"), "w").write(text + "\n")
 
 
 if __name__ == "__main__":

@@ -82,18 +82,19 @@ def test_cost_allgather_world_size_2_gloo(built, tmp_path):
 _DRY = {}
 
 
-def _bench_dry_run(workload, fresh=False):
+def _bench_dry_run(workload, fresh=False, world=2):
     import json
-    if workload in _DRY and not fresh:
-        return _DRY[workload]
+    key = workload if world == 2 else (workload, world)
+    if key in _DRY and not fresh:
+        return _DRY[key]
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--workload", workload, "--steps", "1",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dry-run", "--workload", workload, "--steps", "1",
                         "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    _DRY.setdefault(workload, line)
+    _DRY.setdefault(key, line)
     return line
 
 
@@ -108,6 +109,17 @@ def test_bench_multi_rank_path_world_size_2_gloo(built, workload, total):
     assert line["config"]["rank0_slice"] == [0, total // 2] and line["scaling"] == ("weak" if workload == "c2" else "strong")
     # the id plumbing of the C-ABI exchange (--exchange capi, the default): every rank ended with rank 0's 128 bytes (gather_check covers it)
     assert line["exchange"] == "capi" and isinstance(line["comm_id_sha1"], str) and len(line["comm_id_sha1"]) == 40
+
+
+@pytest.mark.parametrize("workload,total,per_rank", [("c4", 262144, 32768), ("c5", 32768, 4096)])
+def test_bench_eight_rank_form_of_the_sharded_workloads_gloo(built, workload, total, per_rank):
+    """BASELINE configs[3] and [4] in their 8-RANK form (the driver's `--gpus 8`): eight processes, gloo, the same plumbing as the two-rank rehearsal --
+    rank r holds shard_slice(total, r, 8) = 32768 (C4) / 4096 (C5) instances, the cost histories of all eight ranks arrive rank-major, every rank ends with
+    rank 0's communicator id.  (One GPU exercises a single rank's share of these workloads; this is the slicing and gather order of all eight.)"""
+    line = _bench_dry_run(workload, world=8)
+    assert line["n_gpus"] == 8 and line["gather_check"] is True and line["scaling"] == "strong"
+    assert line["config"]["global_batch"] == total and line["config"]["rank0_slice"] == [0, per_rank] and line["config"]["x0_shape"] == [per_rank, 5]
+    assert line["exchange"] == "capi" and len(line["comm_id_sha1"]) == 40
 
 
 def test_comm_unique_id_differs_between_runs(built):
