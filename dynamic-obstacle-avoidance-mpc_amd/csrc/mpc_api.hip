@@ -118,6 +118,7 @@ mpc::KParams make_params(const mpc_config &c, int batch)
     p.mu_settled = truncate ? INFINITY : c.mu0;
     p.polish_ratio = c.polish_ratio > 0.0 ? c.polish_ratio : INFINITY;      // off: c_max > inf * c_prev never holds (inf * 0 = NaN included)
     p.polish_tol = c.polish_tol > 0.0 ? (float)c.polish_tol : INFINITY;     // off: no estimate exceeds inf
+    p.polish_tol_unsolved = c.polish_tol > 0.0 ? mpc::kPolishUnsolved * (float)c.polish_tol : INFINITY;
     return p;
 }
 

@@ -72,6 +72,7 @@ struct KParams {
     double tol, mu0, thr0;
     double polish_ratio;                 // polish of the interior point (kPolishMax), indicator (a); +inf = off (mpc_api.hip::make_params)
     float polish_tol;                    // ... indicator (b); +inf = off
+    float polish_tol_unsolved;           // kPolishUnsolved x polish_tol: the estimate above which a solve that has used up its polish is reported as not converged (status 2)
     double tl_min;                       // floor of t and lam: min(kTLMin, qp_tol / 10) (the floor must stay below the tolerance: an active row's rho - t is the floor)
     double mu_div, mu_cap, mu_settled;   // the divergence tests of the interior point as thresholds on mu (mpc_api.hip::make_params): kMuDiverged mu0, kMuCapFailed mu0, mu0 --
                                          // or, mpc_config.qp_fail_policy = 1 ("truncate"), 1e300 / inf / inf: a diverging solve runs to the iteration cap and ends as status 2
@@ -314,6 +315,7 @@ __device__ __forceinline__ double seg21_reduce(double v, int lane)
 //      polish_wanted(); a stage is a lane, so the indicator needs no cross-lane reduction: one ballot (seg_any).
 // What solves left behind when their products slipped under qp_tol was the parity tail beyond 1e-6.
 static constexpr int kPolishMax = 2;
+static constexpr float kPolishUnsolved = 100.0f;      // oracle/mpc_oracle.c POLISH_UNSOLVED
 // MPC_NAN_NOTE.  A NaN / overflow of the row state must end the solve (status 4) as it does in the oracle, where it surfaces in mu at the head of the next
 // iteration.  In the kernels the floors of the update (t = fmax(t + a dt, floor): fmax drops a NaN) would wash it out of t and lam, and a solve that diverged
 // under qp_fail_policy 1 would come back "converged" with every pair at the floor and the linear residual at 0 (found by the truncate-policy test once the
@@ -330,7 +332,8 @@ static constexpr int kPolishMax = 2;
 struct IpmState {            // per instance (segment-uniform)
     int status = 2, it_done = 0, npolish = 0;
     bool running = true;
-    bool want_step = false;   // polish indicator (b) of the step just taken (ipm_polish_step)
+    bool want_step = false;   // polish indicator (b) of the step just taken (ipm_polish_step) ...
+    bool unsolved = false;    // ... and the same estimate against kPolishUnsolved x polish_tol: an end-game that is not a tail but a QP left unsolved
     double cprev = INFINITY;  // c_max at the head of the previous iteration
 };
 // head of iteration `it`: failure by NaN / divergence, convergence (or a polish iteration), iteration cap
@@ -339,8 +342,12 @@ __device__ __forceinline__ void ipm_head(const KParams &p, IpmState &S, int it, 
     if (!S.running) return;
     if (!(mu == mu) || !(fabs(mu) <= p.mu_div)) { S.status = 4; S.running = false; S.it_done = it; }      // NaN, or diverged: an infeasible QP
     else if (lin <= p.tol && cmax <= p.tol) {
-        // converged -- or one more iteration, the polish (kPolishMax; polish off: the ratio is +inf)
-        if (S.npolish < kPolishMax && it < p.iter_max && (cmax > p.polish_ratio * S.cprev || S.want_step)) S.npolish++;
+        // converged -- or one more iteration, the polish (kPolishMax; polish off: the ratio is +inf) -- or NOT SOLVED: the polish is used up and the step
+        // estimate still stands two orders of magnitude above polish_tol (an end-game whose Newton steps have lost their accuracy to the barrier weights
+        // lam / t_floor; oracle ipm_solve): the step is applied as after an iteration cap, status 2, instead of being reported as converged
+        const bool want = cmax > p.polish_ratio * S.cprev || S.want_step;
+        if (want && S.npolish >= kPolishMax && S.unsolved) { S.status = 2; S.running = false; S.it_done = it; }
+        else if (want && S.npolish < kPolishMax && it < p.iter_max) S.npolish++;
         else { S.status = 0; S.running = false; S.it_done = it; }
     }
     else if (it >= p.iter_max) {      // at the cap with mu above a healthy solve's: diverging or stalled, not slow
@@ -371,11 +378,12 @@ __device__ __forceinline__ void ipm_step_lengths(double rmax, double rmaxd, doub
 // polish indicator (b): est = s r min(1, 10 r) > tol with r = min(s / s', 1/2).  est is the SMALLEST of s / 2, s^2 / s' and 10 s^3 / s'^2 (r >= 1/2: the
 // first; 0.1 < r < 1/2: the second; r <= 0.1: the third), so est > tol is the conjunction of three comparisons -- no division, no case selection, float
 // arithmetic, every product left to right exactly as oracle/mpc_oracle.c::polish_wanted forms it.
-__device__ __forceinline__ bool polish_wanted(float s, float sp, float tol)
+__device__ __forceinline__ void polish_wanted(float s, float sp, float tol, float tol_unsolved, bool &want, bool &unsolved)
 {
-    float pa = 0.5f * s, pb = s * s, qb = tol * sp, pc = 10.0f * s * s * s, qc = tol * sp * sp;
-    asm volatile("" : "+v"(pa), "+v"(pb), "+v"(qb), "+v"(pc), "+v"(qc));      // (products pinned: what is left are three compares and two mask ANDs -- nothing to branch around)
-    return (pa > tol) & (pb > qb) & (pc > qc);
+    float pa = 0.5f * s, pb = s * s, qb = tol * sp, pc = 10.0f * s * s * s, qc = tol * sp * sp, rb = tol_unsolved * sp, rc = tol_unsolved * sp * sp;
+    asm volatile("" : "+v"(pa), "+v"(pb), "+v"(qb), "+v"(pc), "+v"(qc), "+v"(rb), "+v"(rc));      // (products pinned: what is left are compares and mask ANDs -- nothing to branch around)
+    want = (pa > tol) & (pb > qb) & (pc > qc);
+    unsolved = (pa > tol_unsolved) & (pb > rb) & (pc > rc);      // the same estimate against kPolishUnsolved x polish_tol (KParams::polish_tol_unsolved)
 }
 // does any lane of the calling lane's G-lane segment hold `w`?  One ballot; the segment mask is a per-lane constant.
 template <int G>
@@ -397,9 +405,10 @@ __device__ __forceinline__ void ipm_polish_step(const KParams &p, IpmState &S, i
     const float f0 = (float)dz[0], f1 = (float)dz[1], f2 = (float)dz[2], f3 = (float)dz[3], f4 = (float)dz[4], f5 = (float)dz[5], f6 = (float)dz[6];
     const float dm = fmaxf(fmaxf(fmaxf(fabsf(f0), fabsf(f1)), fabsf(f2)), fmaxf(fmaxf(fmaxf(fabsf(f3), fabsf(f4)), fabsf(f5)), fabsf(f6)));
     const float sn = (float)alpha * dm;
-    const bool w = polish_wanted(sn, stepl, p.polish_tol);      // (polish_tol = +inf: indicator off)
+    bool w, u;
+    polish_wanted(sn, stepl, p.polish_tol, p.polish_tol_unsolved, w, u);      // (polish_tol = +inf: indicator off)
     stepl = sn;
-    S.want_step = seg_any<G>(w, lane);
+    S.want_step = seg_any<G>(w, lane); S.unsolved = seg_any<G>(u, lane);
 }
 // A step that is not finite is not a step (MPC_NAN_NOTE): an overflow that reached z without passing through mu or sigma (the last iteration of a solve that
 // diverged under qp_fail_policy 1 takes alpha = 1 on an infinite direction, and the floors then wash the row state clean) ends as status 4, iterate untouched,

@@ -13,7 +13,8 @@
  *       X[B][N+1][5], U[B][N][2], u0[B][2], cost[B]; status/iters are int32[B].
  *     State is [x, y, psi, v, omega], control is [u_a, u_alpha] (src/models/robot_model.py:14-25).
  *   - per-instance solver status uses the acados codes the reference inspects
- *     (robot_ocp_problem.py:203): 0 ok, 2 QP hit qp_iter_max (step still applied), 4 QP failure (no step).
+ *     (robot_ocp_problem.py:203): 0 ok, 2 QP not converged -- it hit qp_iter_max, or its polish ended with the step estimate still 100 polish_tol
+ *     (mpc_config.polish_tol) -- and its step is still applied, 4 QP failure (no step).
  *   - functions without the _dev suffix take HOST pointers and copy; they synchronise before returning.
  *     _dev functions take DEVICE pointers, enqueue on `stream` (a hipStream_t passed as void*, NULL = the
  *     handle's own stream) and do not synchronise.

@@ -696,12 +696,17 @@ static void residuals(const qp_t *Q, iter_t *I, double (*rg)[NZ], double *rs, do
 #define MU_CAP_FAILED 1e4
 #define MU_CAP_SETTLED 20
 #define POLISH_MAX 2
+#define POLISH_UNSOLVED 100.0f   /* a solve whose step estimate is still this many polish_tol after the polish is reported as not converged (status 2) */
 #define FRAC_TO_BOUNDARY 0.999995   /* step = this fraction of the largest step that keeps t, lam > 0 */
 static double *g_trace = NULL; static int g_trace_cap = 0;
 void orc_set_trace(double *buf, int cap) { g_trace = buf; g_trace_cap = cap; }
 
 /* the polish's step indicator: est = s r min(1, 10 r) > tol with r = min(s / s', 1/2).  est is the smallest of s / 2, s^2 / s' and 10 s^3 / s'^2, so the test is
  * the conjunction of three comparisons: float arithmetic, no division, products left to right (rti_kernel.hpp::polish_wanted does exactly this) */
+static _Thread_local int g_last_dead = 0, g_last_npolish = 0; static _Thread_local float g_last_step = 0;
+int orc_last_dead_pairs(void) { return g_last_dead; }
+int orc_last_npolish(void) { return g_last_npolish; }
+double orc_last_step_norm(void) { return (double)g_last_step; }
 static int polish_wanted(float s, float sp, float tol)
 {
     const float pa = 0.5f * s, pb = s * s, qb = tol * sp, pc = 10.0f * s * s * s, qc = tol * sp * sp;
@@ -770,8 +775,16 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
              *      polish_wanted(), so that both sides decide alike; per stage because a stage is a lane of the kernels: no cross-lane reduction, one ballot.
              * Measured (scripts/polish_probe.py on 8000 first / second solves of C5's problem): beyond 1e-6 from the exact solution 55 -> 0, beyond 1e-7
              * 144 -> 25, at +0.5 % iterations. */
-            int want = c->polish_ratio > 0 && res[3] > c->polish_ratio * cprev;
-            if (c->polish_tol > 0) for (int i = 0; i <= N; i++) want = want || polish_wanted(st_now[i], st_prev[i], (float)c->polish_tol);
+            int want = c->polish_ratio > 0 && res[3] > c->polish_ratio * cprev, unsolved = 0;
+            if (c->polish_tol > 0) for (int i = 0; i <= N; i++) {
+                want = want || polish_wanted(st_now[i], st_prev[i], (float)c->polish_tol);
+                unsolved = unsolved || polish_wanted(st_now[i], st_prev[i], POLISH_UNSOLVED * (float)c->polish_tol);
+            }
+            /* NOT SOLVED: the polish is used up and the step estimate still stands two orders of magnitude above polish_tol.  That is not a tail but an end-game
+             * whose Newton steps have lost their accuracy to the barrier weights lam / t_floor (found by scripts/fuzz_parity.py: a stale warm start, every
+             * termination test at zero, the "solution" 2e-2 from the QP's -- and 8e-3 under round 4's rules): the step is applied as after an iteration cap,
+             * status 2, instead of being reported as converged.  Healthy solves that use up the polish end with estimates <= 3e-6 (measured, 4 problem sizes). */
+            if (want && npolish >= POLISH_MAX && unsolved) { status = 2; break; }
             if (!want || npolish >= POLISH_MAX || it >= c->qp_iter_max) { status = 0; break; }
             npolish++;
         }
@@ -856,7 +869,7 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
                 alphad = FRAC_TO_BOUNDARY * amaxd; if (amaxd >= 1.0) alphad = 1.0;
             }
         }
-        if (g_trace && it < g_trace_cap) { g_trace[4 * it] = mu; g_trace[4 * it + 1] = sigma; g_trace[4 * it + 2] = alpha; g_trace[4 * it + 3] = res[3]; }
+        if (g_trace && it < g_trace_cap) { g_trace[4 * it] = mu; g_trace[4 * it + 1] = getenv("ORC_TRACE_ALPHAD") ? alphad : sigma; g_trace[4 * it + 2] = alpha; g_trace[4 * it + 3] = res[3]; }
         if (!(alpha > 1e-14) || !(alphad > 1e-14)) { status = 4; break; }
         for (int i = 0; i <= N; i++) {      /* per-stage step norms for the polish: (float)alpha * (float)max_a |dz_i[a]| */
             double m_ = 0; for (int a = 0; a < 7; a++) { double m = fabs(dz[i][a]); if (m > m_) m_ = m; }
@@ -869,6 +882,11 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
             if (q->t < TL_MIN) q->t = TL_MIN;      /* floors as in HPIPM's t_min / lam_min [acados-knowledge]: keep */
             if (q->lam < TL_MIN) q->lam = TL_MIN;  /* lam/t finite once a pair has collapsed below rounding        */
         }
+    }
+    {   /* diagnostics of the last solve on this thread (orc_last_dead_pairs): pairs with BOTH t and lam at the floor -- complementary whatever the row does */
+        int dead = 0; for (int e = 0; e < ni; e++) if (Q->it[e].t <= 2 * TL_MIN && Q->it[e].lam <= 2 * TL_MIN) dead++;
+        g_last_dead = dead; g_last_npolish = npolish;
+        g_last_step = 0; for (int i = 0; i <= N; i++) if (st_now[i] > g_last_step) g_last_step = st_now[i];
     }
     if (iters_out) *iters_out = it;
     if (kkt) for (int a = 0; a < 4; a++) kkt[a] = res[a];

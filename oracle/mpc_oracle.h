@@ -142,6 +142,8 @@ int orc_export_qp(const orc_config *c, const double *x0, const double *P, const 
                   double *H, double *g, double *Aeq, double *beq, double *lb, double *ub,
                   double *Cs, double *hs, double *zs, double *Zs);
 
+/* debugging aid: number of pairs of the calling thread's last solve that ended with BOTH t and lam at the floor ("dead": complementary whatever the row does) */
+int orc_last_dead_pairs(void);
 /* debugging aid: record (mu, sigma, alpha, cmax) of every IPM iteration of subsequent single solves into buf[4*cap] */
 void orc_set_trace(double *buf, int cap);
 

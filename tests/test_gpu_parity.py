@@ -7,7 +7,7 @@ qp_tol = 1e-10 (the library's and the oracle's default) and cap QP_ITER = 50, so
 import numpy as np
 import pytest
 
-from helpers import adjudicate_batch, judge_against_oracle, oracle_P, oracle_guess, qp_merit, random_batch
+from helpers import adjudicate, adjudicate_batch, judge_against_oracle, oracle_P, oracle_guess, qp_merit, random_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -867,3 +867,32 @@ def test_qp_fail_policy_truncate_against_the_oracle(env):
     assert (res[50, 1][0]["iters"][bad] >= res[50, 0][0]["iters"][bad]).all()      # without the divergence test the failure is noticed later (step collapse)
     for cap in (10, 50):           # feasible instances: bit for bit the same under both policies
         assert np.array_equal(res[cap, 0][1][good], res[cap, 1][1][good]) and np.array_equal(res[cap, 0][0]["status"][good], res[cap, 1][0]["status"][good])
+
+
+def test_an_unsolved_end_game_is_reported_not_passed_off_as_converged(env):
+    """Found by scripts/fuzz_parity.py (round 5; 1 of 2.6e6 solves): N = 47, one obstacle, a shifted warm start against an x0 that has NOT advanced.  Every
+    termination test of the interior point reads zero (linear residuals, largest live complementarity product), the active set is the exact solution's, and the
+    "solution" is 2e-2 from it (8e-3 under round 4's rules; stationarity residual 0.4): the end-game's Newton steps have lost their accuracy to the barrier
+    weights lam / t_floor.  The polish's step estimate sees it -- after the two polish iterations it still stands at 2e-2, four orders of magnitude above what a
+    healthy solve ends with -- and the solve is reported as NOT converged: status 2 (step applied, as after an iteration cap) on BOTH sides.  The instance's
+    neighbours in the batch are unaffected and judged as usual."""
+    mpc_gpu, orc = env
+    N, no, B, seed, bad = 47, 1, 1500, 863992655, 155
+    x0, goal, obst = random_batch(B, no, seed=seed)
+    keep = np.arange(bad - 20, bad + 21)                       # the instance and forty neighbours
+    x0, goal, obst = x0[keep], goal[keep], obst[keep]
+    bad = 20
+    cfg = orc.config(N, no, 0.1 * N)
+    P = oracle_P(orc, cfg, obst); X, U = oracle_guess(orc, cfg, x0)
+    o0 = orc.rti_solve_batch(cfg, x0, P, goal, X, U)
+    Xs, Us = zip(*[orc.shift(cfg, o0["X"][b], o0["U"][b]) for b in range(len(keep))])
+    Xs, Us = np.stack(Xs), np.stack(Us)
+    o = orc.rti_solve_batch(cfg, x0, P, goal, Xs, Us)            # the same x0 again: the stale warm start
+    with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=len(keep)) as s:
+        s.set_warmstart(Xs, Us); g = s.solve(x0, P, goal); Xg, Ug = s.get_traj(len(keep))
+    assert o["status"][bad] == 2 and g["status"][bad] == 2, (o["status"][bad], g["status"][bad], o["iters"][bad], g["iters"][bad])
+    assert o["iters"][bad] < cfg.qp_iter_max and abs(int(g["iters"][bad]) - int(o["iters"][bad])) <= 2      # not the cap: the "unsolved" rule
+    a = adjudicate(orc, cfg, x0[bad], P[bad], goal[bad], Xs[bad], Us[bad], Xg[bad], Ug[bad], o["X"][bad], o["U"][bad])
+    assert a["kind"] == "exact" and a["d_oracle"] > 1e-3        # it really is far from the QP's solution: the status must not be 0
+    n = judge_against_oracle(orc, cfg, x0, P, goal, Xs, Us, g, Xg, Ug, o)
+    assert n["converged"] >= len(keep) - 6, n

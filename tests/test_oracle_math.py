@@ -293,3 +293,56 @@ def test_exact_qp_verifies_and_the_interior_point_is_within_the_tolerance_of_it(
     assert n_ver >= 0.9 * (r["status"] == 0).sum() and n_ver >= 0.5 * B          # (with hard rows a third of these random QPs is infeasible: status 4)
     d = np.array(d)
     assert d.max() < 1e-5 and np.quantile(d, 0.9) < 1e-7, (d.max(), np.quantile(d, 0.9))
+
+
+def test_polish_and_the_unsolved_rule_on_the_oracle():
+    """The interior point's polish (docs/PROBLEM.md section 2) on the oracle alone: (1) an instance of the parity tail -- C5's problem, a first solve that
+    meets every termination test 1.7e-5 from the exact solution without the polish -- ends within 1e-6 of it with the polish, at no more than 2 extra
+    iterations; (2) the fuzz finding (a stale warm start at N = 47: "converged" 2e-2 from the QP's solution) is reported as status 2, not 0; (3) healthy
+    solves are not touched: same statuses, iterations within +1.5 % on a closed loop."""
+    from oracle import oracle as orc
+    from helpers import exact_qp, random_batch, step_vector
+    # (1)
+    N, no = 50, 10
+    x0, goal, obst = random_batch(4000, no, seed=4242 + N + no)
+    b = 715
+    d = {}
+    for name, kw in (("off", dict(polish_ratio=0.0, polish_tol=0.0)), ("on", {})):
+        cfg = orc.config(N, no, 0.1 * N, **kw)
+        X, U = orc.initial_guess(cfg, x0[b]); P = orc.predict_params(cfg, obst[b])
+        r = orc.rti_solve(cfg, x0[b], P, goal[b], X, U)
+        v = step_vector(N, X, U, r["X"], r["U"])
+        vex, ok, _ = exact_qp(orc.export_qp(cfg, x0[b], P, goal[b], X, U), v)
+        assert ok and r["status"] == 0
+        d[name] = (float(np.abs(v - vex).max()), r["iters"])
+    assert d["off"][0] > 1e-5 and d["on"][0] < 1e-6 and d["on"][1] - d["off"][1] <= 2, d
+    # (2)
+    N, no, seed, b = 47, 1, 863992655, 155
+    x0, goal, obst = random_batch(1500, no, seed=seed)
+    cfg = orc.config(N, no, 0.1 * N)
+    X, U = orc.initial_guess(cfg, x0[b]); P = orc.predict_params(cfg, obst[b])
+    r0 = orc.rti_solve(cfg, x0[b], P, goal[b], X, U)
+    X1, U1 = orc.shift(cfg, r0["X"], r0["U"])
+    r = orc.rti_solve(cfg, x0[b], P, goal[b], X1, U1)
+    assert r0["status"] == 0 and r["status"] == 2 and r["iters"] < cfg.qp_iter_max
+    assert orc.rti_solve(orc.config(N, no, 0.1 * N, polish_tol=0.0), x0[b], P, goal[b], X1, U1)["status"] == 0      # ... which is what it was without the rule
+    # (3)
+    N, no, B = 20, 3, 64
+    x0, goal, obst = random_batch(B, no, seed=5)
+    its = {}
+    for name, kw in (("off", dict(polish_ratio=0.0, polish_tol=0.0)), ("on", {})):
+        cfg = orc.config(N, no, 0.1 * N, **kw)
+        X = np.zeros((B, N + 1, 5)); U = np.zeros((B, N, 2)); x = x0.copy(); ob = obst.copy(); n = 0; st = []
+        for i in range(B):
+            X[i], U[i] = orc.initial_guess(cfg, x[i])
+        for k in range(10):
+            P = np.stack([orc.predict_params(cfg, ob[i]) for i in range(B)])
+            r = orc.rti_solve_batch(cfg, x, P, goal, X, U, nthreads=2)
+            n += int(r["iters"].sum()); st.append(r["status"].copy())
+            for i in range(B):
+                x[i] = orc.dynamics(x[i], r["u0"][i], 0.1)[0]
+                for j in range(no):
+                    ob[i, j] = orc.obstacle_step(cfg, ob[i, j], 0.1)
+                X[i], U[i] = orc.shift(cfg, r["X"][i], r["U"][i])
+        its[name] = (n, np.stack(st))
+    assert np.array_equal(its["on"][1], its["off"][1]) and its["off"][0] <= its["on"][0] <= 1.015 * its["off"][0], (its["on"][0], its["off"][0])
