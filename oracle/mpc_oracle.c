@@ -869,7 +869,7 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
                 alphad = FRAC_TO_BOUNDARY * amaxd; if (amaxd >= 1.0) alphad = 1.0;
             }
         }
-        if (g_trace && it < g_trace_cap) { g_trace[4 * it] = mu; g_trace[4 * it + 1] = getenv("ORC_TRACE_ALPHAD") ? alphad : sigma; g_trace[4 * it + 2] = alpha; g_trace[4 * it + 3] = res[3]; }
+        if (g_trace && it < g_trace_cap) { g_trace[4 * it] = mu; g_trace[4 * it + 1] = sigma; g_trace[4 * it + 2] = alpha; g_trace[4 * it + 3] = res[3]; }
         if (!(alpha > 1e-14) || !(alphad > 1e-14)) { status = 4; break; }
         for (int i = 0; i <= N; i++) {      /* per-stage step norms for the polish: (float)alpha * (float)max_a |dz_i[a]| */
             double m_ = 0; for (int a = 0; a < 7; a++) { double m = fabs(dz[i][a]); if (m > m_) m_ = m; }

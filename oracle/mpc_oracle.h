@@ -144,6 +144,9 @@ int orc_export_qp(const orc_config *c, const double *x0, const double *P, const 
 
 /* debugging aid: number of pairs of the calling thread's last solve that ended with BOTH t and lam at the floor ("dead": complementary whatever the row does) */
 int orc_last_dead_pairs(void);
+/* ... polish iterations it took, and the largest per-stage norm of its last primal step (the polish's indicator (b) looks at these norms) */
+int orc_last_npolish(void);
+double orc_last_step_norm(void);
 /* debugging aid: record (mu, sigma, alpha, cmax) of every IPM iteration of subsequent single solves into buf[4*cap] */
 void orc_set_trace(double *buf, int cap);
 
