@@ -548,3 +548,25 @@ def test_torch_process_group_and_the_library_communicator_in_one_process(env):
     full = json.load(open(os.path.join(root, "profiles", "bench_last.json")))
     assert full["rccl_mapped"] == [os.path.realpath(line["rccl_path"])] or full["rccl_mapped"] == [line["rccl_path"]], full["rccl_mapped"]
     assert line["value"] > 1e6
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_run_the_sharded_workload(env):
+    """`bench.py --gpus 2` for real -- two processes, each with its own handles, streams and contiguous shard of the ONE global C5 batch (16384 of 32768
+    instances per rank), the kernels running, the barrier / max-over-ranks timing, the double-buffered cost exchange on the side stream with the join of the
+    pipelined sub-batch streams -- on the one GPU of this box (MPC_BENCH_ONE_GPU=1: both ranks on cuda:0, and the exchange over gloo because RCCL refuses two
+    ranks on one device; the RCCL form of the exchange is rehearsed with one rank in the test above).  What the 8-GPU run does per rank, minus xGMI."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    envv = dict(os.environ, MPC_BENCH_ONE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        envv.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c5", "--steps", "1", "--warmup", "0"], env=envv,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["exchange"] == "torch" and line["gather_check"] is True
+    assert line["config"]["global_batch"] == 32768 and line["config"]["per_gpu_batch"] == 16384 and line["config"]["N"] == 50 and line["config"]["n_obst"] == 10
+    assert line["torch_pg"]["world"] == 2 and line["torch_pg"]["all_reduce_after_exchange_ok"] is True
+    assert line["value"] > 2e5 and 10 < line["mean_ipm_iters"] < 16 and line["streams_per_gpu"] == 2
