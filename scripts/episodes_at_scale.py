@@ -1,5 +1,5 @@
 """The reference's experiment protocol (experiments.py:20-36: np.random.seed(i), scenario draw, 5 noisy obstacles, at most 400 control steps, stop at the goal) for MANY seeds at
-once, everything random produced on the device (GPU box).  usage: python scripts/episodes_at_scale.py [count ...]  -> gpurun_out/r03_episodes_at_scale.json"""
+once, everything random produced on the device (GPU box).  usage: python scripts/episodes_at_scale.py [count ...]  -> gpurun_out/<tag>_episodes_at_scale.json (MPC_PROFILE_TAG, default r05)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "dynamic-obstacle-avoidance-mpc_amd")]
@@ -18,4 +18,4 @@ for B in [int(a) for a in sys.argv[1:]] or [100, 13000, 100000]:
         out[f"{scen} x {B}"] = dict(seconds=best, control_steps_run=int(r["steps_run"]), solves=int(r["solves"]), solves_per_s=r["solves"] / best,
                                     reached=float(tb[:, 1].mean()), hit=float(tb[:, 0].mean()), mean_steps=float(tb[:, 4].mean()), out_of_bounds=float(tb[:, 5].mean()))
         print(scen, B, out[f"{scen} x {B}"], flush=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r03_episodes_at_scale.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", os.environ.get("MPC_PROFILE_TAG", "r05") + "_episodes_at_scale.json"), "w"), indent=1)
