@@ -819,9 +819,14 @@ def main():
         torch_pg = {"backend": dist.get_backend(), "world": dist.get_world_size(), "all_reduce_after_exchange_ok": bool(float(probe[0].item()) == world * (world + 1) / 2)}
     rccl_maps = sorted({l.split()[-1] for l in open("/proc/self/maps") if "rccl" in l and "/" in l})
     gather_ok = None
-    if exch is not None:         # the last completed message: every rank's row of the final control step must be that rank's own costs (rank 0 checks its own)
+    if exch is not None:         # the last completed message: on every rank, the rank's own block must be its own cost history, and every other block must have arrived
         got = exch.gathered()
         gather_ok = bool(torch.equal(got[rank], exch.hist[((exch.n - 1) // GATHER_EVERY) % 2]))
+        gather_ok = gather_ok and all(bool(torch.isfinite(got[q]).all()) and float(got[q].abs().sum()) > 0.0 for q in range(world))      # every rank's block arrived
+        if dist is not None:      # ... and the line reports the check of ALL ranks, not only rank 0's
+            flag = torch.tensor([1.0 if gather_ok else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            gather_ok = bool(flag.item() == 1.0)
 
     value = G * EPISODE * args.steps / r["elapsed"]
     out = {"metric": "MPC solves/sec (N=20, 3 obstacles)" if N == 20 and no == 3 else f"MPC solves/sec (N={N}, {no} obstacles)",
