@@ -2315,6 +2315,273 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     // sweeps need ~100 doubles of their own and VALU operands can address only 256 VGPRs.  OPAQUE() hides a value's
     // history from the optimiser (no instruction is emitted), so that recomputations are neither hoisted nor merged back.
 #define OPAQUE(x) asm volatile("" : "+v"(x))
+    // ---- THE PARTS OF AN ITERATION THAT DO NOT DEPEND ON THE ROW-STORAGE POLICY, ONE DEFINITION (round 5) ----
+    // The branch-free and the branched form below differ in how the ROWS of a stage are held and visited; what they shared as duplicated text -- the rows' residual
+    // and weight formulas, the cost part of the predictor's right-hand side, the factor sweep with its staging, the three vector sweeps -- is defined here once
+    // (lambdas, each called from exactly one place per instantiated kernel: inlined, the same instructions as the text they replace).
+    // residual r_d = rho(z) - t of the box rows of variable k, from the iterate (never stored)
+    auto box_rd = [&](int k, const double vals[NB], const double zz[7], double &rdl, double &rdh) {
+        const double zk = zz[zidx[k]];
+        rdl = ((vals[k] - lo[k]) + zk) - tl[k];
+        rdh = ((hi[k] - vals[k]) - zk) - th[k];
+    };
+    // weights / residuals of obstacle row pair j at the iterate zz
+    struct SoftT { double w1, w2, rD, be1, be2, rs, rd1, rd2; };
+    auto soft_terms = [&](int j, const ObstView &v, const double zz[7]) {
+        SoftT o;
+        const double y = v.ax * zz[2] + v.ay * zz[3];
+        o.w1 = l1[j] * v.rt1;
+        if (soft) {
+            o.rd1 = (v.hh + y + sv[j]) - t1[j]; o.rd2 = sv[j] - t2[j];
+            o.be1 = (l1[j] * t1[j] + l1[j] * o.rd1) * v.rt1;
+            o.w2 = l2[j] * v.rt2;
+            o.be2 = (l2[j] * t2[j] + l2[j] * o.rd2) * v.rt2;
+            o.rs = zpen * sv[j] + zpen - l1[j] - l2[j];
+            o.rD = rcp_nr(zpen + o.w1 + o.w2);
+        } else {
+            o.rd1 = (v.hh + y) - t1[j]; o.rd2 = 0.0;
+            o.be1 = (l1[j] * t1[j] + l1[j] * o.rd1) * v.rt1;
+            o.w2 = 0.0; o.be2 = 0.0; o.rs = 0.0; o.rD = 0.0;
+        }
+        return o;
+    };
+    // an opaque 0.0 per phase (one v_mov; see obst_view)
+    auto phase_zero = [&]() { double zz_ = 0.0; if constexpr (LEAN) asm volatile("" : "+v"(zz_)); return zz_; };
+    // LEAN: the reciprocals of the box rows are phase-local as well (recomputed at the head of every phase that uses them)
+    auto refresh_box_rcp = [&]() {
+        if constexpr (LEAN) {
+            const double pz = phase_zero();
+#pragma unroll
+            for (int k = 0; k < NB; k++) { rtl[k] = rcp_nr(tl[k] + pz); rth[k] = rcp_nr(th[k] + pz); }
+        }
+    };
+
+    // predictor, cost part: bounds and iterate values of this phase, Gauss-Newton gradient (H z + q) and the diagonal of the reduced Hessian before the rows enter
+    auto predictor_weights = [&](double (&vals)[NB], double (&Hq)[8], double (&gloc)[7], double (&cb)[7]) {
+    refresh_box_rcp();
+    reload_bounds();
+    vals[0] = ui[0]; vals[1] = ui[1]; vals[2] = xi[0]; vals[3] = xi[1]; vals[4] = xi[3]; vals[5] = xi[4];
+#pragma unroll
+    for (int k = 0; k < NB; k++) OPAQUE(vals[k]);
+    // Gauss-Newton gradient q and diagonal Hessian, z order (ua, ual, x, y, psi, v, om); robot_ocp_problem.py:59-83
+    double Hd[7];
+    {   // stage / terminal weights chosen per lane as a select of VALUES: the wave-uniform kernel arguments pass through an opaque
+        // scalar copy first -- written as if / else on the argument arrays, the optimiser selects the ADDRESS and issues five
+        // per-lane global loads from the kernel-argument segment inside the iteration loop
+        double hs[7], ht[5], wg[6], we[4];
+#ifdef MPC_NO_RELOAD
+#pragma unroll
+        for (int c = 0; c < 7; c++) { hs[c] = p.Hd_stage[c]; asm volatile("" : "+s"(hs[c])); }
+#pragma unroll
+        for (int c = 0; c < 5; c++) { ht[c] = p.Hd_term[c]; asm volatile("" : "+s"(ht[c])); }
+#pragma unroll
+        for (int c = 0; c < 6; c++) { wg[c] = p.Wg[c]; asm volatile("" : "+s"(wg[c])); }
+#pragma unroll
+        for (int c = 0; c < 4; c++) { we[c] = p.Weg[c]; asm volatile("" : "+s"(we[c])); }
+#else
+        KArg *pk = (KArg *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(pk));
+#pragma unroll
+        for (int c = 0; c < 7; c++) hs[c] = pk->Hd_stage[c];
+#pragma unroll
+        for (int c = 0; c < 5; c++) ht[c] = pk->Hd_term[c];
+#pragma unroll
+        for (int c = 0; c < 6; c++) wg[c] = pk->Wg[c];
+#pragma unroll
+        for (int c = 0; c < 4; c++) we[c] = pk->Weg[c];
+#endif
+        Hd[0] = has_u ? hs[0] : 0.0; Hd[1] = has_u ? hs[1] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 5; c++) Hd[2 + c] = has_u ? hs[2 + c] : ht[c];
+        gloc[0] = (has_u ? wg[4] : 0.0) * vals[0]; gloc[1] = (has_u ? wg[5] : 0.0) * vals[1];
+        gloc[2] = (has_u ? wg[0] : we[0]) * (vals[2] - gl[0]); gloc[3] = (has_u ? wg[1] : we[1]) * (vals[3] - gl[1]); gloc[4] = 0.0;
+        gloc[5] = (has_u ? wg[2] : we[2]) * vals[4]; gloc[6] = (has_u ? wg[3] : we[3]) * vals[5];
+    }
+    Hq[0] = has_u ? Hd[0] : 1.0; Hq[1] = has_u ? Hd[1] : 1.0; Hq[2] = Hd[2]; Hq[3] = Hd[3]; Hq[4] = Hd[4]; Hq[5] = Hd[5]; Hq[6] = Hd[6]; Hq[7] = 0.0;   // diagonal in z order, then Qxy
+#pragma unroll
+    for (int c = 0; c < 7; c++) { gloc[c] += Hd[c] * z[c]; cb[c] = 0.0; }                              // (H z + q - C'lam), sum_c c beta_c
+    };
+    // predictor, sweep part: H~aug_t and the affine column to LDS, Riccati factor sweep, this lane's gains back (F)
+    auto factor_sweep = [&](const double (&Hq)[8], const double (&gloc)[7], const double (&cb)[7], const double (&bbr)[5], StageFac &F) {
+    MPC_TICK(1);
+    double gxs[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) gxs[c] = gloc[2 + c] + cb[2 + c];
+    if (USE_MFMA) {
+        if (act) {      // H~aug_t in accumulator layout: z~ order (x0..x4, 1, ua, ual)
+            double *hc = ML.HC + 64 * i;
+            const double lu0 = gloc[0] + cb[0], lu1 = gloc[1] + cb[1];
+            hc[MfmaLds::at(0, 0)] = Hq[2]; hc[MfmaLds::at(1, 1)] = Hq[3]; hc[MfmaLds::at(2, 2)] = Hq[4];
+            hc[MfmaLds::at(3, 3)] = Hq[5]; hc[MfmaLds::at(4, 4)] = Hq[6];
+            hc[MfmaLds::at(0, 1)] = Hq[7]; hc[MfmaLds::at(1, 0)] = Hq[7];
+            hc[MfmaLds::at(6, 6)] = Hq[0]; hc[MfmaLds::at(7, 7)] = Hq[1];
+#pragma unroll
+            for (int c = 0; c < 5; c++) { hc[MfmaLds::at(c, 5)] = gxs[c]; hc[MfmaLds::at(5, c)] = gxs[c]; }
+            hc[MfmaLds::at(6, 5)] = lu0; hc[MfmaLds::at(5, 6)] = lu0;
+            hc[MfmaLds::at(7, 5)] = lu1; hc[MfmaLds::at(5, 7)] = lu1;
+        }
+        wave_sync();
+        mfma_factor(lane, N, ML, rhoPi);
+        wave_sync();
+        F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 5; c++) { F.K0[c] = 0.0; F.K1[c] = 0.0; }
+        if (has_u) {
+            const double *ko = ML.KO + 16 * i;
+#pragma unroll
+            for (int c = 0; c < 5; c++) { F.K0[c] = ko[c]; F.K1[c] = ko[6 + c]; }
+            F.k0 = ko[5]; F.k1 = ko[11]; F.i00 = ko[12]; F.l = ko[13]; F.i11 = ko[14];
+        }
+    } else if (ROWPAR) {
+        if (act) {      // H~aug_t, dense 8 x 8, z~ order (x0..x4, 1, ua, ual); affine column of W~_t
+            const double lu0 = gloc[0] + cb[0], lu1 = gloc[1] + cb[1];
+            const double Hrow[8][8] = {{Hq[2], Hq[7], 0.0, 0.0, 0.0, gxs[0], 0.0, 0.0}, {Hq[7], Hq[3], 0.0, 0.0, 0.0, gxs[1], 0.0, 0.0},
+                                       {0.0, 0.0, Hq[4], 0.0, 0.0, gxs[2], 0.0, 0.0}, {0.0, 0.0, 0.0, Hq[5], 0.0, gxs[3], 0.0, 0.0},
+                                       {0.0, 0.0, 0.0, 0.0, Hq[6], gxs[4], 0.0, 0.0}, {gxs[0], gxs[1], gxs[2], gxs[3], gxs[4], 0.0, lu0, lu1},
+                                       {0.0, 0.0, 0.0, 0.0, 0.0, lu0, Hq[0], 0.0}, {0.0, 0.0, 0.0, 0.0, 0.0, lu1, 0.0, Hq[1]}};
+            double *hc = RL.H + LT::HS * i;
+            if constexpr (COMPACT) {    // rows 0..5, then H66 and H77 (rows 6, 7 are synthesised by the sweep, RowLdsC)
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int c = 0; c < 8; c++) hc[r * 8 + c] = Hrow[r][c];
+                hc[48] = Hq[0]; hc[51] = Hq[1];
+                if (has_u) { double *w = RL.W + LT::WS * i; w[5] = bbr[0]; w[13] = bbr[1]; w[16] = bbr[2]; w[17] = bbr[3]; w[18] = bbr[4]; }
+            } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+#pragma unroll
+                for (int c = 0; c < 8; c++) hc[r * 8 + c] = Hrow[r][c];
+            if (has_u) {
+#pragma unroll
+                for (int k = 0; k < 5; k++) RL.W[RowLds::WS * i + k * 8 + 5] = bbr[k];
+            }
+            }
+        }
+        wave_sync();
+        MPC_TICK(9);
+#ifdef MPC_FACTOR_PLAIN
+        rowpar_factor(lane, N, RS, sweep_worker);
+#else
+        if constexpr (COMPACT) {
+#ifdef MPC_COMPACT_PLAIN
+            rowpar_factor(lane, N, RS, sweep_worker);
+#else
+            rowpar_factor_fast_c(lane, N, RS, sweep_worker);
+#endif
+        } else {
+#ifdef MPC_MFMA4
+            if constexpr (G == 64) mfma4_factor(lane, N, RS); else
+#endif
+            rowpar_factor_fast(lane, N, RS, sweep_worker);
+        }
+#endif
+        wave_sync();
+        F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 5; c++) { F.K0[c] = 0.0; F.K1[c] = 0.0; }
+        if (has_u) {
+            const double *ko = RL.H + LT::HS * i;
+#pragma unroll
+            for (int c = 0; c < 5; c++) { F.K0[c] = ko[c]; F.K1[c] = ko[8 + c]; }
+            F.k0 = ko[5]; F.k1 = ko[13]; F.i00 = ko[6]; F.l = ko[7]; F.i11 = ko[14];
+        }
+        // (no barrier: every lane overwrites only the block it has just read, and a wavefront's LDS operations complete in order)
+        if (has_u) {    // closed-loop matrix Acl = A + B K of this stage, row-major, for the row-parallel vector recursions
+            double *acl = RL.H + LT::HS * i + RowVec::ACL;
+            const StageLin SL = stage_lin();
+            const double Ar[2][5] = {{1.0, 0.0, SL.a02, SL.a03, SL.a04}, {0.0, 1.0, SL.a12, SL.a13, SL.a14}};
+            const double Br[2][2] = {{SL.b00, SL.b01}, {SL.b10, SL.b11}};
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                acl[0 * RowVec::RS + c] = Ar[0][c] + Br[0][0] * F.K0[c] + Br[0][1] * F.K1[c];
+                acl[1 * RowVec::RS + c] = Ar[1][c] + Br[1][0] * F.K0[c] + Br[1][1] * F.K1[c];
+                acl[2 * RowVec::RS + c] = (c == 2 ? 1.0 : (c == 4 ? dt : 0.0)) + h2 * F.K1[c];
+                acl[3 * RowVec::RS + c] = (c == 3 ? 1.0 : 0.0) + dt * F.K0[c];
+                acl[4 * RowVec::RS + c] = (c == 4 ? 1.0 : 0.0) + dt * F.K1[c];
+            }
+        }
+    } else
+        systolic_factor(i, N, S, Hq, gloc[0] + cb[0], gloc[1] + cb[1], gxs, bbr, rhoPi != 0.0, F);
+    };
+    // forward vector sweep of the affine step: za
+    auto affine_rollout = [&](const double (&bbr)[5], const double (&x_init)[5], StageFac &F, double (&za)[7]) {
+    MPC_TICK(2);
+    if (ROWPAR) {
+        if (has_u) {        // c_t = r_b + B k
+            double *cc = RL.H + LT::HS * i + RowVec::ACL + 5;      // c[r] closes row r
+            const StageLin SL = stage_lin();
+            cc[0 * RowVec::RS] = bbr[0] + SL.b00 * F.k0 + SL.b01 * F.k1; cc[1 * RowVec::RS] = bbr[1] + SL.b10 * F.k0 + SL.b11 * F.k1;
+            cc[2 * RowVec::RS] = bbr[2] + h2 * F.k1; cc[3 * RowVec::RS] = bbr[3] + dt * F.k0; cc[4 * RowVec::RS] = bbr[4] + dt * F.k1;
+        }
+        if (i == 0) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = SLDS ? rhoPi * lds_raw[RowLdsC::CT + slot * 5 + c] : x_init[c];
+        }
+        wave_sync();
+        rowpar_vector_fast<true>(lane, N, RS, sweep_worker);
+        wave_sync();
+        if (act) {
+            const double *xx = RL.H + LT::HS * i + RowVec::X;
+            double u0 = F.k0, u1 = F.k1;
+#pragma unroll
+            for (int c = 0; c < 5; c++) { za[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }
+            za[0] = u0; za[1] = u1;
+        }
+    } else
+        systolic_rollout<true>(i, N, S, F, x_init, bbr, za);
+    MPC_TICK(3);
+    };
+    // corrector: adjoint sweep of the right-hand side change gc, feed-forward, forward sweep, dz = corrector + affine step
+    auto corrector_sweeps = [&](const double (&gc)[7], const double (&bbr)[5], const double (&x_init)[5], const double (&za)[7], StageFac &F, double (&dz)[7]) {
+    MPC_TICK(5);
+    if (ROWPAR) {
+        if (act) {      // c~_t = gc_x + K' gc_u  (K = 0 in the terminal lane)
+            double *cc = RL.H + LT::HS * i + RowVec::CT;
+#pragma unroll
+            for (int c = 0; c < 5; c++) cc[c] = gc[2 + c] + F.K0[c] * gc[0] + F.K1[c] * gc[1];
+        }
+        wave_sync();
+        rowpar_vector_fast<false>(lane, N, RS, sweep_worker);
+        wave_sync();
+        if (has_u) {    // feed-forward of the corrector right-hand side: k = -Muu^-1 (gc_u + B' p_{t+1})
+            const double *pp = RL.H + LT::HS * (i + 1) + RowVec::P;
+            const double pv[5] = {pp[0], pp[1], pp[2], pp[3], pp[4]};
+            const StageLin SL = stage_lin();
+            const double m0 = gc[0] + SL.dua(pv), m1 = gc[1] + SL.dual(pv);
+            F.k1 = fma(F.l, m0, -m1) * F.i11;
+            F.k0 = fma(-F.l, F.k1, -(m0 * F.i00));
+        }
+    } else
+        systolic_corrector(i, N, S, gc, F);
+    MPC_TICK(6);
+    if (ROWPAR) {
+        if (has_u) {        // homogeneous dynamics: c_t = B k
+            double *cc = RL.H + LT::HS * i + RowVec::ACL + 5;
+            const StageLin SL = stage_lin();
+            cc[0 * RowVec::RS] = SL.b00 * F.k0 + SL.b01 * F.k1; cc[1 * RowVec::RS] = SL.b10 * F.k0 + SL.b11 * F.k1;
+            cc[2 * RowVec::RS] = h2 * F.k1; cc[3 * RowVec::RS] = dt * F.k0; cc[4 * RowVec::RS] = dt * F.k1;
+        }
+        if (i == 0) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = 0.0;
+        }
+        wave_sync();
+        rowpar_vector_fast<true>(lane, N, RS, sweep_worker);
+        wave_sync();
+        if (act) {
+            const double *xx = RL.H + LT::HS * i + RowVec::X;
+            double u0 = F.k0, u1 = F.k1;
+#pragma unroll
+            for (int c = 0; c < 5; c++) { dz[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }
+            dz[0] = u0; dz[1] = u1;
+        }
+    } else
+        systolic_rollout<false>(i, N, S, F, x_init, bbr, dz);
+#pragma unroll
+    for (int c = 0; c < 7; c++) dz[c] += za[c];
+    MPC_TICK(7);
+    };
     // Two forms of the iteration's row phases (same arithmetic, same interior point):
     //   BRANCHFREE (3 and 5 obstacle row pairs): every row of the stage computed by every lane, existence as 0 / 1 factors (see m_u, m_x, m_s);
     //   the branched form (10 row pairs): the rows under `if (row exists)`.  With ten obstacles the register file is full to the last
@@ -2357,43 +2624,6 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         ipm.cprev = cmax;
         MPC_TICK(0);
 
-        // residual r_d = rho(z) - t of the box rows of variable k, from the iterate (never stored)
-        auto box_rd = [&](int k, const double vals[NB], const double zz[7], double &rdl, double &rdh) {
-            const double zk = zz[zidx[k]];
-            rdl = ((vals[k] - lo[k]) + zk) - tl[k];
-            rdh = ((hi[k] - vals[k]) - zk) - th[k];
-        };
-        // weights / residuals of obstacle row pair j at the iterate zz
-        struct SoftT { double w1, w2, rD, be1, be2, rs, rd1, rd2; };
-        auto soft_terms = [&](int j, const ObstView &v, const double zz[7]) {
-            SoftT o;
-            const double y = v.ax * zz[2] + v.ay * zz[3];
-            o.w1 = l1[j] * v.rt1;
-            if (soft) {
-                o.rd1 = (v.hh + y + sv[j]) - t1[j]; o.rd2 = sv[j] - t2[j];
-                o.be1 = (l1[j] * t1[j] + l1[j] * o.rd1) * v.rt1;
-                o.w2 = l2[j] * v.rt2;
-                o.be2 = (l2[j] * t2[j] + l2[j] * o.rd2) * v.rt2;
-                o.rs = zpen * sv[j] + zpen - l1[j] - l2[j];
-                o.rD = rcp_nr(zpen + o.w1 + o.w2);
-            } else {
-                o.rd1 = (v.hh + y) - t1[j]; o.rd2 = 0.0;
-                o.be1 = (l1[j] * t1[j] + l1[j] * o.rd1) * v.rt1;
-                o.w2 = 0.0; o.be2 = 0.0; o.rs = 0.0; o.rD = 0.0;
-            }
-            return o;
-        };
-        // an opaque 0.0 per phase (one v_mov; see obst_view)
-        auto phase_zero = [&]() { double zz_ = 0.0; if constexpr (LEAN) asm volatile("" : "+v"(zz_)); return zz_; };
-        // LEAN: the reciprocals of the box rows are phase-local as well (recomputed at the head of every phase that uses them)
-        auto refresh_box_rcp = [&]() {
-            if constexpr (LEAN) {
-                const double pz = phase_zero();
-#pragma unroll
-                for (int k = 0; k < NB; k++) { rtl[k] = rcp_nr(tl[k] + pz); rth[k] = rcp_nr(th[k] + pz); }
-            }
-        };
-
         // ---- predictor (sigma = 0): local gradient, barrier terms, reduced Hessian ----
         StageFac F;
         double za[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -2401,48 +2631,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #pragma unroll
         for (int c = 0; c < 5; c++) { bbr[c] = rhoPi * bb[c]; x_init[c] = SLDS ? 0.0 : rhoPi * d0[c]; }
         {
-            refresh_box_rcp();
-            reload_bounds();
-            double vals[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
-#pragma unroll
-            for (int k = 0; k < NB; k++) OPAQUE(vals[k]);
-            // Gauss-Newton gradient q and diagonal Hessian, z order (ua, ual, x, y, psi, v, om); robot_ocp_problem.py:59-83
-            double Hd[7], gloc[7], cb[7];
-            {   // stage / terminal weights chosen per lane as a select of VALUES: the wave-uniform kernel arguments pass through an opaque
-                // scalar copy first -- written as if / else on the argument arrays, the optimiser selects the ADDRESS and issues five
-                // per-lane global loads from the kernel-argument segment inside the iteration loop
-                double hs[7], ht[5], wg[6], we[4];
-#ifdef MPC_NO_RELOAD
-#pragma unroll
-                for (int c = 0; c < 7; c++) { hs[c] = p.Hd_stage[c]; asm volatile("" : "+s"(hs[c])); }
-#pragma unroll
-                for (int c = 0; c < 5; c++) { ht[c] = p.Hd_term[c]; asm volatile("" : "+s"(ht[c])); }
-#pragma unroll
-                for (int c = 0; c < 6; c++) { wg[c] = p.Wg[c]; asm volatile("" : "+s"(wg[c])); }
-#pragma unroll
-                for (int c = 0; c < 4; c++) { we[c] = p.Weg[c]; asm volatile("" : "+s"(we[c])); }
-#else
-                KArg *pk = (KArg *)__builtin_amdgcn_kernarg_segment_ptr();
-                asm volatile("" : "+s"(pk));
-#pragma unroll
-                for (int c = 0; c < 7; c++) hs[c] = pk->Hd_stage[c];
-#pragma unroll
-                for (int c = 0; c < 5; c++) ht[c] = pk->Hd_term[c];
-#pragma unroll
-                for (int c = 0; c < 6; c++) wg[c] = pk->Wg[c];
-#pragma unroll
-                for (int c = 0; c < 4; c++) we[c] = pk->Weg[c];
-#endif
-                Hd[0] = has_u ? hs[0] : 0.0; Hd[1] = has_u ? hs[1] : 0.0;
-#pragma unroll
-                for (int c = 0; c < 5; c++) Hd[2 + c] = has_u ? hs[2 + c] : ht[c];
-                gloc[0] = (has_u ? wg[4] : 0.0) * vals[0]; gloc[1] = (has_u ? wg[5] : 0.0) * vals[1];
-                gloc[2] = (has_u ? wg[0] : we[0]) * (vals[2] - gl[0]); gloc[3] = (has_u ? wg[1] : we[1]) * (vals[3] - gl[1]); gloc[4] = 0.0;
-                gloc[5] = (has_u ? wg[2] : we[2]) * vals[4]; gloc[6] = (has_u ? wg[3] : we[3]) * vals[5];
-            }
-            double Hq[8] = {has_u ? Hd[0] : 1.0, has_u ? Hd[1] : 1.0, Hd[2], Hd[3], Hd[4], Hd[5], Hd[6], 0.0};   // diagonal in z order, then Qxy
-#pragma unroll
-            for (int c = 0; c < 7; c++) { gloc[c] += Hd[c] * z[c]; cb[c] = 0.0; }                              // (H z + q - C'lam), sum_c c beta_c
+            double vals[NB], Hq[8], gloc[7], cb[7];
+            predictor_weights(vals, Hq, gloc, cb);
 #pragma unroll
             for (int k = 0; k < NB; k++) {
                 double rdl, rdh;
@@ -2474,132 +2664,9 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                 gloc[2] = fma(-m_s, gx, gloc[2]); gloc[3] = fma(-m_s, gy, gloc[3]);
                 cb[2] = fma(m_s, cx, cb[2]); cb[3] = fma(m_s, cy, cb[3]);
             }
-            MPC_TICK(1);
-            double gxs[5];
-#pragma unroll
-            for (int c = 0; c < 5; c++) gxs[c] = gloc[2 + c] + cb[2 + c];
-            if (USE_MFMA) {
-                if (act) {      // H~aug_t in accumulator layout: z~ order (x0..x4, 1, ua, ual)
-                    double *hc = ML.HC + 64 * i;
-                    const double lu0 = gloc[0] + cb[0], lu1 = gloc[1] + cb[1];
-                    hc[MfmaLds::at(0, 0)] = Hq[2]; hc[MfmaLds::at(1, 1)] = Hq[3]; hc[MfmaLds::at(2, 2)] = Hq[4];
-                    hc[MfmaLds::at(3, 3)] = Hq[5]; hc[MfmaLds::at(4, 4)] = Hq[6];
-                    hc[MfmaLds::at(0, 1)] = Hq[7]; hc[MfmaLds::at(1, 0)] = Hq[7];
-                    hc[MfmaLds::at(6, 6)] = Hq[0]; hc[MfmaLds::at(7, 7)] = Hq[1];
-#pragma unroll
-                    for (int c = 0; c < 5; c++) { hc[MfmaLds::at(c, 5)] = gxs[c]; hc[MfmaLds::at(5, c)] = gxs[c]; }
-                    hc[MfmaLds::at(6, 5)] = lu0; hc[MfmaLds::at(5, 6)] = lu0;
-                    hc[MfmaLds::at(7, 5)] = lu1; hc[MfmaLds::at(5, 7)] = lu1;
-                }
-                wave_sync();
-                mfma_factor(lane, N, ML, rhoPi);
-                wave_sync();
-                F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;
-#pragma unroll
-                for (int c = 0; c < 5; c++) { F.K0[c] = 0.0; F.K1[c] = 0.0; }
-                if (has_u) {
-                    const double *ko = ML.KO + 16 * i;
-#pragma unroll
-                    for (int c = 0; c < 5; c++) { F.K0[c] = ko[c]; F.K1[c] = ko[6 + c]; }
-                    F.k0 = ko[5]; F.k1 = ko[11]; F.i00 = ko[12]; F.l = ko[13]; F.i11 = ko[14];
-                }
-            } else if (ROWPAR) {
-                if (act) {      // H~aug_t, dense 8 x 8, z~ order (x0..x4, 1, ua, ual); affine column of W~_t
-                    const double lu0 = gloc[0] + cb[0], lu1 = gloc[1] + cb[1];
-                    const double Hrow[8][8] = {{Hq[2], Hq[7], 0.0, 0.0, 0.0, gxs[0], 0.0, 0.0}, {Hq[7], Hq[3], 0.0, 0.0, 0.0, gxs[1], 0.0, 0.0},
-                                               {0.0, 0.0, Hq[4], 0.0, 0.0, gxs[2], 0.0, 0.0}, {0.0, 0.0, 0.0, Hq[5], 0.0, gxs[3], 0.0, 0.0},
-                                               {0.0, 0.0, 0.0, 0.0, Hq[6], gxs[4], 0.0, 0.0}, {gxs[0], gxs[1], gxs[2], gxs[3], gxs[4], 0.0, lu0, lu1},
-                                               {0.0, 0.0, 0.0, 0.0, 0.0, lu0, Hq[0], 0.0}, {0.0, 0.0, 0.0, 0.0, 0.0, lu1, 0.0, Hq[1]}};
-                    double *hc = RL.H + LT::HS * i;
-                    if constexpr (COMPACT) {    // rows 0..5, then H66 and H77 (rows 6, 7 are synthesised by the sweep, RowLdsC)
-#pragma unroll
-                        for (int r = 0; r < 6; r++)
-#pragma unroll
-                            for (int c = 0; c < 8; c++) hc[r * 8 + c] = Hrow[r][c];
-                        hc[48] = Hq[0]; hc[51] = Hq[1];
-                        if (has_u) { double *w = RL.W + LT::WS * i; w[5] = bbr[0]; w[13] = bbr[1]; w[16] = bbr[2]; w[17] = bbr[3]; w[18] = bbr[4]; }
-                    } else {
-#pragma unroll
-                    for (int r = 0; r < 8; r++)
-#pragma unroll
-                        for (int c = 0; c < 8; c++) hc[r * 8 + c] = Hrow[r][c];
-                    if (has_u) {
-#pragma unroll
-                        for (int k = 0; k < 5; k++) RL.W[RowLds::WS * i + k * 8 + 5] = bbr[k];
-                    }
-                    }
-                }
-                wave_sync();
-                MPC_TICK(9);
-#ifdef MPC_FACTOR_PLAIN
-                rowpar_factor(lane, N, RS, sweep_worker);
-#else
-                if constexpr (COMPACT) {
-#ifdef MPC_COMPACT_PLAIN
-                    rowpar_factor(lane, N, RS, sweep_worker);
-#else
-                    rowpar_factor_fast_c(lane, N, RS, sweep_worker);
-#endif
-                } else {
-#ifdef MPC_MFMA4
-                    if constexpr (G == 64) mfma4_factor(lane, N, RS); else
-#endif
-                    rowpar_factor_fast(lane, N, RS, sweep_worker);
-                }
-#endif
-                wave_sync();
-                F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;
-#pragma unroll
-                for (int c = 0; c < 5; c++) { F.K0[c] = 0.0; F.K1[c] = 0.0; }
-                if (has_u) {
-                    const double *ko = RL.H + LT::HS * i;
-#pragma unroll
-                    for (int c = 0; c < 5; c++) { F.K0[c] = ko[c]; F.K1[c] = ko[8 + c]; }
-                    F.k0 = ko[5]; F.k1 = ko[13]; F.i00 = ko[6]; F.l = ko[7]; F.i11 = ko[14];
-                }
-                // (no barrier: every lane overwrites only the block it has just read, and a wavefront's LDS operations complete in order)
-                if (has_u) {    // closed-loop matrix Acl = A + B K of this stage, row-major, for the row-parallel vector recursions
-                    double *acl = RL.H + LT::HS * i + RowVec::ACL;
-                    const StageLin SL = stage_lin();
-                    const double Ar[2][5] = {{1.0, 0.0, SL.a02, SL.a03, SL.a04}, {0.0, 1.0, SL.a12, SL.a13, SL.a14}};
-                    const double Br[2][2] = {{SL.b00, SL.b01}, {SL.b10, SL.b11}};
-#pragma unroll
-                    for (int c = 0; c < 5; c++) {
-                        acl[0 * RowVec::RS + c] = Ar[0][c] + Br[0][0] * F.K0[c] + Br[0][1] * F.K1[c];
-                        acl[1 * RowVec::RS + c] = Ar[1][c] + Br[1][0] * F.K0[c] + Br[1][1] * F.K1[c];
-                        acl[2 * RowVec::RS + c] = (c == 2 ? 1.0 : (c == 4 ? dt : 0.0)) + h2 * F.K1[c];
-                        acl[3 * RowVec::RS + c] = (c == 3 ? 1.0 : 0.0) + dt * F.K0[c];
-                        acl[4 * RowVec::RS + c] = (c == 4 ? 1.0 : 0.0) + dt * F.K1[c];
-                    }
-                }
-            } else
-                systolic_factor(i, N, S, Hq, gloc[0] + cb[0], gloc[1] + cb[1], gxs, bbr, rhoPi != 0.0, F);
+            factor_sweep(Hq, gloc, cb, bbr, F);
         }
-        MPC_TICK(2);
-        if (ROWPAR) {
-            if (has_u) {        // c_t = r_b + B k
-                double *cc = RL.H + LT::HS * i + RowVec::ACL + 5;      // c[r] closes row r
-                const StageLin SL = stage_lin();
-                cc[0 * RowVec::RS] = bbr[0] + SL.b00 * F.k0 + SL.b01 * F.k1; cc[1 * RowVec::RS] = bbr[1] + SL.b10 * F.k0 + SL.b11 * F.k1;
-                cc[2 * RowVec::RS] = bbr[2] + h2 * F.k1; cc[3 * RowVec::RS] = bbr[3] + dt * F.k0; cc[4 * RowVec::RS] = bbr[4] + dt * F.k1;
-            }
-            if (i == 0) {
-#pragma unroll
-                for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = SLDS ? rhoPi * lds_raw[RowLdsC::CT + slot * 5 + c] : x_init[c];
-            }
-            wave_sync();
-            rowpar_vector_fast<true>(lane, N, RS, sweep_worker);
-            wave_sync();
-            if (act) {
-                const double *xx = RL.H + LT::HS * i + RowVec::X;
-                double u0 = F.k0, u1 = F.k1;
-#pragma unroll
-                for (int c = 0; c < 5; c++) { za[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }
-                za[0] = u0; za[1] = u1;
-            }
-        } else
-            systolic_rollout<true>(i, N, S, F, x_init, bbr, za);
-        MPC_TICK(3);
+        affine_rollout(bbr, x_init, F, za);
 
         // ---- affine step: dt, dlam per row, step ratios, products dlam_aff * dt_aff ----
         // The products dlam_aff * dt_aff of the rows are not carried from here to the combined step (18 doubles with 3 obstacles, 32 with 10: they would
@@ -2703,54 +2770,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             double gc[7];
 #pragma unroll
             for (int c = 0; c < 7; c++) gc[c] = fma(-smu, G0[c], G1[c]);
-            MPC_TICK(5);
-            if (ROWPAR) {
-                if (act) {      // c~_t = gc_x + K' gc_u  (K = 0 in the terminal lane)
-                    double *cc = RL.H + LT::HS * i + RowVec::CT;
-#pragma unroll
-                    for (int c = 0; c < 5; c++) cc[c] = gc[2 + c] + F.K0[c] * gc[0] + F.K1[c] * gc[1];
-                }
-                wave_sync();
-                rowpar_vector_fast<false>(lane, N, RS, sweep_worker);
-                wave_sync();
-                if (has_u) {    // feed-forward of the corrector right-hand side: k = -Muu^-1 (gc_u + B' p_{t+1})
-                    const double *pp = RL.H + LT::HS * (i + 1) + RowVec::P;
-                    const double pv[5] = {pp[0], pp[1], pp[2], pp[3], pp[4]};
-                    const StageLin SL = stage_lin();
-                    const double m0 = gc[0] + SL.dua(pv), m1 = gc[1] + SL.dual(pv);
-                    F.k1 = fma(F.l, m0, -m1) * F.i11;
-                    F.k0 = fma(-F.l, F.k1, -(m0 * F.i00));
-                }
-            } else
-                systolic_corrector(i, N, S, gc, F);
+            corrector_sweeps(gc, bbr, x_init, za, F, dz);
         }
-        MPC_TICK(6);
-        if (ROWPAR) {
-            if (has_u) {        // homogeneous dynamics: c_t = B k
-                double *cc = RL.H + LT::HS * i + RowVec::ACL + 5;
-                const StageLin SL = stage_lin();
-                cc[0 * RowVec::RS] = SL.b00 * F.k0 + SL.b01 * F.k1; cc[1 * RowVec::RS] = SL.b10 * F.k0 + SL.b11 * F.k1;
-                cc[2 * RowVec::RS] = h2 * F.k1; cc[3 * RowVec::RS] = dt * F.k0; cc[4 * RowVec::RS] = dt * F.k1;
-            }
-            if (i == 0) {
-#pragma unroll
-                for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = 0.0;
-            }
-            wave_sync();
-            rowpar_vector_fast<true>(lane, N, RS, sweep_worker);
-            wave_sync();
-            if (act) {
-                const double *xx = RL.H + LT::HS * i + RowVec::X;
-                double u0 = F.k0, u1 = F.k1;
-#pragma unroll
-                for (int c = 0; c < 5; c++) { dz[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }
-                dz[0] = u0; dz[1] = u1;
-            }
-        } else
-            systolic_rollout<false>(i, N, S, F, x_init, bbr, dz);
-#pragma unroll
-        for (int c = 0; c < 7; c++) dz[c] += za[c];
-        MPC_TICK(7);
 
         // ---- combined step: ratios, step length, update (instances that have stopped keep their state) ----
         {
@@ -2903,43 +2924,6 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         ipm.cprev = cmax;
         MPC_TICK(0);
 
-        // residual r_d = rho(z) - t of the box rows of variable k, from the iterate (never stored)
-        auto box_rd = [&](int k, const double vals[NB], const double zz[7], double &rdl, double &rdh) {
-            const double zk = zz[zidx[k]];
-            rdl = ((vals[k] - lo[k]) + zk) - tl[k];
-            rdh = ((hi[k] - vals[k]) - zk) - th[k];
-        };
-        // weights / residuals of obstacle row pair j at the iterate zz
-        struct SoftT { double w1, w2, rD, be1, be2, rs, rd1, rd2; };
-        auto soft_terms = [&](int j, const ObstView &v, const double zz[7]) {
-            SoftT o;
-            const double y = v.ax * zz[2] + v.ay * zz[3];
-            o.w1 = l1[j] * v.rt1;
-            if (soft) {
-                o.rd1 = (v.hh + y + sv[j]) - t1[j]; o.rd2 = sv[j] - t2[j];
-                o.be1 = (l1[j] * t1[j] + l1[j] * o.rd1) * v.rt1;
-                o.w2 = l2[j] * v.rt2;
-                o.be2 = (l2[j] * t2[j] + l2[j] * o.rd2) * v.rt2;
-                o.rs = zpen * sv[j] + zpen - l1[j] - l2[j];
-                o.rD = rcp_nr(zpen + o.w1 + o.w2);
-            } else {
-                o.rd1 = (v.hh + y) - t1[j]; o.rd2 = 0.0;
-                o.be1 = (l1[j] * t1[j] + l1[j] * o.rd1) * v.rt1;
-                o.w2 = 0.0; o.be2 = 0.0; o.rs = 0.0; o.rD = 0.0;
-            }
-            return o;
-        };
-        // an opaque 0.0 per phase (one v_mov; see obst_view)
-        auto phase_zero = [&]() { double zz_ = 0.0; if constexpr (LEAN) asm volatile("" : "+v"(zz_)); return zz_; };
-        // LEAN: the reciprocals of the box rows are phase-local as well (recomputed at the head of every phase that uses them)
-        auto refresh_box_rcp = [&]() {
-            if constexpr (LEAN) {
-                const double pz = phase_zero();
-#pragma unroll
-                for (int k = 0; k < NB; k++) { rtl[k] = rcp_nr(tl[k] + pz); rth[k] = rcp_nr(th[k] + pz); }
-            }
-        };
-
         // ---- predictor (sigma = 0): local gradient, barrier terms, reduced Hessian ----
         StageFac F;
         double za[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -2947,48 +2931,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
 #pragma unroll
         for (int c = 0; c < 5; c++) { bbr[c] = rhoPi * bb[c]; x_init[c] = SLDS ? 0.0 : rhoPi * d0[c]; }
         {
-            refresh_box_rcp();
-            reload_bounds();
-            double vals[NB] = {ui[0], ui[1], xi[0], xi[1], xi[3], xi[4]};
-#pragma unroll
-            for (int k = 0; k < NB; k++) OPAQUE(vals[k]);
-            // Gauss-Newton gradient q and diagonal Hessian, z order (ua, ual, x, y, psi, v, om); robot_ocp_problem.py:59-83
-            double Hd[7], gloc[7], cb[7];
-            {   // stage / terminal weights chosen per lane as a select of VALUES: the wave-uniform kernel arguments pass through an opaque
-                // scalar copy first -- written as if / else on the argument arrays, the optimiser selects the ADDRESS and issues five
-                // per-lane global loads from the kernel-argument segment inside the iteration loop
-                double hs[7], ht[5], wg[6], we[4];
-#ifdef MPC_NO_RELOAD
-#pragma unroll
-                for (int c = 0; c < 7; c++) { hs[c] = p.Hd_stage[c]; asm volatile("" : "+s"(hs[c])); }
-#pragma unroll
-                for (int c = 0; c < 5; c++) { ht[c] = p.Hd_term[c]; asm volatile("" : "+s"(ht[c])); }
-#pragma unroll
-                for (int c = 0; c < 6; c++) { wg[c] = p.Wg[c]; asm volatile("" : "+s"(wg[c])); }
-#pragma unroll
-                for (int c = 0; c < 4; c++) { we[c] = p.Weg[c]; asm volatile("" : "+s"(we[c])); }
-#else
-                KArg *pk = (KArg *)__builtin_amdgcn_kernarg_segment_ptr();
-                asm volatile("" : "+s"(pk));
-#pragma unroll
-                for (int c = 0; c < 7; c++) hs[c] = pk->Hd_stage[c];
-#pragma unroll
-                for (int c = 0; c < 5; c++) ht[c] = pk->Hd_term[c];
-#pragma unroll
-                for (int c = 0; c < 6; c++) wg[c] = pk->Wg[c];
-#pragma unroll
-                for (int c = 0; c < 4; c++) we[c] = pk->Weg[c];
-#endif
-                Hd[0] = has_u ? hs[0] : 0.0; Hd[1] = has_u ? hs[1] : 0.0;
-#pragma unroll
-                for (int c = 0; c < 5; c++) Hd[2 + c] = has_u ? hs[2 + c] : ht[c];
-                gloc[0] = (has_u ? wg[4] : 0.0) * vals[0]; gloc[1] = (has_u ? wg[5] : 0.0) * vals[1];
-                gloc[2] = (has_u ? wg[0] : we[0]) * (vals[2] - gl[0]); gloc[3] = (has_u ? wg[1] : we[1]) * (vals[3] - gl[1]); gloc[4] = 0.0;
-                gloc[5] = (has_u ? wg[2] : we[2]) * vals[4]; gloc[6] = (has_u ? wg[3] : we[3]) * vals[5];
-            }
-            double Hq[8] = {has_u ? Hd[0] : 1.0, has_u ? Hd[1] : 1.0, Hd[2], Hd[3], Hd[4], Hd[5], Hd[6], 0.0};   // diagonal in z order, then Qxy
-#pragma unroll
-            for (int c = 0; c < 7; c++) { gloc[c] += Hd[c] * z[c]; cb[c] = 0.0; }                              // (H z + q - C'lam), sum_c c beta_c
+            double vals[NB], Hq[8], gloc[7], cb[7];
+            predictor_weights(vals, Hq, gloc, cb);
 #pragma unroll
             for (int k = 0; k < NB; k++) if ((k < 2) ? vbu : vbx) {
                 double rdl, rdh;
@@ -3016,132 +2960,9 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                     cb[2] += geff * v.ax; cb[3] += geff * v.ay;
                 }
             }
-            MPC_TICK(1);
-            double gxs[5];
-#pragma unroll
-            for (int c = 0; c < 5; c++) gxs[c] = gloc[2 + c] + cb[2 + c];
-            if (USE_MFMA) {
-                if (act) {      // H~aug_t in accumulator layout: z~ order (x0..x4, 1, ua, ual)
-                    double *hc = ML.HC + 64 * i;
-                    const double lu0 = gloc[0] + cb[0], lu1 = gloc[1] + cb[1];
-                    hc[MfmaLds::at(0, 0)] = Hq[2]; hc[MfmaLds::at(1, 1)] = Hq[3]; hc[MfmaLds::at(2, 2)] = Hq[4];
-                    hc[MfmaLds::at(3, 3)] = Hq[5]; hc[MfmaLds::at(4, 4)] = Hq[6];
-                    hc[MfmaLds::at(0, 1)] = Hq[7]; hc[MfmaLds::at(1, 0)] = Hq[7];
-                    hc[MfmaLds::at(6, 6)] = Hq[0]; hc[MfmaLds::at(7, 7)] = Hq[1];
-#pragma unroll
-                    for (int c = 0; c < 5; c++) { hc[MfmaLds::at(c, 5)] = gxs[c]; hc[MfmaLds::at(5, c)] = gxs[c]; }
-                    hc[MfmaLds::at(6, 5)] = lu0; hc[MfmaLds::at(5, 6)] = lu0;
-                    hc[MfmaLds::at(7, 5)] = lu1; hc[MfmaLds::at(5, 7)] = lu1;
-                }
-                wave_sync();
-                mfma_factor(lane, N, ML, rhoPi);
-                wave_sync();
-                F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;
-#pragma unroll
-                for (int c = 0; c < 5; c++) { F.K0[c] = 0.0; F.K1[c] = 0.0; }
-                if (has_u) {
-                    const double *ko = ML.KO + 16 * i;
-#pragma unroll
-                    for (int c = 0; c < 5; c++) { F.K0[c] = ko[c]; F.K1[c] = ko[6 + c]; }
-                    F.k0 = ko[5]; F.k1 = ko[11]; F.i00 = ko[12]; F.l = ko[13]; F.i11 = ko[14];
-                }
-            } else if (ROWPAR) {
-                if (act) {      // H~aug_t, dense 8 x 8, z~ order (x0..x4, 1, ua, ual); affine column of W~_t
-                    const double lu0 = gloc[0] + cb[0], lu1 = gloc[1] + cb[1];
-                    const double Hrow[8][8] = {{Hq[2], Hq[7], 0.0, 0.0, 0.0, gxs[0], 0.0, 0.0}, {Hq[7], Hq[3], 0.0, 0.0, 0.0, gxs[1], 0.0, 0.0},
-                                               {0.0, 0.0, Hq[4], 0.0, 0.0, gxs[2], 0.0, 0.0}, {0.0, 0.0, 0.0, Hq[5], 0.0, gxs[3], 0.0, 0.0},
-                                               {0.0, 0.0, 0.0, 0.0, Hq[6], gxs[4], 0.0, 0.0}, {gxs[0], gxs[1], gxs[2], gxs[3], gxs[4], 0.0, lu0, lu1},
-                                               {0.0, 0.0, 0.0, 0.0, 0.0, lu0, Hq[0], 0.0}, {0.0, 0.0, 0.0, 0.0, 0.0, lu1, 0.0, Hq[1]}};
-                    double *hc = RL.H + LT::HS * i;
-                    if constexpr (COMPACT) {    // rows 0..5, then H66 and H77 (rows 6, 7 are synthesised by the sweep, RowLdsC)
-#pragma unroll
-                        for (int r = 0; r < 6; r++)
-#pragma unroll
-                            for (int c = 0; c < 8; c++) hc[r * 8 + c] = Hrow[r][c];
-                        hc[48] = Hq[0]; hc[51] = Hq[1];
-                        if (has_u) { double *w = RL.W + LT::WS * i; w[5] = bbr[0]; w[13] = bbr[1]; w[16] = bbr[2]; w[17] = bbr[3]; w[18] = bbr[4]; }
-                    } else {
-#pragma unroll
-                    for (int r = 0; r < 8; r++)
-#pragma unroll
-                        for (int c = 0; c < 8; c++) hc[r * 8 + c] = Hrow[r][c];
-                    if (has_u) {
-#pragma unroll
-                        for (int k = 0; k < 5; k++) RL.W[RowLds::WS * i + k * 8 + 5] = bbr[k];
-                    }
-                    }
-                }
-                wave_sync();
-                MPC_TICK(9);
-#ifdef MPC_FACTOR_PLAIN
-                rowpar_factor(lane, N, RS, sweep_worker);
-#else
-                if constexpr (COMPACT) {
-#ifdef MPC_COMPACT_PLAIN
-                    rowpar_factor(lane, N, RS, sweep_worker);
-#else
-                    rowpar_factor_fast_c(lane, N, RS, sweep_worker);
-#endif
-                } else {
-#ifdef MPC_MFMA4
-                    if constexpr (G == 64) mfma4_factor(lane, N, RS); else
-#endif
-                    rowpar_factor_fast(lane, N, RS, sweep_worker);
-                }
-#endif
-                wave_sync();
-                F.i00 = 1.0; F.l = 0.0; F.i11 = 1.0; F.k0 = 0.0; F.k1 = 0.0;
-#pragma unroll
-                for (int c = 0; c < 5; c++) { F.K0[c] = 0.0; F.K1[c] = 0.0; }
-                if (has_u) {
-                    const double *ko = RL.H + LT::HS * i;
-#pragma unroll
-                    for (int c = 0; c < 5; c++) { F.K0[c] = ko[c]; F.K1[c] = ko[8 + c]; }
-                    F.k0 = ko[5]; F.k1 = ko[13]; F.i00 = ko[6]; F.l = ko[7]; F.i11 = ko[14];
-                }
-                // (no barrier: every lane overwrites only the block it has just read, and a wavefront's LDS operations complete in order)
-                if (has_u) {    // closed-loop matrix Acl = A + B K of this stage, row-major, for the row-parallel vector recursions
-                    double *acl = RL.H + LT::HS * i + RowVec::ACL;
-                    const StageLin SL = stage_lin();
-                    const double Ar[2][5] = {{1.0, 0.0, SL.a02, SL.a03, SL.a04}, {0.0, 1.0, SL.a12, SL.a13, SL.a14}};
-                    const double Br[2][2] = {{SL.b00, SL.b01}, {SL.b10, SL.b11}};
-#pragma unroll
-                    for (int c = 0; c < 5; c++) {
-                        acl[0 * RowVec::RS + c] = Ar[0][c] + Br[0][0] * F.K0[c] + Br[0][1] * F.K1[c];
-                        acl[1 * RowVec::RS + c] = Ar[1][c] + Br[1][0] * F.K0[c] + Br[1][1] * F.K1[c];
-                        acl[2 * RowVec::RS + c] = (c == 2 ? 1.0 : (c == 4 ? dt : 0.0)) + h2 * F.K1[c];
-                        acl[3 * RowVec::RS + c] = (c == 3 ? 1.0 : 0.0) + dt * F.K0[c];
-                        acl[4 * RowVec::RS + c] = (c == 4 ? 1.0 : 0.0) + dt * F.K1[c];
-                    }
-                }
-            } else
-                systolic_factor(i, N, S, Hq, gloc[0] + cb[0], gloc[1] + cb[1], gxs, bbr, rhoPi != 0.0, F);
+            factor_sweep(Hq, gloc, cb, bbr, F);
         }
-        MPC_TICK(2);
-        if (ROWPAR) {
-            if (has_u) {        // c_t = r_b + B k
-                double *cc = RL.H + LT::HS * i + RowVec::ACL + 5;      // c[r] closes row r
-                const StageLin SL = stage_lin();
-                cc[0 * RowVec::RS] = bbr[0] + SL.b00 * F.k0 + SL.b01 * F.k1; cc[1 * RowVec::RS] = bbr[1] + SL.b10 * F.k0 + SL.b11 * F.k1;
-                cc[2 * RowVec::RS] = bbr[2] + h2 * F.k1; cc[3 * RowVec::RS] = bbr[3] + dt * F.k0; cc[4 * RowVec::RS] = bbr[4] + dt * F.k1;
-            }
-            if (i == 0) {
-#pragma unroll
-                for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = SLDS ? rhoPi * lds_raw[RowLdsC::CT + slot * 5 + c] : x_init[c];
-            }
-            wave_sync();
-            rowpar_vector_fast<true>(lane, N, RS, sweep_worker);
-            wave_sync();
-            if (act) {
-                const double *xx = RL.H + LT::HS * i + RowVec::X;
-                double u0 = F.k0, u1 = F.k1;
-#pragma unroll
-                for (int c = 0; c < 5; c++) { za[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }
-                za[0] = u0; za[1] = u1;
-            }
-        } else
-            systolic_rollout<true>(i, N, S, F, x_init, bbr, za);
-        MPC_TICK(3);
+        affine_rollout(bbr, x_init, F, za);
 
         // ---- affine step: dt, dlam per row, step ratios, products dlam_aff * dt_aff ----
         double ppl[NB], pph[NB], pp1[NOBST], pp2[NOBST];
@@ -3248,54 +3069,8 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
                     gc[2] += geff * v.ax; gc[3] += geff * v.ay;
                 }
             }
-            MPC_TICK(5);
-            if (ROWPAR) {
-                if (act) {      // c~_t = gc_x + K' gc_u  (K = 0 in the terminal lane)
-                    double *cc = RL.H + LT::HS * i + RowVec::CT;
-#pragma unroll
-                    for (int c = 0; c < 5; c++) cc[c] = gc[2 + c] + F.K0[c] * gc[0] + F.K1[c] * gc[1];
-                }
-                wave_sync();
-                rowpar_vector_fast<false>(lane, N, RS, sweep_worker);
-                wave_sync();
-                if (has_u) {    // feed-forward of the corrector right-hand side: k = -Muu^-1 (gc_u + B' p_{t+1})
-                    const double *pp = RL.H + LT::HS * (i + 1) + RowVec::P;
-                    const double pv[5] = {pp[0], pp[1], pp[2], pp[3], pp[4]};
-                    const StageLin SL = stage_lin();
-                    const double m0 = gc[0] + SL.dua(pv), m1 = gc[1] + SL.dual(pv);
-                    F.k1 = fma(F.l, m0, -m1) * F.i11;
-                    F.k0 = fma(-F.l, F.k1, -(m0 * F.i00));
-                }
-            } else
-                systolic_corrector(i, N, S, gc, F);
+            corrector_sweeps(gc, bbr, x_init, za, F, dz);
         }
-        MPC_TICK(6);
-        if (ROWPAR) {
-            if (has_u) {        // homogeneous dynamics: c_t = B k
-                double *cc = RL.H + LT::HS * i + RowVec::ACL + 5;
-                const StageLin SL = stage_lin();
-                cc[0 * RowVec::RS] = SL.b00 * F.k0 + SL.b01 * F.k1; cc[1 * RowVec::RS] = SL.b10 * F.k0 + SL.b11 * F.k1;
-                cc[2 * RowVec::RS] = h2 * F.k1; cc[3 * RowVec::RS] = dt * F.k0; cc[4 * RowVec::RS] = dt * F.k1;
-            }
-            if (i == 0) {
-#pragma unroll
-                for (int c = 0; c < 5; c++) RL.H[RowVec::X + c] = 0.0;
-            }
-            wave_sync();
-            rowpar_vector_fast<true>(lane, N, RS, sweep_worker);
-            wave_sync();
-            if (act) {
-                const double *xx = RL.H + LT::HS * i + RowVec::X;
-                double u0 = F.k0, u1 = F.k1;
-#pragma unroll
-                for (int c = 0; c < 5; c++) { dz[2 + c] = xx[c]; u0 += F.K0[c] * xx[c]; u1 += F.K1[c] * xx[c]; }
-                dz[0] = u0; dz[1] = u1;
-            }
-        } else
-            systolic_rollout<false>(i, N, S, F, x_init, bbr, dz);
-#pragma unroll
-        for (int c = 0; c < 7; c++) dz[c] += za[c];
-        MPC_TICK(7);
 
         // ---- combined step: ratios, step length, update (instances that have stopped keep their state) ----
         {
