@@ -61,9 +61,9 @@ def agree_between_caps(a, b, tol):
 
 
 CAPS = {"RANDOM": ("20221031_215846", "20221031_220735", "20221031_221343"), "EDGE": ("20221031_220136", "20221031_220939", "20221031_221613")}
-# rows reproduced to (1e-3, 1e-6) per table, the smaller of the two lane mappings (scripts/replay_counts.py on MI355X); asserted: these minus 2
-MEASURED = {"20221031_215846": (48, 36), "20221031_220136": (57, 39), "20221031_220735": (44, 35), "20221031_220939": (46, 36), "20221031_221343": (21, 14),
-            "20221031_221613": (20, 15), "20221031_224515": (54, 49), "20221031_224642": (58, 46), "20221031_225145": (30, 26), "20221031_225445": (37, 28)}
+# rows reproduced to (1e-3, 1e-6) per table, the smaller of the two lane mappings (scripts/replay_counts.py on MI355X, round 5: 416 / 333 of 1000); asserted: these minus 2
+MEASURED = {"20221031_215846": (49, 37), "20221031_220136": (56, 39), "20221031_220735": (44, 35), "20221031_220939": (45, 36), "20221031_221343": (21, 14),
+            "20221031_221613": (19, 15), "20221031_224515": (54, 49), "20221031_224642": (58, 46), "20221031_225145": (30, 29), "20221031_225445": (40, 33)}
 
 
 @pytest.mark.parametrize("scen", ["RANDOM", "EDGE"])
