@@ -72,6 +72,7 @@ struct KParams {
     double tol, mu0, thr0;
     double polish_ratio;                 // polish of the interior point (kPolishMax), indicator (a); +inf = off (mpc_api.hip::make_params)
     float polish_tol;                    // ... indicator (b); +inf = off
+    float polish_kappa;                  // floor of the step estimate as a fraction of the step (mpc_config.polish_step_frac)
     float polish_tol_unsolved;           // kPolishUnsolved x polish_tol: the estimate above which a solve that has used up its polish is reported as not converged (status 2)
     double tl_min;                       // floor of t and lam: min(kTLMin, qp_tol / 10) (the floor must stay below the tolerance: an active row's rho - t is the floor)
     double mu_div, mu_cap, mu_settled;   // the divergence tests of the interior point as thresholds on mu (mpc_api.hip::make_params): kMuDiverged mu0, kMuCapFailed mu0, mu0 --
@@ -375,15 +376,15 @@ __device__ __forceinline__ void ipm_step_lengths(double rmax, double rmaxd, doub
     alpha = (amax >= 1.0) ? 1.0 : kFracToBoundary * amax;          // primal step: z, s, t
     alphad = (amaxd >= 1.0) ? 1.0 : kFracToBoundary * amaxd;       // dual step: lam
 }
-// polish indicator (b): est = s r min(1, 10 r) > tol with r = min(s / s', 1/2).  est is the SMALLEST of s / 2, s^2 / s' and 10 s^3 / s'^2 (r >= 1/2: the
+// polish indicator (b): est > tol with est = max(s r min(1, 10 r), kappa s), r = min(s / s', 1/2).  s r min(1, 10 r) is the SMALLEST of s / 2, s^2 / s' and 10 s^3 / s'^2 (r >= 1/2: the
 // first; 0.1 < r < 1/2: the second; r <= 0.1: the third), so est > tol is the conjunction of three comparisons -- no division, no case selection, float
 // arithmetic, every product left to right exactly as oracle/mpc_oracle.c::polish_wanted forms it.
-__device__ __forceinline__ void polish_wanted(float s, float sp, float tol, float tol_unsolved, bool &want, bool &unsolved)
+__device__ __forceinline__ void polish_wanted(float s, float sp, float tol, float tol_unsolved, float kappa, bool &want, bool &unsolved)
 {
-    float pa = 0.5f * s, pb = s * s, qb = tol * sp, pc = 10.0f * s * s * s, qc = tol * sp * sp, rb = tol_unsolved * sp, rc = tol_unsolved * sp * sp;
-    asm volatile("" : "+v"(pa), "+v"(pb), "+v"(qb), "+v"(pc), "+v"(qc), "+v"(rb), "+v"(rc));      // (products pinned: what is left are compares and mask ANDs -- nothing to branch around)
-    want = (pa > tol) & (pb > qb) & (pc > qc);
-    unsolved = (pa > tol_unsolved) & (pb > rb) & (pc > rc);      // the same estimate against kPolishUnsolved x polish_tol (KParams::polish_tol_unsolved)
+    float pa = 0.5f * s, pb = s * s, qb = tol * sp, pc = 10.0f * s * s * s, qc = tol * sp * sp, rb = tol_unsolved * sp, rc = tol_unsolved * sp * sp, pd = kappa * s;
+    asm volatile("" : "+v"(pa), "+v"(pb), "+v"(qb), "+v"(pc), "+v"(qc), "+v"(rb), "+v"(rc), "+v"(pd));      // (products pinned: what is left are compares and mask logic -- nothing to branch around)
+    want = ((pa > tol) & (pb > qb) & (pc > qc)) | (pd > tol);      // kappa s: the floor of the estimate (KParams::polish_kappa, mpc_config.polish_step_frac)
+    unsolved = ((pa > tol_unsolved) & (pb > rb) & (pc > rc)) | (pd > tol_unsolved);      // the same estimate against kPolishUnsolved x polish_tol (KParams::polish_tol_unsolved)
 }
 // does any lane of the calling lane's G-lane segment hold `w`?  One ballot; the segment mask is a per-lane constant.
 template <int G>
@@ -406,7 +407,7 @@ __device__ __forceinline__ void ipm_polish_step(const KParams &p, IpmState &S, i
     const float dm = fmaxf(fmaxf(fmaxf(fabsf(f0), fabsf(f1)), fabsf(f2)), fmaxf(fmaxf(fmaxf(fabsf(f3), fabsf(f4)), fabsf(f5)), fabsf(f6)));
     const float sn = (float)alpha * dm;
     bool w, u;
-    polish_wanted(sn, stepl, p.polish_tol, p.polish_tol_unsolved, w, u);      // (polish_tol = +inf: indicator off)
+    polish_wanted(sn, stepl, p.polish_tol, p.polish_tol_unsolved, p.polish_kappa, w, u);      // (polish_tol = +inf: indicator off)
     stepl = sn;
     S.want_step = seg_any<G>(w, lane); S.unsolved = seg_any<G>(u, lane);
 }

@@ -38,7 +38,7 @@ class MpcConfig(C.Structure):
         ("arena", _d * 4), ("bug_compat_predict", _i32),
         ("mu0", _d), ("thr0", _d),
         ("qp_fail_policy", _i32),
-        ("polish_ratio", _d), ("polish_tol", _d),
+        ("polish_ratio", _d), ("polish_tol", _d), ("polish_step_frac", _d),
     ]
 
 

@@ -41,7 +41,7 @@ extern "C" {
 #define MPC_NU 2
 
 /* Version of this header's binary interface: bumped whenever `struct mpc_config` changes size or layout or an entry point changes its signature
- * (round 4: trailing field qp_fail_policy, +8 bytes; round 5, version 6: trailing fields polish_ratio, polish_tol, +16 bytes, mpc_abi_version itself).  A host compares it with mpc_abi_version() of the library it loaded BEFORE it calls
+ * (round 4: trailing field qp_fail_policy, +8 bytes; round 5, version 6: trailing fields polish_ratio, polish_tol, polish_step_frac, +24 bytes, mpc_abi_version itself).  A host compares it with mpc_abi_version() of the library it loaded BEFORE it calls
  * mpc_default_config / mpc_create: a host built against an older struct would otherwise be written past its end.  (No reference counterpart: acados
  * regenerates and recompiles its C interface per problem.) */
 #define MPC_ABI_VERSION 6
@@ -86,6 +86,9 @@ typedef struct mpc_config {
                                step long).  0 = that indicator off.  Defaults 1e-2 and 1e-6 (the stated parity tolerance): the solves that met the tolerance 1e-6 .. 2e-5
                                from the QP's exact solution (0.7 % of the first solves of BASELINE configs[4]'s problem) are gone at +0.5 % iterations (DESIGN.md
                                section 2).  (The qp_solver tolerances of robot_ocp_problem.py:126-132 are left at acados' defaults there.) */
+    double polish_step_frac; /* floor of that estimate as a fraction of the step: est = max(s r min(1, 10 r), polish_step_frac s).  Default 0.01 from N = 30 on, else 0: at long
+                               horizons the last Newton step leaves 1.5 .. 10 % of itself behind whatever contraction was observed (5 solves of 1.2e7 fuzz solves ended
+                               1e-5 .. 2e-5 from the exact solution without it, none beyond 3e-7 with it; +0.4 .. 0.8 % iterations there, +3.8 % at N = 20 where nothing needs it) */
 } mpc_config;
 
 typedef struct mpc_handle mpc_handle;

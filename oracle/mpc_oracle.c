@@ -90,6 +90,11 @@ void orc_default_config(orc_config *c, int N, int n_obst, double Tf)
     c->thr0 = n_obst >= 8 ? 0.3 : 0.1;
     c->qp_fail_policy = 0;
     c->polish_ratio = 1e-2; c->polish_tol = 1e-6;
+    /* polish_step_frac (kappa): from N = 30 on the last Newton step of a solve is trusted to 1 % only.  Measured (scripts/fuzz_parity.py, fuzz_closed_loop.py, round 5): at
+     * N = 30 .. 62 five solves of 1.2e7 ended 1e-5 .. 2e-5 from the exact solution on either side although the observed contraction (4e-3) promised 3e-8 -- the remainder of
+     * their 2e-4 long last step was 1.5 % .. 10 % of it (barrier weights lam / t_floor through a long Riccati recursion); with kappa = 0.01 every one of them ends <= 3e-7.
+     * Price: +0.4 .. 0.8 % iterations at N >= 30 with 5 .. 10 obstacles -- and +3.8 % at N = 20, where no solve of 1e7 needed it: hence the horizon in the default. */
+    c->polish_step_frac = N >= 30 ? 0.01 : 0.0;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -701,16 +706,17 @@ static void residuals(const qp_t *Q, iter_t *I, double (*rg)[NZ], double *rs, do
 static double *g_trace = NULL; static int g_trace_cap = 0;
 void orc_set_trace(double *buf, int cap) { g_trace = buf; g_trace_cap = cap; }
 
-/* the polish's step indicator: est = s r min(1, 10 r) > tol with r = min(s / s', 1/2).  est is the smallest of s / 2, s^2 / s' and 10 s^3 / s'^2, so the test is
- * the conjunction of three comparisons: float arithmetic, no division, products left to right (rti_kernel.hpp::polish_wanted does exactly this) */
+/* the polish's step indicator: est > tol with est = max(s r min(1, 10 r), kappa s), r = min(s / s', 1/2).  s r min(1, 10 r) is the smallest of s / 2, s^2 / s' and
+ * 10 s^3 / s'^2, so that part is the conjunction of three comparisons; kappa s is the floor of the estimate: what the last Newton step of a long horizon leaves
+ * behind whatever contraction was observed (polish_step_frac).  Float arithmetic, no division, products left to right (rti_kernel.hpp::polish_wanted does exactly this) */
 static _Thread_local int g_last_dead = 0, g_last_npolish = 0; static _Thread_local float g_last_step = 0;
 int orc_last_dead_pairs(void) { return g_last_dead; }
 int orc_last_npolish(void) { return g_last_npolish; }
 double orc_last_step_norm(void) { return (double)g_last_step; }
-static int polish_wanted(float s, float sp, float tol)
+static int polish_wanted(float s, float sp, float tol, float kappa)
 {
-    const float pa = 0.5f * s, pb = s * s, qb = tol * sp, pc = 10.0f * s * s * s, qc = tol * sp * sp;
-    return pa > tol && pb > qb && pc > qc;
+    const float pa = 0.5f * s, pb = s * s, qb = tol * sp, pc = 10.0f * s * s * s, qc = tol * sp * sp, pd = kappa * s;
+    return (pa > tol && pb > qb && pc > qc) || pd > tol;
 }
 
 static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, double *kkt)
@@ -773,12 +779,13 @@ static int ipm_solve(const orc_config *c, qp_t *Q, iter_t *I, int *iters_out, do
              *      of the stage's last step alpha * dz_i, s_i' of the one before and r = min(s_i / s_i', 1/2) the observed contraction, the estimate
              *      s_i r min(1, 10 r) = min(s_i / 2, s_i^2 / s_i', 10 s_i^3 / s_i'^2) of what remains exceeds polish_tol for ANY stage.  Float arithmetic, as in
              *      polish_wanted(), so that both sides decide alike; per stage because a stage is a lane of the kernels: no cross-lane reduction, one ballot.
+             *      From N = 30 on the estimate has the floor polish_step_frac * s_i (see orc_default_config).
              * Measured (scripts/polish_probe.py on 8000 first / second solves of C5's problem): beyond 1e-6 from the exact solution 55 -> 0, beyond 1e-7
              * 144 -> 25, at +0.5 % iterations. */
             int want = c->polish_ratio > 0 && res[3] > c->polish_ratio * cprev, unsolved = 0;
             if (c->polish_tol > 0) for (int i = 0; i <= N; i++) {
-                want = want || polish_wanted(st_now[i], st_prev[i], (float)c->polish_tol);
-                unsolved = unsolved || polish_wanted(st_now[i], st_prev[i], POLISH_UNSOLVED * (float)c->polish_tol);
+                want = want || polish_wanted(st_now[i], st_prev[i], (float)c->polish_tol, (float)c->polish_step_frac);
+                unsolved = unsolved || polish_wanted(st_now[i], st_prev[i], POLISH_UNSOLVED * (float)c->polish_tol, (float)c->polish_step_frac);
             }
             /* NOT SOLVED: the polish is used up and the step estimate still stands two orders of magnitude above polish_tol.  That is not a tail but an end-game
              * whose Newton steps have lost their accuracy to the barrier weights lam / t_floor (found by scripts/fuzz_parity.py: a stale warm start, every

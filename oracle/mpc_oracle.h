@@ -77,6 +77,7 @@ typedef struct orc_config {
      * end-game), or (polish_tol) while for any stage the estimate s r min(1, 10 r) of the remaining primal error exceeds polish_tol (s: max-norm of the stage's
      * last step, r = min(s / previous s, 1/2)); 0 = that indicator off.  Defaults 1e-2 and 1e-6 (the stated parity tolerance). */
     double polish_ratio, polish_tol;
+    double polish_step_frac;  /* floor of that estimate as a fraction of s: default 0.01 from N = 30 on, else 0 (orc_default_config says why) */
 } orc_config;
 
 void orc_default_config(orc_config *c, int N, int n_obst, double Tf);

@@ -29,7 +29,7 @@ class OrcConfig(C.Structure):
         ("arena", _d * 4), ("bug_compat_predict", C.c_int),
         ("mu0", _d), ("thr0", _d),
         ("qp_fail_policy", C.c_int),
-        ("polish_ratio", _d), ("polish_tol", _d),
+        ("polish_ratio", _d), ("polish_tol", _d), ("polish_step_frac", _d),
     ]
 
 

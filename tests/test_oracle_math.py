@@ -326,6 +326,19 @@ def test_polish_and_the_unsolved_rule_on_the_oracle():
     r = orc.rti_solve(cfg, x0[b], P, goal[b], X1, U1)
     assert r0["status"] == 0 and r["status"] == 2 and r["iters"] < cfg.qp_iter_max
     assert orc.rti_solve(orc.config(N, no, 0.1 * N, polish_tol=0.0), x0[b], P, goal[b], X1, U1)["status"] == 0      # ... which is what it was without the rule
+    # (2b) the long-horizon findings of the round-5 fuzz (1e-5 .. 2e-5 from exact on either side although the observed contraction promised 3e-8): with the floor of
+    # the estimate (polish_step_frac 0.01 from N = 30 on: the default) they end within 3e-7, without it they are where the fuzz found them
+    for N, no, B, seed, b, bxt, was in ((62, 5, 1500, 261131589, 1116, 1, 2e-6), (30, 5, 1025, 390641943, 325, 1, 1e-5)):
+        x0, goal, obst = random_batch(B, no, seed=seed)
+        for frac, bound in ((0.0, None), (None, 3e-7)):
+            cfg = orc.config(N, no, 0.1 * N, bx_terminal=bxt, **({} if frac is None else dict(polish_step_frac=frac)))
+            X, U = orc.initial_guess(cfg, x0[b]); P = orc.predict_params(cfg, obst[b])
+            r = orc.rti_solve(cfg, x0[b], P, goal[b], X, U)
+            v = step_vector(N, X, U, r["X"], r["U"])
+            vex, ok, _ = exact_qp(orc.export_qp(cfg, x0[b], P, goal[b], X, U), v)
+            dd = float(np.abs(v - vex).max())
+            assert ok and r["status"] == 0 and (dd > was if bound is None else dd < bound), (N, frac, dd)
+    assert orc.config(20, 3, 2.0).polish_step_frac == 0.0 and orc.config(30, 3, 3.0).polish_step_frac == 0.01
     # (3)
     N, no, B = 20, 3, 64
     x0, goal, obst = random_batch(B, no, seed=5)
