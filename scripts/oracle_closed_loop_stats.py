@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """CPU ORACLE closed loops on random scenarios (the distributions of bench.py's C3 / C5): mean interior-point iterations and status counts per configuration
-under a variant of the specification (--exp -> ORC_EXP, --cfg overrides).  Test infrastructure; no GPU.
-    python scripts/oracle_closed_loop_stats.py --exp 26 --cfg polish_tol=-1e-6"""
+under a variant of the specification (--cfg overrides; --exp -> ORC_INVESTIGATE, the oracle's investigation switches).  Test infrastructure; no GPU.
+    python scripts/oracle_closed_loop_stats.py --cfg polish_ratio=0.0,polish_tol=0.0"""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
@@ -13,7 +13,7 @@ ap.add_argument("--B", type=int, default=512); ap.add_argument("--steps", type=i
 ap.add_argument("--sizes", default="20:3,20:5,20:10,30:3,50:10,10:5")
 ap.add_argument("--out", default=None)
 a = ap.parse_args()
-os.environ["ORC_EXP"] = str(a.exp)
+os.environ["ORC_INVESTIGATE"] = str(a.exp)
 from oracle import oracle as orc
 from helpers import random_batch
 orc.build()

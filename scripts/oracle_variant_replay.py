@@ -3,12 +3,12 @@
 
 All ten recorded tables (tests/golden/reference_tables.json: src/simulation/test_data/20221031_*; the two `interpolate_init` ones with the straight-line guess of
 robot_ocp_problem.py:293-300), protocol experiments.py:20-36 with the reference's own numpy streams, tests/helpers.py::OracleLoop.  A variant is a set of
-oracle configuration overrides (--cfg qp_tol=1e-8,polish_tol=-1e-6) and / or the oracle's experiment switches (--exp N -> environment ORC_EXP, read by
+oracle configuration overrides (--cfg qp_tol=1e-8,polish_tol=0.0) and / or the oracle's investigation switches (--exp N -> environment ORC_INVESTIGATE, read by
 oracle/mpc_oracle.c).  Output per table: seeds reproduced to 1e-3 / 1e-6 (control steps exact, flags equal), per-seed rows, number of solves that did not
 converge; totals; and, with --seeds, only those seeds (the 12 converged-but-unmatched ones of VERDICT r04 item 3).
 
     python scripts/oracle_variant_replay.py --tag base --out profiles/r05_variant_base.json
-    python scripts/oracle_variant_replay.py --exp 7 --cfg polish_tol=-1e-6 --tag polish --out ...
+    python scripts/oracle_variant_replay.py --exp 3 --cfg qp_tol=1e-8 --tag rows --out ...
 """
 import argparse
 import json
