@@ -16,7 +16,8 @@ Workloads (BASELINE.json configs):
   c4 (configs[3]): ONE global batch of 262144 randomized scenarios (seed 1234), rank r solves the contiguous slice
      mpc_gpu.sharding.shard_slice(262144, r, world) -- 32768 per GPU on 8 GPUs (strong scaling)
   c5 (configs[4]): N = 50, 10 obstacles, one global batch of 32768, sharded the same way (4096 per GPU on 8 GPUs)
-Multi-GPU: one process per GPU; `--gpus N` without a torchrun environment starts the N ranks itself (torch.distributed.run, before
+Multi-GPU: one process per GPU, the SAME workload for every N unless --workload says otherwise (default c2: 1024 per GPU, weak -- one curve for the driver's 1 / 2 / 4 / 8 runs);
+`--gpus N` without a torchrun environment starts the N ranks itself (torch.distributed.run, before
 anything touches the GPU) and relays rank 0's JSON line.  No data-path collective; the per-scenario costs of 50 consecutive control
 steps travel in one all-gather on a side stream -- through the library's own C-ABI collective (--exchange capi, the default: rank 0's
 mpc_comm_unique_id is broadcast over the torch.distributed group that the launcher set up anyway, every rank calls mpc_comm_init, and each
@@ -680,8 +681,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20, help="timed episodes (100 control steps each)")
     ap.add_argument("--warmup", type=int, default=3, help="untimed episodes")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                    help="default: c2 on one GPU (BASELINE configs[1], the configuration the metric is quoted on); with --gpus N > 1 the sharded "
-                         "global batch c4 (configs[3]: 262144 scenarios over the ranks)")
+                    help="default: c2 for every N (BASELINE configs[1], the configuration the metric is quoted on: 1024 scenarios per GPU, weak scaling); c4 / c5: "
+                         "the sharded global batches of configs[3] / [4] (262144 / 32768 scenarios over the ranks, strong scaling)")
     ap.add_argument("--exchange", default="capi", choices=["capi", "torch"],
                     help="multi-rank cost all-gather: capi = the library's own C-ABI collective (mpc_comm_init + mpc_allgather_cost_dev, RCCL called by "
                          "libmpcgpu; default), torch = torch.distributed.all_gather_into_tensor")
@@ -703,7 +704,10 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the multi-rank plumbing (gloo), no kernels")
     args = ap.parse_args()
     if args.workload is None:
-        args.workload = "c4" if max(args.gpus, int(os.environ.get("WORLD_SIZE", "1"))) > 1 else "c2"
+        # ONE workload for every N, so that the driver's 1 / 2 / 4 / 8-GPU values form one curve: the configuration the metric is quoted on (C2), 1024 scenarios PER
+        # GPU -- weak scaling.  The sharded global batches of BASELINE configs[3] / [4] are `--workload c4 | c5` (strong scaling; one rank's share of them is
+        # measured on one GPU by the default run: c4_share, c5_share)
+        args.workload = "c2"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args, sys.argv[1:])

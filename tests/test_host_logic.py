@@ -198,3 +198,18 @@ def test_bench_dry_run_last_stdout_line_parses(built):
     for wl in ("c2", "c4"):
         line = _bench_dry_run(wl)
         assert len(json.dumps(line)) < 4096 and line["metric"].startswith("MPC solves/sec")
+
+
+def test_bench_default_workload_is_the_same_for_every_rank_count(built):
+    """The driver runs `bench.py --gpus N` for N = 1, 2, 4, 8 without a --workload and computes scaling from the values: they must be ONE workload -- the
+    configuration the metric is quoted on (C2), 1024 scenarios per GPU, weak scaling -- not C2 at N = 1 and the sharded C4 beyond (rounds 1-4)."""
+    import json
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["workload"].startswith("C2") and line["config"]["global_batch"] == 2048
+    assert line["metric"] == "MPC solves/sec (N=20, 3 obstacles)"
