@@ -675,6 +675,21 @@ def dry_run(args, world, rank):
         dist.destroy_process_group()
 
 
+def rendezvous_guard(seconds, rank, _exit=os._exit):
+    """A timer that ends THIS process with code 3 if it is not cancelled within `seconds`: mpc_comm_init (ncclCommInitRank) blocks in native code until every
+    rank has joined, so a rank that never arrives would otherwise hang the job; torchrun then takes the other ranks down."""
+    import threading
+
+    def fire():
+        sys.stderr.write(f"bench.py: rank {rank} still inside the mpc_comm_init rendezvous after {seconds:.0f} s -- giving up (MPC_BENCH_COMM_TIMEOUT)\n")
+        sys.stderr.flush()
+        _exit(3)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -791,12 +806,16 @@ def main():
                 ok, err = 0.0, f"{type(e).__name__}: {e}"[:200]
             ok, err = agree(ok, err)
             if ok == 1.0:
+                # the rendezvous itself cannot be abandoned once entered (a native blocking call on every rank): a rank still inside it after
+                # MPC_BENCH_COMM_TIMEOUT seconds (default 300) ends the job non-zero with a message instead of hanging the launcher
+                guard = rendezvous_guard(float(os.environ.get("MPC_BENCH_COMM_TIMEOUT", "300")), rank)
                 try:
                     uid = exchange_comm_id(dist, rank, mpc_gpu.BatchedMpc.comm_unique_id) if world > 1 else bytes(mpc_gpu.BatchedMpc.comm_unique_id())
                     loop.m.comm_init(rank, world, uid)
                 except Exception as e:      # noqa: BLE001
                     ok, err = 0.0, f"{type(e).__name__}: {e}"[:200]
                 ok, err = agree(ok, err)
+                guard.cancel()
             if ok < 1.0:
                 exchange_note = f"capi set-up failed on a rank ({err or 'another rank'})"
                 try:

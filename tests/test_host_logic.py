@@ -213,3 +213,19 @@ def test_bench_default_workload_is_the_same_for_every_rank_count(built):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["workload"].startswith("C2") and line["config"]["global_batch"] == 2048
     assert line["metric"] == "MPC solves/sec (N=20, 3 obstacles)"
+
+
+def test_bench_rendezvous_guard_fires_once_and_can_be_cancelled():
+    """mpc_comm_init blocks in native code until every rank has joined: bench.py arms a timer around it that ends the process non-zero instead of hanging the
+    launcher.  Here with a stand-in for os._exit: an armed guard fires with code 3, a cancelled one never does."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    fired = []
+    g = bench.rendezvous_guard(0.05, 1, _exit=fired.append)
+    time.sleep(0.5)
+    assert fired == [3] and not g.is_alive()
+    g = bench.rendezvous_guard(0.2, 0, _exit=fired.append)
+    g.cancel()
+    time.sleep(0.5)
+    assert fired == [3]
