@@ -1,7 +1,10 @@
 """Randomised sweep of the FUSED closed-loop control step (mpc_closed_loop_step_dev) against the oracle-side loop (tests/helpers.py::OracleLoop),
 resynchronised before every step: horizon, obstacle count, batch, lane mapping, the aliasing defect switch and the noise drawn at random.
 Per step and instance: status, obstacle states bit for bit, episode flags and step counter, plant state / warm start / margin to 1e-6 (or the
-step judged by the QP).  usage (GPU box): python scripts/fuzz_closed_loop.py [seconds] [seed]   -> gpurun_out/fuzz_closed_loop.json"""
+step judged by the QP).  A status difference with both sides at the iteration cap or one short of it is the at-the-cap borderline of tests/helpers.py::judge_against_oracle
+(recorded with both iteration counts under `at_cap`, not a finding).
+usage (GPU box): python scripts/fuzz_closed_loop.py [seconds] [seed]   -> gpurun_out/fuzz_closed_loop.json
+                 python scripts/fuzz_closed_loop.py replay <earlier json> <its seed>   runs only the configurations that record lists under `failures` / `at_cap`"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "dynamic-obstacle-avoidance-mpc_amd"), os.path.join(ROOT, "tests")]
@@ -12,16 +15,26 @@ from oracle import oracle as orc
 from helpers import OracleLoop, adjudicate, random_batch
 from test_gpu_closed_loop import GpuLoop
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
-t0 = time.time(); log = []; fails = []; adjudicated = []
-while time.time() - t0 < budget:
+replay = None
+if len(sys.argv) > 1 and sys.argv[1] == "replay":
+    earlier = json.load(open(sys.argv[2]))
+    replay = {f["seed"] for f in earlier["failures"] + earlier.get("at_cap", [])}
+    budget, rng = 1e9, np.random.default_rng(int(sys.argv[3]))
+else:
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+t0 = time.time(); log = []; fails = []; adjudicated = []; at_cap = []
+while time.time() - t0 < budget and (replay is None or replay):
     N = int(rng.choice([3, 9, 10, 15, 20, 21, 31, 40, 50])); no = int(rng.integers(1, 11)); B = int(rng.choice([1, 3, 8, 21, 40]))
     if N > 31: B = min(B, 12)
     alias = bool(rng.random() > 0.4); lps = int(rng.choice([0, 1])); lanes = int(rng.choice([0, 0, 16, 21, 32, 64])); K = 6
     seed = int(rng.integers(1 << 30))
+    speeds = rng.uniform(-0.5, 1.5, B)
+    if replay is not None:
+        if seed not in replay: continue
+        replay.discard(seed)
     x0, goal, obst = random_batch(B, no, seed=seed)
-    x0[:, 3] = rng.uniform(-0.5, 1.5, B)
+    x0[:, 3] = speeds
     noise = np.random.default_rng(seed).standard_normal((K, B, no, 2))
     cfg = orc.config(N, no, 0.1 * N)
     rec = dict(N=N, n_obst=no, B=B, alias=alias, lps=lps, lanes=lanes, seed=seed)
@@ -43,7 +56,11 @@ while time.time() - t0 < budget:
                 why = None
                 if r is None:
                     if not all(np.array_equal(after[key][b], before[key][b]) for key in ("x0", "obst", "X", "U")) or after["steps"][b] != before["steps"][b]: why = "finished episode moved"
-                elif after["status"][b] != r["status"]: why = f"status {after['status'][b]} vs {r['status']}"
+                elif after["status"][b] != r["status"]:
+                    ig, io, cap = int(after["iters"][b]), int(r["iters"]), int(cfg.qp_iter_max)
+                    what = dict(rec, step=k, inst=b, status_gpu=int(after["status"][b]), status_oracle=int(r["status"]), iters_gpu=ig, iters_oracle=io, cap=cap)
+                    if min(ig, io) >= cap - 1: at_cap.append(what)
+                    else: why = f"status {after['status'][b]} ({ig} iterations) vs {r['status']} ({io}), cap {cap}"
                 elif not np.array_equal(after["obst"][b], L.obst): why = "obstacle motion"
                 elif after["flags"][b] != L.flags or after["steps"][b] != L.steps: why = f"flags/steps {after['flags'][b]},{after['steps'][b]} vs {L.flags},{L.steps}"
                 elif r["status"] == 0:
@@ -67,9 +84,9 @@ while time.time() - t0 < budget:
 mpc_gpu.BatchedMpc.default_lanes_per_stage = 0
 kernels = sorted({r.get("kernel", "?") for r in log})
 ex = [a for a in adjudicated if a["kind"] == "exact"]
-out = dict(configurations=len(log), distinct_kernels=len(kernels), kernels=kernels, failures=fails, worst=max((r.get("worst", 0.0) for r in log), default=0.0),
+out = dict(configurations=len(log), distinct_kernels=len(kernels), kernels=kernels, failures=fails, at_cap=at_cap, worst=max((r.get("worst", 0.0) for r in log), default=0.0),
            adjudicated=len(adjudicated), adjudicated_exact=len(ex), worst_d_gpu_exact=max((a["d_gpu"] for a in ex), default=0.0), worst_d_oracle_exact=max((a["d_oracle"] for a in ex), default=0.0),
            worst_d_gpu_oracle_adjudicated=max((a["d_gpu_oracle"] for a in adjudicated), default=0.0), adjudications=sorted(adjudicated, key=lambda a: -a["d_gpu_oracle"])[:40])
-print(json.dumps({k: out[k] for k in ("configurations", "distinct_kernels", "failures", "worst", "adjudicated", "adjudicated_exact", "worst_d_gpu_exact", "worst_d_oracle_exact", "worst_d_gpu_oracle_adjudicated")}, indent=1)[:5000])
+print(json.dumps({k: out[k] for k in ("configurations", "distinct_kernels", "failures", "at_cap", "worst", "adjudicated", "adjudicated_exact", "worst_d_gpu_exact", "worst_d_oracle_exact", "worst_d_gpu_oracle_adjudicated")}, indent=1)[:5000])
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "fuzz_closed_loop.json"), "w"), indent=1)
 sys.exit(1 if fails else 0)
