@@ -40,3 +40,4 @@ if split:
     for k, n in zip(range(10, 15), ["loads + look-ahead", "iterate loads", "linearise + W staging", "row state init", "tail (step, plant, stores)"]):
         print(f"  outside the IPM loop: {n:28s} {t[:,k].mean():10.0f} cycles")
 for k, n in enumerate(names[:10]): print(f"  {n:24s} {t[:,k].mean():10.0f} cycles  {100*t[:,k].mean()/tot:5.1f}%   per iter {t[:,k].mean()/it:8.0f}")
+if split: print(f"  {'(split kernel: the affine forward sweep itself, not in the total above)':24s} {t[:,15].mean():10.0f} cycles   per iter {t[:,15].mean()/it:8.0f}")
