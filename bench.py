@@ -492,8 +492,16 @@ def roofline(loop, N, no, r):
         # perfect schedule of the same instructions could recover; the rest of the distance to the FP64 peak is lanes without data and the lone stream.
         latency_frac = (LONE_WAVE_VALU_CYCLES * pm["valu_insts"] + LONE_WAVE_LDS_CYCLES * pm["lds_insts"]) / (4.0 * pm["wave_cycles"])
         wait_frac = pm["wait_any"] / pm["wave_cycles"] if pm.get("wait_any") else None
+    sweep_frac = None
+    try:        # per phase: the sweeps' loop bodies in the shipped listing at the same prices (dependent multiply-adds 8.4) over their measured cycles (scripts/critical_path_model.py)
+        cp = json.load(open(os.path.join(ROOT, "profiles", "r05_critical_path_c2.json")))
+        for rec in cp["kernels"]:
+            if rec["kernel"] == kname:
+                sweep_frac = {"factor": rec["factor_sweep"]["model_over_measured"], "vector": rec["vector_sweep"]["model_over_measured"]}
+    except (OSError, KeyError, ValueError):
+        pass
     return {"bound": "fp64_valu", "achieved": flops / avg_s / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
-            "latency_frac": latency_frac, "wait_frac": wait_frac,
+            "latency_frac": latency_frac, "wait_frac": wait_frac, "sweep_frac": sweep_frac,
             "latency_model": (f"(5.0 cycles x SQ_INSTS_VALU + 14 cycles x SQ_INSTS_LDS) / (4 x SQ_WAVE_CYCLES) of profiles/{pm['file']}: the kernel's own instruction stream at the "
                               "price a lone wavefront pays per instruction (micro-benchmarks, docs/HISTORY.md 4.1c; all VALU taken as independent: a lower bound of "
                               "the floor) over the cycles its wavefronts were resident") if latency_frac is not None else None,
@@ -573,7 +581,7 @@ def compact_line(out):
     line.update(pick(out, ("dtype", "data")))
     line["config"] = pick(cfg, ("workload", "global_batch", "per_gpu_batch", "N", "n_obst", "qp_tol", "control_steps_per_step", "parallelism"))
     line.update(pick(out, ("mean_ipm_iters", "qp_failure_frac", "streams_per_gpu", "exchange", "rccl_ranks", "gather_check", "rccl_path", "torch_pg")))
-    line["roofline"] = pick(out["roofline"], ("bound", "achieved", "peak", "unit", "frac", "issue", "latency_frac", "lanes_active", "lanes_exec", "traffic", "kernel", "avg_launch_us"))
+    line["roofline"] = pick(out["roofline"], ("bound", "achieved", "peak", "unit", "frac", "issue", "latency_frac", "sweep_frac", "lanes_active", "lanes_exec", "traffic", "kernel", "avg_launch_us"))
     for key, name in (("extra", "c3"), ("extra_c5", "c5"), ("extra_c4_share", "c4_share"), ("extra_c5_share", "c5_share")):
         e = out.get(key)
         if e:
