@@ -3,7 +3,7 @@ cases use small batches).  For each configuration: B random instances, first sol
 the oracle is fed the GPU's own shifted iterate (identical inputs per solve).  Every converged instance whose GPU and oracle iterates differ by more than
 1e-6 is adjudicated against the exact solution of the exported QP (tests/helpers.py::adjudicate -> exact_qp: an active-set iteration with verified KKT
 conditions); a random sample of the instances that AGREE is measured against it too (the interior point's own floor).
-usage (GPU box): python scripts/parity_sweep.py [quick]      -> gpurun_out/parity_sweep.json (copied to profiles/r05_parity_sweep.json)"""
+usage (GPU box): python scripts/parity_sweep.py [quick] [seed offset]      -> gpurun_out/parity_sweep.json (copied to profiles/r05_parity_sweep.json; offset 1000: r05_parity_sweep_second_sample.json)"""
 import sys, os, json, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "dynamic-obstacle-avoidance-mpc_amd"), os.path.join(ROOT, "tests")]
@@ -13,9 +13,10 @@ from oracle import oracle as orc
 from helpers import oracle_P, adjudicate, exact_qp, step_vector, random_batch, EXACT_FACTOR, EXACT_CAP
 
 QUICK = len(sys.argv) > 1 and sys.argv[1] == "quick"
+SEED_OFFSET = next((int(a) for a in sys.argv[1:] if a.isdigit()), 0)      # another sample of the same configurations
 MAX_ADJ = 400          # outliers adjudicated per step (all of them in every configuration measured so far)
 N_SAMPLE = 40 if QUICK else 150    # agreeing instances measured against the exact solution per configuration (first step)
-out = {"method": __doc__.split("usage")[0].strip(), "qp_tol": orc.config().qp_tol, "EXACT_FACTOR": EXACT_FACTOR, "EXACT_CAP": EXACT_CAP, "configurations": {}}
+out = {"method": __doc__.split("usage")[0].strip(), "qp_tol": orc.config().qp_tol, "EXACT_FACTOR": EXACT_FACTOR, "EXACT_CAP": EXACT_CAP, "seed_offset": SEED_OFFSET, "configurations": {}}
 t_all = time.time()
 # (lps, waves, lanes): lanes per horizon stage (1: rti_solve_kernel, 3 / 2: rti_split_kernel), wavefronts per SIMD of the split kernel,
 # lanes per instance of the one-lane kernel (21: three instances per wavefront, compact LDS blocks; 0: automatic)
@@ -26,7 +27,7 @@ CONFIGS = [(20, 3, 20000, 1, 1, 32), (20, 3, 20000, 1, 1, 21), (20, 3, 20000, 3,
 if QUICK:
     CONFIGS = [(20, 3, 4000, 1, 1, 21), (20, 3, 4000, 3, 1, 0), (50, 10, 1500, 1, 1, 0)]
 for N, no, B, lps, waves, lanes in CONFIGS:
-    x0, goal, obst = random_batch(B, no, seed=4242 + N + no)
+    x0, goal, obst = random_batch(B, no, seed=4242 + N + no + SEED_OFFSET)
     cfg = orc.config(N, no, 0.1 * N)
     res = []
     with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
