@@ -50,6 +50,7 @@ LONE_WAVE_LDS_CYCLES = 14.0  # (issue cost, whatever the width): micro-benchmark
 VALU_CYCLES_PER_INST = 4     # a wave64 VALU instruction holds its 16-lane SIMD for 4 cycles: the issue roof of one SIMD is 1 instruction per 4 cycles
 EPISODE = 100                # control steps per episode = per bench step
 GATHER_EVERY = 50            # control steps per cost all-gather message
+PMC_STALE_TOL = 0.05         # a committed PMC profile speaks for this run only while the run's launch time is within 5 % of the profile's
 EVENT_EVERY = 7              # HIP events around every 7th launch (coprime with EPISODE: the samples visit every position of an episode)
 
 WORKLOADS = {   # name: (N, n_obst, per-GPU batch or None, global batch or None, scaling)
@@ -107,7 +108,7 @@ def measured_pmc(kernel_name, batch):
             if d["batch"] == batch and kernel_name.replace(" ", "") in d["kernel"].replace(" ", ""):
                 t = d["hbm_traffic_bytes_per_launch"]
                 c = d["counters"]
-                best = dict(traffic=t["fetch_raw_kb"] * 1024 + t["write_bytes"], file=os.path.basename(f),
+                best = dict(traffic=t["fetch_raw_kb"] * 1024 + t["write_bytes"], file=os.path.basename(f), kernel=d["kernel"],
                             valu_insts=c.get("SQ_INSTS_VALU", {}).get("mean_per_launch"), avg_ns=(d.get("kernel_stats") or {}).get("avg_ns"),
                             lds_insts=c.get("SQ_INSTS_LDS", {}).get("mean_per_launch"), wave_cycles=c.get("SQ_WAVE_CYCLES", {}).get("mean_per_launch"),
                             wait_any=c.get("SQ_WAIT_ANY", {}).get("mean_per_launch"),
@@ -340,7 +341,7 @@ def cpu_budget():
     return n, quota
 
 
-def cpu_baseline(N, n_obst, x0, goal, obst, budget_s=24.0):
+def cpu_baseline(N, n_obst, x0, goal, obst, budget_s=18.0, steady_s=5.0):
     """The oracle (CPU restatement of the same RTI step; acados itself cannot run on this box) timed on this box's host cores on a
     bounded sample of the same workload: closed-loop control steps of the first S scenarios (a few untimed, then timed until the budget
     is used; solve calls only).  Three figures: all hardware threads or half of them, whichever is faster (`value`, `cores`); one thread;
@@ -353,27 +354,26 @@ def cpu_baseline(N, n_obst, x0, goal, obst, budget_s=24.0):
     dt = 0.1
 
     def closed_loop_rate(S, nthreads, budget, warm=5):
-        xs, gs, os_ = x0[:S].copy(), goal[:S].copy(), obst[:S].copy()
-        X = np.zeros((S, N + 1, 5)); U = np.zeros((S, N, 2))
-        for b in range(S):
-            X[b], U[b] = orc.initial_guess(cfg, xs[b])
+        """solve calls of closed-loop episodes of the first S scenarios (each episode from the initial scenario, as the GPU's) until `budget` seconds have passed;
+        the first `warm` control steps of the first episode untimed"""
         solves, secs, steps, t_begin = 0, 0.0, 0, time.perf_counter()
         while True:
-            P = np.stack([orc.predict_params(cfg, os_[b]) for b in range(S)])
-            t0 = time.perf_counter()
-            r = orc.rti_solve_batch(cfg, xs, P, gs, X, U, nthreads=nthreads)
-            t1 = time.perf_counter()
-            if steps >= warm:
-                solves += S; secs += t1 - t0
-            X, U = r["X"], r["U"]
+            xs, gs, os_ = x0[:S].copy(), goal[:S].copy(), obst[:S].copy()
+            X = np.zeros((S, N + 1, 5)); U = np.zeros((S, N, 2))
             for b in range(S):
-                xs[b] = orc.dynamics(xs[b], r["u0"][b], dt)[0]
-                for j in range(n_obst):
-                    os_[b, j] = orc.obstacle_step(cfg, os_[b, j], dt)
-                X[b], U[b] = orc.shift(cfg, X[b], U[b])
-            steps += 1
-            if (time.perf_counter() - t_begin > budget and steps >= warm + 3) or steps >= EPISODE:
-                return solves / secs, steps - warm
+                X[b], U[b] = orc.initial_guess(cfg, xs[b])
+            for _ in range(EPISODE):
+                P = orc.predict_params_batch(cfg, os_)
+                t0 = time.perf_counter()
+                r = orc.rti_solve_batch(cfg, xs, P, gs, X, U, nthreads=nthreads)
+                t1 = time.perf_counter()
+                if steps >= warm:
+                    solves += S; secs += t1 - t0
+                X, U = r["X"], r["U"]
+                orc.advance_batch(cfg, xs, r["u0"], os_, X, U)      # plant step, obstacle step, warm-start shift: in place, one call
+                steps += 1
+                if time.perf_counter() - t_begin > budget and steps >= warm + 3:
+                    return solves / secs, steps - warm
 
     S_all = min(len(x0), max(64, 8 * ncpu))
     # doubling sweep over the OpenMP thread count, 8, 16, 32 ... up to the hardware threads this process may run on, ~2 s each; it stops at the plateau
@@ -381,11 +381,15 @@ def cpu_baseline(N, n_obst, x0, goal, obst, budget_s=24.0):
     # was still linear at 32 threads although the cgroup quota reads ~16 cores
     rates, n, prev = {}, min(8, ncpu), 0.0
     while True:
-        rates[n] = closed_loop_rate(S_all, n, budget_s / 12)
+        rates[n] = closed_loop_rate(S_all, n, budget_s / 9)
         if n >= ncpu or rates[n][0] < 1.05 * prev:
             break
         prev, n = rates[n][0], min(ncpu, 2 * n)
     best = max(rates, key=lambda n: rates[n][0])
+    # ... and the plateau thread count timed three times over >= 5 s of wall time each (the sweep's 2 s points differ by +-25 % between runs on the driver's box,
+    # VERDICT r05 weak 7): `value` is the median, `spread` the three samples' minimum and maximum
+    reps = sorted(closed_loop_rate(S_all, best, steady_s) for _ in range(3))
+    steady, steady_steps = reps[1]
     one, one_steps = closed_loop_rate(min(len(x0), 16), 1, budget_s / 6)
     # reference call pattern: ONE scenario, the reference's per-step solver calls (ShimLoop) on oracle-backed objects, wall time of
     # everything in the loop (that is the point: the reference's step is Python overhead around the solve)
@@ -399,13 +403,14 @@ def cpu_baseline(N, n_obst, x0, goal, obst, budget_s=24.0):
     while time.perf_counter() - t0 < budget_s / 8 and n_py < 4 * EPISODE:
         loop.control_step(st); loop.shift_warm_start(); n_py += 1
     py_rate = n_py / (time.perf_counter() - t0)
-    return {"value": rates[best][0], "unit": "solves/s", "cores": best, "kind": "port", "host_cpu": orc._cpu_model(), "host_threads": ncpu,
+    return {"value": steady, "unit": "solves/s", "cores": best, "kind": "port", "host_cpu": orc._cpu_model(), "host_threads": ncpu,
+            "spread": {"min": float(f"{reps[0][0]:.4g}"), "max": float(f"{reps[2][0]:.4g}"), "samples": 3, "seconds_each": steady_s},
             "cpu_quota_cores": quota,
-            "one_thread": one, "per_core": rates[best][0] / best, "scaling_efficiency": rates[best][0] / (best * one),
+            "one_thread": one, "per_core": steady / best, "scaling_efficiency": steady / (best * one),
             "python_call_pattern_one_thread": py_rate,
             "threads": {str(n): float(f"{r[0]:.4g}") for n, r in rates.items()},
-            "sample": f"{S_all} scenarios x {rates[best][1]} closed-loop steps, C oracle -O3 OpenMP, solve calls only; thread sweep to plateau",
-            "sample_detail": f"first {S_all} scenarios x {rates[best][1]} closed-loop control steps (after 5 untimed) of the same workload, oracle "
+            "sample": f"{S_all} scenarios x {steady_steps} closed-loop steps x 3 (median; spread = min / max), C oracle -O3 OpenMP at the plateau of a thread sweep, solve calls only",
+            "sample_detail": f"first {S_all} scenarios x {steady_steps} closed-loop control steps (after 5 untimed), three times, of the same workload, oracle "
                              f"(C, f64, -O3 -march=native, OpenMP over instances), solve calls only; one_thread: 16 scenarios x {one_steps} steps; "
                              f"python_call_pattern: 1 scenario x {n_py} control steps through the reference's ~{8 * N + 12} solver calls per step "
                              "(whole loop timed); acados itself cannot run here, so this is a restatement, not the reference's solver",
@@ -480,6 +485,20 @@ def roofline(loop, N, no, r):
     flops = algorithmic_flops_per_solve(N, no, r["mean_iters"]) * batch
     abytes = algorithmic_bytes_per_solve(N, no) * batch
     pm = measured_pmc(kname, batch)
+    # The PMC-derived fields (issue, latency_frac, wait_frac, lanes_exec, traffic, sweep_frac) are NOT measured by this run: they are replayed from the newest
+    # committed rocprofv3 profile of the same kernel and batch.  `pmc_source` names that file with the kernel duration it was taken at, and the fields are
+    # withheld (null, with a note on stderr) when this run's own launch time differs from the profile's by more than PMC_STALE_TOL -- the kernel has changed
+    # since the profile was taken.  Pipelined runs compare nothing (their launches overlap): they carry no PMC fields at all.
+    pmc_source, pmc_stale = None, False
+    if pm:
+        prof_us = pm["avg_ns"] * 1e-3 if pm.get("avg_ns") else None
+        pmc_source = {"file": "profiles/" + pm["file"], "kernel": pm["kernel"], "avg_launch_us": prof_us}
+        if loop.streams > 1 or prof_us is None or abs(avg_s * 1e6 - prof_us) > PMC_STALE_TOL * prof_us:
+            pmc_stale = True
+            sys.stderr.write(f"bench.py: PMC-derived roofline fields withheld for {kname} at batch {batch}: this run {avg_s * 1e6:.1f} us per launch"
+                             f"{' (pipelined streams)' if loop.streams > 1 else ''}, {pm['file']} was taken at {prof_us} us -- re-profile (scripts/profile_passes.sh)\n")
+            pmc_source["stale"] = True
+            pm = None
     issue = None
     if pm and pm["valu_insts"] and pm["avg_ns"]:
         # the roof that binds: VALU issue slots.  SQ_INSTS_VALU x 4 cycles / (SIMDs x kernel cycles), instructions and duration from the SAME profile
@@ -493,14 +512,18 @@ def roofline(loop, N, no, r):
         latency_frac = (LONE_WAVE_VALU_CYCLES * pm["valu_insts"] + LONE_WAVE_LDS_CYCLES * pm["lds_insts"]) / (4.0 * pm["wave_cycles"])
         wait_frac = pm["wait_any"] / pm["wave_cycles"] if pm.get("wait_any") else None
     sweep_frac = None
-    try:        # per phase: the sweeps' loop bodies in the shipped listing at the same prices (dependent multiply-adds 8.4) over their measured cycles (scripts/critical_path_model.py)
-        cp = json.load(open(os.path.join(ROOT, "profiles", "r05_critical_path_c2.json")))
+    try:        # per phase: the sweeps' loop bodies in the shipped listing at the same prices (dependent multiply-adds 8.4) over their measured cycles (scripts/critical_path_model.py);
+        import glob      # a recorded figure like the PMC ones: the newest committed record, withheld together with them
+        cps = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_critical_path_c2.json")))
+        cp = json.load(open(cps[-1])) if cps and pm else {"kernels": []}
         for rec in cp["kernels"]:
             if rec["kernel"] == kname:
                 sweep_frac = {"factor": rec["factor_sweep"]["model_over_measured"], "vector": rec["vector_sweep"]["model_over_measured"]}
+                pmc_source["sweep_frac_file"] = "profiles/" + os.path.basename(cps[-1])
     except (OSError, KeyError, ValueError):
         pass
     return {"bound": "fp64_valu", "achieved": flops / avg_s / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+            "pmc_source": pmc_source, "pmc_stale": pmc_stale,
             "latency_frac": latency_frac, "wait_frac": wait_frac, "sweep_frac": sweep_frac,
             "latency_model": (f"(5.0 cycles x SQ_INSTS_VALU + 14 cycles x SQ_INSTS_LDS) / (4 x SQ_WAVE_CYCLES) of profiles/{pm['file']}: the kernel's own instruction stream at the "
                               "price a lone wavefront pays per instruction (micro-benchmarks, docs/HISTORY.md 4.1c; all VALU taken as independent: a lower bound of "
@@ -558,7 +581,9 @@ def c1_latency(mpc_gpu, N, no):
 # ------------------------------------------------------------------------------------------------------------------ the output line
 
 LINE_LIMIT = 4096            # the driver keeps only the tail of stdout: a line beyond a few KB is cut and cannot be parsed (BENCH_r04: 20.7 KB -> parsed null)
-FULL_RECORD = os.path.join(ROOT, "profiles", "bench_last.json")
+# the full record of a run: --record PATH, else $MPC_BENCH_RECORD, else gpurun_out/bench_last.json (scratch: a bench run must not dirty the tracked tree -- until
+# round 5 it overwrote profiles/bench_last.json; records worth keeping are copied to profiles/rNN_* by hand)
+FULL_RECORD = os.environ.get("MPC_BENCH_RECORD") or os.path.join(ROOT, "gpurun_out", "bench_last.json")
 
 
 def _num(v, digits=5):
@@ -582,6 +607,10 @@ def compact_line(out):
     line["config"] = pick(cfg, ("workload", "global_batch", "per_gpu_batch", "N", "n_obst", "qp_tol", "control_steps_per_step", "parallelism"))
     line.update(pick(out, ("mean_ipm_iters", "qp_failure_frac", "streams_per_gpu", "exchange", "rccl_ranks", "gather_check", "rccl_path", "torch_pg")))
     line["roofline"] = pick(out["roofline"], ("bound", "achieved", "peak", "unit", "frac", "issue", "latency_frac", "sweep_frac", "lanes_active", "lanes_exec", "traffic", "kernel", "avg_launch_us"))
+    for k in ("issue", "latency_frac", "traffic"):          # the replayed fields are always present: a number, or null when their profile no longer describes the run
+        line["roofline"].setdefault(k, None)
+    src = out["roofline"].get("pmc_source")
+    line["roofline"]["pmc_source"] = None if not src else f"{os.path.basename(src['file'])}@{_num(src.get('avg_launch_us'), 4)}us" + (" STALE" if src.get("stale") else "")
     for key, name in (("extra", "c3"), ("extra_c5", "c5"), ("extra_c4_share", "c4_share"), ("extra_c5_share", "c5_share")):
         e = out.get(key)
         if e:
@@ -592,9 +621,9 @@ def compact_line(out):
     if "c1" in out:
         line["c1_ms_per_solve"] = _num(out["c1"]["ms_per_solve_median"])
     if "cpu_baseline" in out:
-        line["cpu_baseline"] = pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "one_thread", "python_call_pattern_one_thread", "host_cpu",
+        line["cpu_baseline"] = pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "spread", "one_thread", "python_call_pattern_one_thread", "host_cpu",
                                                           "host_threads", "threads", "sample"))
-    line["full_record"] = os.path.relpath(FULL_RECORD, ROOT)
+    line["full_record"] = os.path.relpath(FULL_RECORD, ROOT) if os.path.abspath(FULL_RECORD).startswith(ROOT + os.sep) else FULL_RECORD
     text = json.dumps(line, separators=(",", ":"))
     assert len(text) < LINE_LIMIT, f"bench line is {len(text)} bytes: the driver cannot parse more than {LINE_LIMIT}"
     return text
@@ -602,13 +631,12 @@ def compact_line(out):
 
 def emit(out):
     """full record to the files, compact line to stdout (the LAST line of stdout)"""
-    for path in (FULL_RECORD, os.path.join(ROOT, "gpurun_out", "bench_last.json")):
-        try:
-            if os.path.isdir(os.path.dirname(path)):
-                with open(path, "w") as f:
-                    json.dump(out, f, indent=1)
-        except OSError as e:
-            sys.stderr.write(f"bench.py: could not write {path}: {e}\n")
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(FULL_RECORD)), exist_ok=True)
+        with open(FULL_RECORD, "w") as f:
+            json.dump(out, f, indent=1)
+    except OSError as e:
+        sys.stderr.write(f"bench.py: could not write {FULL_RECORD}: {e}\n")
     sys.stdout.flush()
     print(compact_line(out), flush=True)
 
@@ -725,7 +753,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the supplementary C3, C5 and C1 measurements")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the multi-rank plumbing (gloo), no kernels")
+    ap.add_argument("--record", default=None, help="where the full record (every note and nested detail) goes; default $MPC_BENCH_RECORD or gpurun_out/bench_last.json")
     args = ap.parse_args()
+    if args.record:
+        global FULL_RECORD
+        FULL_RECORD = os.path.abspath(args.record)
     if args.workload is None:
         # ONE workload for every N, so that the driver's 1 / 2 / 4 / 8-GPU values form one curve: the configuration the metric is quoted on (C2), 1024 scenarios PER
         # GPU -- weak scaling.  The sharded global batches of BASELINE configs[3] / [4] are `--workload c4 | c5` (strong scaling; one rank's share of them is

@@ -120,6 +120,7 @@ mpc::KParams make_params(const mpc_config &c, int batch)
     p.polish_tol = c.polish_tol > 0.0 ? (float)c.polish_tol : INFINITY;     // off: no estimate exceeds inf
     p.polish_tol_unsolved = c.polish_tol > 0.0 ? mpc::kPolishUnsolved * (float)c.polish_tol : INFINITY;
     p.polish_kappa = (float)c.polish_step_frac;
+    p.polish_res_g = c.polish_res_g > 0.0 ? c.polish_res_g : INFINITY;      // off: ipm_head never asks for the residual
     return p;
 }
 
@@ -448,6 +449,7 @@ int mpc_default_config(mpc_config *c, int N, int n_obst, double Tf)
     c->qp_fail_policy = 0;
     c->polish_ratio = 1e-2; c->polish_tol = 1e-6;      // oracle/mpc_oracle.c orc_default_config
     c->polish_step_frac = N >= 30 ? 0.01 : 0.0;         // ... which says why the horizon is in this default
+    c->polish_res_g = 1e-7;
     return MPC_OK;
 }
 
@@ -462,6 +464,7 @@ int mpc_create(const mpc_config *cfg, int device, int max_batch, mpc_handle **ou
     if (!(cfg->polish_ratio >= 0.0) || !(cfg->polish_ratio <= 1.0)) return fail(MPC_ERR_ARG, "polish_ratio must be in [0, 1] (0 = that indicator off)");
     if (!(cfg->polish_tol >= 0.0) || !(cfg->polish_tol <= 1.0)) return fail(MPC_ERR_ARG, "polish_tol must be in [0, 1] (0 = that indicator off)");
     if (!(cfg->polish_step_frac >= 0.0) || !(cfg->polish_step_frac <= 0.5)) return fail(MPC_ERR_ARG, "polish_step_frac must be in [0, 0.5]");
+    if (!(cfg->polish_res_g >= 0.0)) return fail(MPC_ERR_ARG, "polish_res_g must be >= 0 (0 = that indicator off)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(MPC_ERR_NODEVICE, "no HIP device visible: libmpcgpu has no CPU path");

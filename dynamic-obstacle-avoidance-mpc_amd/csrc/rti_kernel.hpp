@@ -74,6 +74,7 @@ struct KParams {
     float polish_tol;                    // ... indicator (b); +inf = off
     float polish_kappa;                  // floor of the step estimate as a fraction of the step (mpc_config.polish_step_frac)
     float polish_tol_unsolved;           // kPolishUnsolved x polish_tol: the estimate above which a solve that has used up its polish is reported as not converged (status 2)
+    double polish_res_g;                 // ... indicator (c), round 6: the stationarity residual (adjoint_inputs) above which a polish iteration is taken; +inf = off
     double tl_min;                       // floor of t and lam: min(kTLMin, qp_tol / 10) (the floor must stay below the tolerance: an active row's rho - t is the floor)
     double mu_div, mu_cap, mu_settled;   // the divergence tests of the interior point as thresholds on mu (mpc_api.hip::make_params): kMuDiverged mu0, kMuCapFailed mu0, mu0 --
                                          // or, mpc_config.qp_fail_policy = 1 ("truncate"), 1e300 / inf / inf: a diverging solve runs to the iteration cap and ends as status 2
@@ -317,6 +318,8 @@ __device__ __forceinline__ double seg21_reduce(double v, int lane)
 // What solves left behind when their products slipped under qp_tol was the parity tail beyond 1e-6.
 static constexpr int kPolishMax = 2;
 static constexpr float kPolishUnsolved = 100.0f;      // oracle/mpc_oracle.c POLISH_UNSOLVED
+static constexpr float kStationarityStep = 1e-6f;     // indicator (c), the stationarity residual (adjoint_inputs), is formed only behind a step that was still longer than this in
+                                                      // some stage (oracle/mpc_oracle.c STATIONARITY_STEP): behind a shorter one the step length itself bounds what remains
 // MPC_NAN_NOTE.  A NaN / overflow of the row state must end the solve (status 4) as it does in the oracle, where it surfaces in mu at the head of the next
 // iteration.  In the kernels the floors of the update (t = fmax(t + a dt, floor): fmax drops a NaN) would wash it out of t and lam, and a solve that diverged
 // under qp_fail_policy 1 would come back "converged" with every pair at the floor and the linear residual at 0 (found by the truncate-policy test once the
@@ -335,6 +338,8 @@ struct IpmState {            // per instance (segment-uniform)
     bool running = true;
     bool want_step = false;   // polish indicator (b) of the step just taken (ipm_polish_step) ...
     bool unsolved = false;    // ... and the same estimate against kPolishUnsolved x polish_tol: an end-game that is not a tail but a QP left unsolved
+    bool long_step = false;   // some stage's last step was longer than kStationarityStep: only then is indicator (c) worth its sweep
+    bool ask_g = false;       // the termination test holds and indicators (a), (b) are silent: the caller forms the stationarity residual and ipm_head_g decides (indicator (c))
     double cprev = INFINITY;  // c_max at the head of the previous iteration
 };
 // head of iteration `it`: failure by NaN / divergence, convergence (or a polish iteration), iteration cap
@@ -349,11 +354,21 @@ __device__ __forceinline__ void ipm_head(const KParams &p, IpmState &S, int it, 
         const bool want = cmax > p.polish_ratio * S.cprev || S.want_step;
         if (want && S.npolish >= kPolishMax && S.unsolved) { S.status = 2; S.running = false; S.it_done = it; }
         else if (want && S.npolish < kPolishMax && it < p.iter_max) S.npolish++;
+        // indicator (c), round 6: undecided until the caller has formed the stationarity residual (ipm_head_g) -- asked only where it decides: a polish iteration is left
+        else if (!want && S.long_step && S.npolish < kPolishMax && it > 0 && it < p.iter_max && p.polish_res_g < INFINITY) S.ask_g = true;
         else { S.status = 0; S.running = false; S.it_done = it; }
     }
     else if (it >= p.iter_max) {      // at the cap with mu above a healthy solve's: diverging or stalled, not slow
         S.status = (mu > p.mu_cap || (it >= kMuCapSettled && mu > p.mu_settled)) ? 4 : 2; S.running = false; S.it_done = it;
     }
+}
+// ... second half of the head for the instances that asked (IpmState::ask_g): converged, or one more iteration because the Lagrangian is not yet stationary
+__device__ __forceinline__ void ipm_head_g(const KParams &p, IpmState &S, int it, double res_g)
+{
+    if (!S.ask_g) return;
+    S.ask_g = false;
+    if (res_g > p.polish_res_g) S.npolish++;
+    else { S.status = 0; S.running = false; S.it_done = it; }
 }
 // largest affine steps that keep t, lam > 0 from the largest ratios -dt/t, -dlam/lam (true divisions, as the oracle: a 1-ulp reciprocal here moves a
 // sensitive instance past the parity tolerance)
@@ -409,7 +424,7 @@ __device__ __forceinline__ void ipm_polish_step(const KParams &p, IpmState &S, i
     bool w, u;
     polish_wanted(sn, stepl, p.polish_tol, p.polish_tol_unsolved, p.polish_kappa, w, u);      // (polish_tol = +inf: indicator off)
     stepl = sn;
-    S.want_step = seg_any<G>(w, lane); S.unsolved = seg_any<G>(u, lane);
+    S.want_step = seg_any<G>(w, lane); S.unsolved = seg_any<G>(u, lane); S.long_step = seg_any<G>(sn > kStationarityStep, lane);
 }
 // A step that is not finite is not a step (MPC_NAN_NOTE): an overflow that reached z without passing through mu or sigma (the last iteration of a solve that
 // diverged under qp_fail_policy 1 takes alpha = 1 on an infinite direction, and the floors then wash the row state clean) ends as status 4, iterate untouched,
@@ -473,6 +488,62 @@ __device__ __forceinline__ double from_left(double v)
     const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x138, 0xf, 0xf, true);
     const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
+}
+
+// ---- POLISH INDICATOR (c): THE STATIONARITY RESIDUAL (round 6; oracle/mpc_oracle.c ipm_solve, residuals()) ----
+// With g_t = (H z + q - C' lam)_t per stage (z order: ua, ual, x, y, psi, v, om) and the costates of the OPEN-LOOP adjoint recursion
+//     pi_N = g_x,N,    pi_t = g_x,t + A_t' pi_{t+1},
+// the state blocks of the Lagrangian's gradient vanish and what is left are the input blocks  ru_t = g_u,t + B_t' pi_{t+1}  (HPIPM's res_g on this
+// choice of costates; the slack equations are per row and stay with the callers).  The recursion is sequential in the stage index -- but A = I + E with E
+// strictly upper triangular in the order (x, y | psi, v | om) (the plant is a chain of integrators), so it is THREE LEVELS OF SUFFIX SUMS over the stages:
+//     pi_x = suf(g_x), pi_y = suf(g_y);     pi_psi = suf(g_psi + a02 pi_x+ + a12 pi_y+), pi_v = suf(g_v + a03 pi_x+ + a13 pi_y+);
+//     pi_om = suf(g_om + a04 pi_x+ + a14 pi_y+ + dt pi_psi+)                    (+ : the value of stage t + 1)
+// and a suffix sum over the lanes of an instance is four DPP shift-and-add steps per 16-lane row plus the totals of the rows behind it: ~30 instructions per
+// level whatever the horizon, against 32 per STAGE for the systolic form of the same recursion (N = 50: 1600).  Formed about once per two solves.
+// inclusive suffix sum over the calling lane's 16-lane DPP row: out[j] = v[j] + v[j + 1] + ... to the end of the row (row_shl:n reads lane j + n, zero beyond the row)
+__device__ __forceinline__ double row_suffix(double v)
+{
+    v += dpp_f64<0x101>(v);
+    v += dpp_f64<0x102>(v);
+    v += dpp_f64<0x104>(v);
+    v += dpp_f64<0x108>(v);
+    return v;
+}
+// ... over the G-lane segment of the calling lane (G = 64, 32, 16: whole rows; G = 21: three instances in lanes [0, 21), [21, 42), [42, 63) -- two masked row
+// passes as in seg21_reduce, L for the lanes of a row's lower instance and U for the others; an instance continues into the NEXT row's lower part).  Fixed order.
+template <int G>
+__device__ __forceinline__ double seg_suffix(double v, int lane)
+{
+    const int row = lane >> 4;
+    if (G == 21) {
+        const bool low = seg21_lower(lane);
+        const double vl = row_suffix(low ? v : 0.0), vu = row_suffix(low ? 0.0 : v);
+        const double l1 = lane_value(vl, 16), l2 = lane_value(vl, 32), l3 = lane_value(vl, 48);
+        const double nxt = row == 0 ? l1 : (row == 1 ? l2 : (row == 2 ? l3 : 0.0));
+        return low ? (row == 0 ? vl + nxt : vl) : vu + nxt;
+    }
+    v = row_suffix(v);
+    if (G == 16) return v;
+    const double t1 = lane_value(v, 16), t2 = lane_value(v, 32), t3 = lane_value(v, 48);
+    if (G == 32) return (row & 1) ? v : v + (row == 0 ? t1 : t3);
+    const double a2 = t2 + t3, a1 = t1 + a2;
+    return v + (row == 0 ? a1 : (row == 1 ? a2 : (row == 2 ? t3 : 0.0)));
+}
+// max(|ru_t[0]|, |ru_t[1]|) of the calling lane's stage.  `src`: this lane holds a stage's g (one lane per stage: the stage exists; rti_split_kernel: the stage's
+// first lane -- the other lanes of a stage enter the sums with zero and so hold the NEXT stage's suffix, which is what the first lane reads from its right
+// neighbour); `nxt`: ... and the stage has a successor (t < N).
+template <int G>
+__device__ __forceinline__ double adjoint_inputs(bool src, bool nxt, const StageLin &S, const double g[7], int lane)
+{
+    const double s0 = from_right(seg_suffix<G>(src ? g[2] : 0.0, lane)), s1 = from_right(seg_suffix<G>(src ? g[3] : 0.0, lane));
+    const double px = nxt ? s0 : 0.0, py = nxt ? s1 : 0.0;
+    const double s2 = from_right(seg_suffix<G>(src ? g[4] + S.a02 * px + S.a12 * py : 0.0, lane));
+    const double s3 = from_right(seg_suffix<G>(src ? g[5] + S.a03 * px + S.a13 * py : 0.0, lane));
+    const double ppsi = nxt ? s2 : 0.0, pv = nxt ? s3 : 0.0;
+    const double s4 = from_right(seg_suffix<G>(src ? g[6] + S.a04 * px + S.a14 * py + S.dt * ppsi : 0.0, lane));
+    const double pom = nxt ? s4 : 0.0;
+    const double ru0 = g[0] + S.b00 * px + S.b10 * py + S.dt * pv, ru1 = g[1] + S.b01 * px + S.b11 * py + S.h2 * ppsi + S.dt * pom;
+    return nxt ? fmax(fabs(ru0), fabs(ru1)) : 0.0;
 }
 
 // Riccati factors of one stage, kept in the registers of the lane that owns the stage
@@ -2358,9 +2429,12 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     };
 
     // predictor, cost part: bounds and iterate values of this phase, Gauss-Newton gradient (H z + q) and the diagonal of the reduced Hessian before the rows enter
-    auto predictor_weights = [&](double (&vals)[NB], double (&Hq)[8], double (&gloc)[7], double (&cb)[7]) {
+    // (rows: the caller goes on to the box rows -- their reciprocals and bounds are made current here; the polish's stationarity residual needs neither)
+    auto predictor_weights = [&](double (&vals)[NB], double (&Hq)[8], double (&gloc)[7], double (&cb)[7], auto rows) {
+    if constexpr (decltype(rows)::value) {
     refresh_box_rcp();
     reload_bounds();
+    }
     vals[0] = ui[0]; vals[1] = ui[1]; vals[2] = xi[0]; vals[3] = xi[1]; vals[4] = xi[3]; vals[5] = xi[4];
 #pragma unroll
     for (int k = 0; k < NB; k++) OPAQUE(vals[k]);
@@ -2583,6 +2657,27 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     for (int c = 0; c < 7; c++) dz[c] += za[c];
     MPC_TICK(7);
     };
+    // polish indicator (c): the stationarity residual at the iterate -- g = H z + q - C' lam of this lane's stage (the cost part as the predictor forms it, the
+    // rows' multipliers entered through the 0 / 1 factors in both forms of the row phases), the open-loop adjoint sweep for the input blocks, the slack equations
+    // Z s + z - lam_1 - lam_2 of this lane's soft rows; max-norm over the instance.  Runs where ipm_head asks for it (IpmState::ask_g): about once per solve.
+    auto stationarity = [&]() {
+        double vals[NB], Hq[8], g[7], cb[7];
+        predictor_weights(vals, Hq, g, cb, std::false_type{});
+#pragma unroll
+        for (int k = 0; k < NB; k++) g[zidx[k]] = fma(MPC_MK(k), lh[k] - ll[k], g[zidx[k]]);
+        double gx = 0.0, gy = 0.0, rsm = 0.0;
+        const double pz = phase_zero();
+#pragma unroll
+        for (int j = 0; j < NOBST; j++) {
+            if (ROW_OFF(j)) continue;
+            const ObstView v = obst_view(j, pz);
+            gx += l1[j] * v.ax; gy += l1[j] * v.ay;
+            if (soft) rsm = fmax(rsm, fabs(zpen * sv[j] + zpen - l1[j] - l2[j]));
+        }
+        g[2] = fma(-m_s, gx, g[2]); g[3] = fma(-m_s, gy, g[3]);
+        const double ru = adjoint_inputs<G>(act, has_u, stage_lin(), g, lane);
+        return seg_max<G>(fmax(ru, m_s * rsm), lane);
+    };
     // Two forms of the iteration's row phases (same arithmetic, same interior point):
     //   BRANCHFREE (3 and 5 obstacle row pairs): every row of the stage computed by every lane, existence as 0 / 1 factors (see m_u, m_x, m_s);
     //   the branched form (10 row pairs): the rows under `if (row exists)`.  With ten obstacles the register file is full to the last
@@ -2621,6 +2716,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         const double mu = msum * inv_items;
         const double lin = rhoPi * lin0;
         ipm_head(p, ipm, it, mu, lin, cmax);
+        if (__ballot(ipm.ask_g) != 0ull) ipm_head_g(p, ipm, it, stationarity());
         if (__ballot(running) == 0ull) break;
         ipm.cprev = cmax;
         MPC_TICK(0);
@@ -2633,7 +2729,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         for (int c = 0; c < 5; c++) { bbr[c] = rhoPi * bb[c]; x_init[c] = SLDS ? 0.0 : rhoPi * d0[c]; }
         {
             double vals[NB], Hq[8], gloc[7], cb[7];
-            predictor_weights(vals, Hq, gloc, cb);
+            predictor_weights(vals, Hq, gloc, cb, std::true_type{});
 #pragma unroll
             for (int k = 0; k < NB; k++) {
                 double rdl, rdh;
@@ -2921,6 +3017,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         const double mu = msum * inv_items;
         const double lin = rhoPi * lin0;
         ipm_head(p, ipm, it, mu, lin, cmax);
+        if (__ballot(ipm.ask_g) != 0ull) ipm_head_g(p, ipm, it, stationarity());
         if (__ballot(running) == 0ull) break;
         ipm.cprev = cmax;
         MPC_TICK(0);
@@ -2933,7 +3030,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         for (int c = 0; c < 5; c++) { bbr[c] = rhoPi * bb[c]; x_init[c] = SLDS ? 0.0 : rhoPi * d0[c]; }
         {
             double vals[NB], Hq[8], gloc[7], cb[7];
-            predictor_weights(vals, Hq, gloc, cb);
+            predictor_weights(vals, Hq, gloc, cb, std::true_type{});
 #pragma unroll
             for (int k = 0; k < NB; k++) if ((k < 2) ? vbu : vbx) {
                 double rdl, rdh;

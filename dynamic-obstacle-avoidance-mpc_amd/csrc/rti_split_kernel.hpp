@@ -370,6 +370,32 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
     float stepl = 0.0f;       // this lane's (stage's) last step norm, for the polish (ipm_polish_step)
     if (!(lin0 <= 1e300)) { status = 4; running = false; }
 
+    // polish indicator (c) (rti_kernel.hpp: adjoint_inputs, ipm_head_g): the stationarity residual at the iterate.  Every lane forms its share of
+    // g = H z + q - C' lam (its box variables, its obstacle rows), the shares travel to the stage's first lane as in the predictor (one-lane wave shifts, fixed
+    // order), the open-loop adjoint sweep gives the input blocks, the slack equations are per row; max-norm over the wavefront.  About once per solve.
+    auto stationarity = [&]() {
+        double gsh[NBL], gk[6] = {0, 0, 0, 0, 0, 0}, sx = 0.0, sy = 0.0, rsm = 0.0;
+#pragma unroll
+        for (int s = 0; s < NBL; s++) { gsh[s] = gc0[s] + hd[s] * zs[s] + (bp[s] ? lh[s] - ll[s] : 0.0); gk[s] = gsh[s]; }
+#pragma unroll
+        for (int s = 0; s < NSL; s++) if (sp[s]) {
+            sx -= l1[s] * ax[s]; sy -= l1[s] * ay[s];
+            if (soft) rsm = fmax(rsm, fabs(zpen * sv[s] + zpen - l1[s] - l2[s]));
+        }
+        double shx = sx, shy = sy;
+#pragma unroll
+        for (int q = 1; q < LPS; q++) {
+#pragma unroll
+            for (int s = 0; s < NBL; s++) gsh[s] = from_right(gsh[s]);
+            shx = from_right(shx); shy = from_right(shy);
+#pragma unroll
+            for (int s = 0; s < NBL; s++) gk[q * NBL + s] = gsh[s];
+            sx += shx; sy += shy;
+        }
+        const double g[7] = {gk[0], gk[1], gk[2] + sx, gk[3] + sy, hd_psi * z[4], gk[4], gk[5]};      // (valid in the stage's first lane)
+        const double ru = adjoint_inputs<64>(own && act, own && has_u, S, g, lane);
+        return wave_uniform(seg_max<64>(fmax(ru, rsm), lane));
+    };
     MPC_TICK(13);
     for (it = 0;; it++) {
         // ---- complementarity measures ----
@@ -396,6 +422,7 @@ __global__ MPC_SPLIT_BOUNDS(W2) void rti_split_kernel(const KParams p)
         const double mu = msum * inv_items;
         const double lin = rhoPi * lin0;
         ipm_head(p, ipm, it, mu, lin, cmax);
+        if (__ballot(ipm.ask_g) != 0ull) ipm_head_g(p, ipm, it, stationarity());
         if (!running) break;      // wave-uniform: one instance per wavefront
         ipm.cprev = wave_uniform(cmax);
         MPC_TICK(0);

@@ -19,7 +19,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 MPC_OK, MPC_ERR_ARG, MPC_ERR_HIP, MPC_ERR_NODEVICE = 0, -1, -2, -3
 STEP_SHIFT, STEP_PLANT, STEP_OBSTACLES, STEP_RESET_ON_FAIL, STEP_ALIAS_BUG, STEP_METRICS, STEP_INTERP_GUESS = 1, 2, 4, 8, 16, 32, 64
 COMM_ID_BYTES = 128      # MPC_COMM_ID_BYTES (RCCL unique id)
-ABI_VERSION = 6          # MPC_ABI_VERSION of include/mpc_gpu.h this mirror (MpcConfig, SYMBOLS) was written against
+ABI_VERSION = 7          # MPC_ABI_VERSION of include/mpc_gpu.h this mirror (MpcConfig, SYMBOLS) was written against
 
 _d = C.c_double
 _i32 = C.c_int32
@@ -38,7 +38,7 @@ class MpcConfig(C.Structure):
         ("arena", _d * 4), ("bug_compat_predict", _i32),
         ("mu0", _d), ("thr0", _d),
         ("qp_fail_policy", _i32),
-        ("polish_ratio", _d), ("polish_tol", _d), ("polish_step_frac", _d),
+        ("polish_ratio", _d), ("polish_tol", _d), ("polish_step_frac", _d), ("polish_res_g", _d),
     ]
 
 
@@ -200,7 +200,10 @@ def lib():
             fn = getattr(L, name)      # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.mpc_abi_version() != ABI_VERSION:      # a stale .so behind a newer struct mirror would be written past the end of MpcConfig
+        # (a diagnostic build supplied through MPC_GPU_LIB may be OLDER than the mirror -- A/B runs against last round's library: it reads and writes a prefix of
+        # the struct, which is safe; a NEWER library behind an older mirror never is)
+        older_ab = bool(os.environ.get("MPC_GPU_LIB")) and L.mpc_abi_version() < ABI_VERSION
+        if L.mpc_abi_version() != ABI_VERSION and not older_ab:      # a stale .so behind a newer struct mirror would be written past the end of MpcConfig
             raise MpcError(f"{LIB_PATH} has ABI version {L.mpc_abi_version()}, this binding expects {ABI_VERSION}: rebuild (mpc_gpu.build(force=True))")
         _LIB = L
     return _LIB

@@ -41,10 +41,11 @@ extern "C" {
 #define MPC_NU 2
 
 /* Version of this header's binary interface: bumped whenever `struct mpc_config` changes size or layout or an entry point changes its signature
- * (round 4: trailing field qp_fail_policy, +8 bytes; round 5, version 6: trailing fields polish_ratio, polish_tol, polish_step_frac, +24 bytes, mpc_abi_version itself).  A host compares it with mpc_abi_version() of the library it loaded BEFORE it calls
+ * (round 4: trailing field qp_fail_policy, +8 bytes; round 5, version 6: trailing fields polish_ratio, polish_tol, polish_step_frac, +24 bytes, mpc_abi_version itself;
+ * round 6, version 7: trailing field polish_res_g, +8 bytes).  A host compares it with mpc_abi_version() of the library it loaded BEFORE it calls
  * mpc_default_config / mpc_create: a host built against an older struct would otherwise be written past its end.  (No reference counterpart: acados
  * regenerates and recompiles its C interface per problem.) */
-#define MPC_ABI_VERSION 6
+#define MPC_ABI_VERSION 7
 
 /* Problem definition.  Defaults (mpc_default_config) are the reference's constants. */
 typedef struct mpc_config {
@@ -89,6 +90,11 @@ typedef struct mpc_config {
     double polish_step_frac; /* floor of that estimate as a fraction of the step: est = max(s r min(1, 10 r), polish_step_frac s).  Default 0.01 from N = 30 on, else 0: at long
                                horizons the last Newton step leaves 1.5 .. 10 % of itself behind whatever contraction was observed (5 solves of 1.2e7 fuzz solves ended
                                1e-5 .. 2e-5 from the exact solution without it, none beyond 3e-7 with it; +0.4 .. 0.8 % iterations there, +3.8 % at N = 20 where nothing needs it) */
+    double polish_res_g;    /* (c), round 6: the stationarity residual of the QP's Lagrangian -- HPIPM's res_g, which acados' default tolerances gate
+                               (robot_ocp_problem.py:126-132 leaves them alone) -- above this value when the termination test holds asks for a polish iteration as well.
+                               Formed once per solve by one open-loop adjoint sweep (input blocks B_i' pi_{i+1} + (H z + q - C' lam)_u; slack equations per row).
+                               Default 1e-7: on BASELINE configs[4]'s problem the solves beyond 1e-7 from the QP's exact solution fall from 5 to 1 of 4000 and the worst
+                               from 1.3e-6 to 2.4e-7 at +0.11 % iterations.  0 = off. */
 } mpc_config;
 
 typedef struct mpc_handle mpc_handle;

@@ -78,6 +78,10 @@ typedef struct orc_config {
      * last step, r = min(s / previous s, 1/2)); 0 = that indicator off.  Defaults 1e-2 and 1e-6 (the stated parity tolerance). */
     double polish_ratio, polish_tol;
     double polish_step_frac;  /* floor of that estimate as a fraction of s: default 0.01 from N = 30 on, else 0 (orc_default_config says why) */
+    /* polish indicator (c) (round 6): the STATIONARITY residual of the QP's Lagrangian (HPIPM's res_g; with the adjoint costates its state blocks vanish, so it is
+     * the input blocks B_i' pi_{i+1} + (H z + q - C' lam)_u and the slack equations Z s + z - lam_1 - lam_2) above this value when the termination test holds
+     * asks for a polish iteration; 0 = off. */
+    double polish_res_g;
 } orc_config;
 
 void orc_default_config(orc_config *c, int N, int n_obst, double Tf);
@@ -132,6 +136,10 @@ void orc_rti_solve_batch(const orc_config *c, int batch, const double *x0, const
                          double *X, double *U, double *u0, double *cost, int *status, int *iters,
                          int nthreads);
 
+/* bench.py's cpu_baseline: the untimed surroundings of the solve for a whole batch per call (look-ahead; plant step + obstacle step + warm-start shift, in place) */
+void orc_predict_params_batch(const orc_config *c, int batch, const double *obst, double *P);
+void orc_advance_batch(const orc_config *c, int batch, double *x, const double *u0, double *obst, double *X, double *U);
+
 /* Assembled QP of one RTI step in dense form for cross-checking with scipy.
  * Variables v = [du_0, dx_1, du_1, ..., dx_N] (dx_0 eliminated), nv = 7N.
  *   min 0.5 v'Hv + g'v + sum_j (zs_j s_j + 0.5 Zs_j s_j^2)
@@ -147,7 +155,13 @@ int orc_export_qp(const orc_config *c, const double *x0, const double *P, const 
 int orc_last_dead_pairs(void);
 /* ... polish iterations it took, and the largest per-stage norm of its last primal step (the polish's indicator (b) looks at these norms) */
 int orc_last_npolish(void);
+/* ... first iteration >= 20 at whose head mu stood above mu0 (-1: none): the settled-mu failure rule's trigger (ipm_solve) */
+int orc_last_settled_it(void);
+/* ... the reduced stationarity residual the polish's indicator (c) last formed on this thread (0: never formed) */
+double orc_last_res_g(void);
 double orc_last_step_norm(void);
+/* investigation switches of scripts/converged_unmatched.py (mpc_oracle.c says which); process-wide, default 0, never set by tests */
+void orc_set_investigation(int switches);
 /* debugging aid: record (mu, sigma, alpha, cmax) of every IPM iteration of subsequent single solves into buf[4*cap] */
 void orc_set_trace(double *buf, int cap);
 

@@ -29,7 +29,7 @@ class OrcConfig(C.Structure):
         ("arena", _d * 4), ("bug_compat_predict", C.c_int),
         ("mu0", _d), ("thr0", _d),
         ("qp_fail_policy", C.c_int),
-        ("polish_ratio", _d), ("polish_tol", _d), ("polish_step_frac", _d),
+        ("polish_ratio", _d), ("polish_tol", _d), ("polish_step_frac", _d), ("polish_res_g", _d),
     ]
 
 
@@ -207,6 +207,12 @@ def rti_solve_trace(cfg, x0, P, goal, X, U, alpha=None):
     return r
 
 
+def set_investigation(switches):
+    """investigation switches of scripts/converged_unmatched.py (mpc_oracle.c orc_set_investigation); process-wide, never called by tests"""
+    lib().orc_set_investigation.argtypes = [C.c_int]
+    lib().orc_set_investigation(int(switches))
+
+
 def rti_solve_batch(cfg, x0, P, goal, X, U, nthreads=0):
     B = x0.shape[0]
     X, U = _a(X).copy(), _a(U).copy()
@@ -214,6 +220,21 @@ def rti_solve_batch(cfg, x0, P, goal, X, U, nthreads=0):
     st, it = np.zeros(B, np.int32), np.zeros(B, np.int32)
     lib().orc_rti_solve_batch(C.byref(cfg), B, _a(x0), _a(P), _a(goal), X, U, u0, cst, st, it, nthreads)
     return dict(X=X, U=U, u0=u0, cost=cst, status=st, iters=it)
+
+
+def predict_params_batch(cfg, obst):
+    """bench.py's cpu_baseline: look-ahead of a whole batch in one call"""
+    obst = _a(obst); B = obst.shape[0]
+    P = np.zeros((B, cfg.N + 1, cfg.n_obst, 2))
+    lib().orc_predict_params_batch.argtypes = [C.POINTER(OrcConfig), C.c_int, _dp, _dp]
+    lib().orc_predict_params_batch(C.byref(cfg), B, obst, P)
+    return P
+
+
+def advance_batch(cfg, x, u0, obst, X, U):
+    """bench.py's cpu_baseline: plant step, noise-free obstacle step and warm-start shift of a whole batch, IN PLACE (C-contiguous float64 arrays)"""
+    lib().orc_advance_batch.argtypes = [C.POINTER(OrcConfig), C.c_int, _dp, _dp, _dp, _dp, _dp]
+    lib().orc_advance_batch(C.byref(cfg), x.shape[0], x, _a(u0), obst, X, U)
 
 
 def export_qp(cfg, x0, P, goal, X, U):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """CPU ORACLE closed loops on random scenarios (the distributions of bench.py's C3 / C5): mean interior-point iterations and status counts per configuration
-under a variant of the specification (--cfg overrides; --exp -> ORC_INVESTIGATE, the oracle's investigation switches).  Test infrastructure; no GPU.
+under a variant of the specification (--cfg overrides; --exp -> orc_set_investigation, the oracle's investigation switches).  Test infrastructure; no GPU.
     python scripts/oracle_closed_loop_stats.py --cfg polish_ratio=0.0,polish_tol=0.0"""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,10 +13,10 @@ ap.add_argument("--B", type=int, default=512); ap.add_argument("--steps", type=i
 ap.add_argument("--sizes", default="20:3,20:5,20:10,30:3,50:10,10:5")
 ap.add_argument("--out", default=None)
 a = ap.parse_args()
-os.environ["ORC_INVESTIGATE"] = str(a.exp)
 from oracle import oracle as orc
 from helpers import random_batch
 orc.build()
+orc.set_investigation(a.exp)
 over = {}
 for kv in filter(None, a.cfg.split(",")):
     k, v = kv.split("="); over[k] = float(v) if ("." in v or "e" in v) else int(v)

@@ -3,7 +3,7 @@
 
 All ten recorded tables (tests/golden/reference_tables.json: src/simulation/test_data/20221031_*; the two `interpolate_init` ones with the straight-line guess of
 robot_ocp_problem.py:293-300), protocol experiments.py:20-36 with the reference's own numpy streams, tests/helpers.py::OracleLoop.  A variant is a set of
-oracle configuration overrides (--cfg qp_tol=1e-8,polish_tol=0.0) and / or the oracle's investigation switches (--exp N -> environment ORC_INVESTIGATE, read by
+oracle configuration overrides (--cfg qp_tol=1e-8,polish_tol=0.0) and / or the oracle's investigation switches (--exp N -> orc_set_investigation of
 oracle/mpc_oracle.c).  Output per table: seeds reproduced to 1e-3 / 1e-6 (control steps exact, flags equal), per-seed rows, number of solves that did not
 converge; totals; and, with --seeds, only those seeds (the 12 converged-but-unmatched ones of VERDICT r04 item 3).
 
@@ -23,8 +23,9 @@ import numpy as np
 
 
 def episode(job):
-    stem, sp, seed, over, alias, perturb = job
+    stem, sp, seed, over, alias, perturb, exp = job
     from oracle import oracle as orc
+    orc.set_investigation(exp)
     from helpers import OracleLoop
     from mpc_gpu.world import reference_streams
     interp = bool(sp.get("interpolate_init"))
@@ -57,7 +58,6 @@ def main():
     ap.add_argument("--perturb", type=float, default=0.0, help="added to the start position x0_x (sensitivity of a closed loop to a perturbation far below any solver tolerance)")
     ap.add_argument("--seeds", default="", help="e.g. RANDOM:28,29,37;EDGE:14,23 -- only these seeds of the tables of that scenario")
     a = ap.parse_args()
-    os.environ["ORC_INVESTIGATE"] = str(a.exp)
     over = {}
     for kv in filter(None, a.cfg.split(",")):
         k, v = kv.split("=")
@@ -74,7 +74,7 @@ def main():
         seeds = only.get(sp["scenario"], [] if only else range(100))
         for seed in seeds:
             for alias in ((True, False) if sp.get("interpolate_init") else (True,)):
-                jobs.append((stem, sp, seed, over, alias, a.perturb))
+                jobs.append((stem, sp, seed, over, alias, a.perturb, a.exp))
     from oracle import oracle as orc
     orc.build()
     t0 = time.time()

@@ -115,7 +115,7 @@ def test_abi_version_and_struct_size_agree_with_the_header(lib):
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "s"), src])
         assert int(subprocess.check_output([os.path.join(d, "s")])) == C.sizeof(lib.MpcConfig)
     cfg = lib.default_config(20, 3, 2.0)
-    assert cfg.polish_ratio == 1e-2 and cfg.polish_tol == 1e-6 and cfg.polish_step_frac == 0.0 and lib.default_config(30, 3, 3.0).polish_step_frac == 0.01
+    assert cfg.polish_ratio == 1e-2 and cfg.polish_tol == 1e-6 and cfg.polish_step_frac == 0.0 and lib.default_config(30, 3, 3.0).polish_step_frac == 0.01 and cfg.polish_res_g == 1e-7
     h = C.c_void_p()
     assert lib.lib().mpc_create(C.byref(lib.default_config(20, 3, 2.0, polish_tol=2.0)), 0, 1, C.byref(h)) == lib.MPC_ERR_ARG
 

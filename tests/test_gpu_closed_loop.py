@@ -354,15 +354,18 @@ def test_c2_bench_workload_against_the_oracle_loop(built):
                 n_conv += 1
                 d = max(np.abs(after["X"][b] - L.X).max(), np.abs(after["U"][b] - L.U).max(), np.abs(after["x0"][b] - L.x).max())
                 if d > 1e-6:
-                    # un-shift is not needed: adjudicate on the step itself from the common iterate
+                    # the same adjudication as everywhere else (helpers.adjudicate: the GPU's step against the EXACT solution of the QP, cap EXACT_CAP), on the
+                    # un-shifted step: the fused control step stores the iterate shifted, so row 0 of the step is x0 (the initial-state equality), rows 1 .. N are rows
+                    # 0 .. N-1 of what was stored, the first input is the applied u0 and inputs 1 .. N-1 are stored inputs 0 .. N-2 (robot_ocp_problem.py:253-258)
                     P = orc.predict_params(cfg, before["obst"][b])
                     rr = orc.rti_solve(cfg, before["x0"][b], P, goal[b], before["X"][b], before["U"][b])
-                    # GPU's un-shifted step: X rows 0..N-2 of the shifted iterate are rows 1..N-1 of the step; adjudicate what is comparable -- the applied control
-                    assert np.abs(after["u0"][b] - rr["u0"]).max() <= 1e-5, (k, b, d)
+                    Xg = np.vstack([before["x0"][b][None], after["X"][b][:N]]); Ug = np.vstack([after["u0"][b][None], after["U"][b][:N - 1]])
+                    a = adjudicate(orc, cfg, before["x0"][b], P, goal[b], before["X"][b], before["U"][b], Xg, Ug, rr["X"], rr["U"])
+                    assert a["passed"], (k, b, d, a)
                     n_adj += 1
                 else:
                     assert np.abs(after["u0"][b] - r["u0"]).max() <= 8e-6, (k, b)
                 worst = max(worst, d)
         del loop
-    assert n_conv >= 150 and n_adj <= 2, (n_conv, n_fail, n_adj, worst)
+    assert n_conv >= 150 and n_adj <= 1, (n_conv, n_fail, n_adj, worst)
     print(f"C2 bench workload, slots {slots}: {n_conv} converged control steps compared, {n_fail} failed QPs (status equal), {n_adj} beyond 1e-6, worst |GPU - oracle| {worst:.2e}")

@@ -513,7 +513,7 @@ def test_full_size_batches_c3_and_c4_share(env, B):
     if "21" in kernel.split(",")[1]:
         assert same.mean() > 0.999
         d = np.abs(X1[perm] - X2).reshape(B, -1).max(1)[same & (h2["status"] == 0)]
-        assert np.median(d) < 1e-11 and np.quantile(d, 0.999) < 1e-5
+        assert np.median(d) < 1e-11 and np.quantile(d, 0.999) < 1e-6      # (round 5: 1e-5; the stated tolerance since the third polish indicator)
     else:
         assert same.all() and np.array_equal(X1[perm], X2) and np.array_equal(U1[perm], U2)
     assert (g1["status"] != 4).mean() > 0.99 and 5.0 < g1["iters"].mean() < 12.0
@@ -572,7 +572,7 @@ def test_instance_scheduling(env, G):
             same = ga["status"] == gb["status"]
             assert same.mean() > 0.999
             d = np.abs(Xa - Xb).reshape(B, -1).max(1)[same & (gb["status"] == 0)]
-            assert np.median(d) < 1e-11 and np.quantile(d, 0.999) < 1e-5
+            assert np.median(d) < 1e-11 and np.quantile(d, 0.999) < 1e-6      # (round 5: 1e-5; the stated tolerance since the third polish indicator)
 
 
 @pytest.mark.gpu
@@ -853,9 +853,9 @@ def test_qp_fail_policy_truncate_against_the_oracle(env):
                 s.set_warmstart(X, U); g = s.solve(x0, P, goal); Xg, Ug = s.get_traj(B)
             res[cap, pol] = (g, Xg, Ug, o)
             assert (g["status"] == o["status"]).all(), (cap, pol, g["status"], o["status"])
-            # feasible instances: the same iteration count; a diverging one is recognised within a few iterations of the oracle (the kernels see the overflow
-            # in sigma or in the step, the oracle in its measured residuals one or two iterations later)
-            assert (np.abs(g["iters"].astype(int) - o["iters"]) <= 3).all() and (g["iters"][good] == o["iters"][good]).all()
+            # feasible instances: the same iteration count; a diverging one is recognised at the same iteration, give or take one (round 6: the oracle mirrors the
+            # kernels' two guards -- a NaN of the centring target, a non-finite step -- instead of noticing the overflow in its residuals one to three iterations later)
+            assert (np.abs(g["iters"].astype(int) - o["iters"]) <= 1).all() and (g["iters"][good] == o["iters"][good]).all()
             assert np.abs(Xg[good] - o["X"][good]).max() < 1e-6
             for b in bad[g["status"][bad] == 4]:
                 assert np.array_equal(Xg[b], X[b]) and np.array_equal(Ug[b], U[b])          # a failed QP leaves the iterate untouched

@@ -77,14 +77,23 @@ def test_recorded_rows_are_reproduced_per_seed(mapping, scen):
     assert np.array_equal(tb[st, 4], rows[st, 4]), (tb[st, 4], rows[st, 4])                 # control-step counts, exactly
     assert np.array_equal(tb[st][:, [0, 1, 5]], rows[st][:, [0, 1, 5]])                     # hit / reached / out of bounds
     assert np.abs(tb[st, 2] - rows[st, 2]).max() <= 1e-4                                       # min margin: measured 6.7e-7
-    # dist_to_goal: 1e-3 for the episodes that REACHED the goal (measured 1.5e-4).  An episode that ran to the 400-step limit without reaching it ends wherever
-    # its hover in front of an obstacle stood after 400 steps, and that position integrates the QP solver's own error: EDGE seed 72 ends 0.2560 / 0.2558 from
-    # the goal in the recorded QP_ITER 100 / 50 tables, 0.2502 here at qp_tol 1e-9, 0.2522 at 1e-10 without the polish, 0.2296 with it and at 1e-11 (round 5,
-    # scripts/oracle_variant_replay.py --seeds EDGE:72; a perturbation of the start by 1e-9 moves it by 1e-8: it is not sensitivity, it is the solver's
-    # accuracy) -- step count, flags and min_margin (6.7e-7) agree.  Such rows are held to 5e-2.
-    reached = rows[st, 1] == 1
+    # dist_to_goal: 1e-3 on every stable seed -- with ONE named exception.  EDGE seed 72 runs to the 400-step limit hovering in front of an obstacle, and where it
+    # stands after 400 steps integrates the QP solver's own error: 0.2560 / 0.2558 from the goal in the recorded QP_ITER 100 / 50 tables, 0.2522 here with the polish
+    # switched off (the round-4 stopping rule), 0.2296 with it (and at qp_tol 1e-11): the polish drives every solve towards the EXACT solution of its QP, which is
+    # tighter than HPIPM at acados' default tolerances (robot_ocp_problem.py:126-132) -- on this one seed it trades fidelity to the reference's closed loop for QP
+    # accuracy.  A start perturbed by 1e-9 moves it by 1e-8: not sensitivity.  Step count, flags and min_margin (6.7e-7) agree.  Both
+    # variants are asserted against their measured values; no other never-arriving row gets a wider bound.
     dd = np.abs(tb[st, 3] - rows[st, 3])
-    assert dd[reached].max() <= 1e-3 and (dd[~reached].max() if (~reached).any() else 0.0) <= 5e-2, (st[dd > 1e-3], dd[dd > 1e-3])
+    named = {"EDGE": {72: (0.2296, 0.2522)}}.get(scen, {})       # seed: (measured with the polish, measured without)
+    plain = np.array([sd not in named for sd in st])
+    assert dd[plain].max() <= 1e-3, (st[plain][dd[plain] > 1e-3], dd[plain][dd[plain] > 1e-3])
+    if named:
+        tb_off, _, _ = replay(mapping, c100, polish_ratio=0.0, polish_tol=0.0, polish_res_g=0.0)
+        for sd, (with_polish, without) in named.items():
+            assert sd in st and rows[sd, 1] == 0 and tb[sd, 1] == 0 and tb[sd, 4] == rows[sd, 4] == tb_off[sd, 4]
+            assert abs(tb[sd, 3] - with_polish) <= 2e-3 and abs(tb_off[sd, 3] - without) <= 2e-3, (sd, tb[sd, 3], tb_off[sd, 3])
+            assert abs(tb_off[sd, 3] - rows[sd, 3]) <= 5e-3      # the round-4 rule stays within 4e-3 of the recording
+        assert np.abs(tb_off[st, 3] - rows[st, 3])[plain].max() <= 1e-3
     m3 = row_match(tb, rows, 1e-3)
     conv50 = agree_between_caps(c100, c50, 1e-3)
     assert (m3 & conv50).sum() >= {"RANDOM": 41, "EDGE": 43}[scen] - 2                        # of 48: converged within 50 iterations everywhere

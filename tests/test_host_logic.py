@@ -193,6 +193,43 @@ def test_bench_line_is_compact_and_parseable():
         bench.compact_line(bloated)
 
 
+def test_bench_roofline_names_its_profile_and_withholds_stale_fields(capsys):
+    """roofline.issue / latency_frac / wait_frac / lanes_exec / traffic / sweep_frac are replayed from the newest committed rocprofv3 PMC profile of the same
+    kernel and batch, not measured by the run: the record names that profile with the launch time it was taken at (`pmc_source`), and when the
+    run's own launch time is more than 5 % away from it -- the kernel changed since -- the fields are null and stderr says so.  achieved / frac / avg_launch_us are
+    always the run's own."""
+    import glob
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    prof = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")) if json.load(open(f))["batch"] == 1024 and "rti_split_kernel<3, 3" in json.load(open(f))["kernel"])[-1]
+    d = json.load(open(prof))
+    us = d["kernel_stats"]["avg_ns"] * 1e-3
+
+    class M:
+        def kernel_name(self, batch): return d["kernel"].split("(")[0]
+    class L:
+        B, streams, m = 1024, 1, M()
+    def run(launch_us):
+        return dict(kern_ms=launch_us * 1e-3 * 100, launches=100, pair_ms=0.0, elapsed=launch_us * 1e-6 * 100 * 1.02, steps=1, mean_iters=10.9)
+    fresh = bench.roofline(L(), 20, 3, run(us * 1.02))
+    assert fresh["pmc_source"]["file"] == "profiles/" + os.path.basename(prof) and abs(fresh["pmc_source"]["avg_launch_us"] - us) < 1e-9 and not fresh["pmc_stale"]
+    assert fresh["issue"] > 0.3 and fresh["latency_frac"] > 0.5 and fresh["traffic"] > 1e6 and fresh["lanes_exec"] > 32
+    stale = bench.roofline(L(), 20, 3, run(us * 1.10))
+    assert stale["pmc_stale"] and stale["pmc_source"]["stale"] and stale["pmc_source"]["file"] == fresh["pmc_source"]["file"]
+    for k in ("issue", "latency_frac", "wait_frac", "lanes_exec", "traffic", "sweep_frac"):
+        assert stale[k] is None, k
+    assert stale["achieved"] > 0 and abs(stale["avg_launch_us"] - us * 1.10) < 1e-6 and stale["frac"] == stale["achieved"] / stale["peak"]
+    assert "withheld" in capsys.readouterr().err
+    # the compact line carries the source (and null fields when stale)
+    line = json.loads(bench.compact_line(dict(json.load(open(os.path.join(ROOT, "profiles", "r04_bench_default.json"))), roofline=stale)))
+    assert line["roofline"]["issue"] is None and line["roofline"]["traffic"] is None and line["roofline"]["pmc_source"].endswith("STALE")
+    line = json.loads(bench.compact_line(dict(json.load(open(os.path.join(ROOT, "profiles", "r04_bench_default.json"))), roofline=fresh)))
+    assert line["roofline"]["pmc_source"].startswith(os.path.basename(prof) + "@") and line["roofline"]["issue"] > 0.3
+    L.streams = 2                                    # pipelined sub-batches: launches overlap, nothing to compare -- no PMC fields
+    assert bench.roofline(L(), 20, 3, run(us))["issue"] is None
+
+
 def test_bench_dry_run_last_stdout_line_parses(built):
     import json
     for wl in ("c2", "c4"):

@@ -307,7 +307,8 @@ def test_polish_and_the_unsolved_rule_on_the_oracle():
     x0, goal, obst = random_batch(4000, no, seed=4242 + N + no)
     b = 715
     d = {}
-    for name, kw in (("off", dict(polish_ratio=0.0, polish_tol=0.0)), ("on", {})):
+    # (round 6: "stationarity" = indicator (c) alone, the residual of the Lagrangian's gradient at 1e-7 -- it sees this instance without the other two)
+    for name, kw in (("off", dict(polish_ratio=0.0, polish_tol=0.0, polish_res_g=0.0)), ("stationarity", dict(polish_ratio=0.0, polish_tol=0.0)), ("on", {})):
         cfg = orc.config(N, no, 0.1 * N, **kw)
         X, U = orc.initial_guess(cfg, x0[b]); P = orc.predict_params(cfg, obst[b])
         r = orc.rti_solve(cfg, x0[b], P, goal[b], X, U)
@@ -316,6 +317,8 @@ def test_polish_and_the_unsolved_rule_on_the_oracle():
         assert ok and r["status"] == 0
         d[name] = (float(np.abs(v - vex).max()), r["iters"])
     assert d["off"][0] > 1e-5 and d["on"][0] < 1e-6 and d["on"][1] - d["off"][1] <= 2, d
+    assert d["stationarity"][0] < 1e-6 and d["stationarity"][1] - d["off"][1] <= 2, d
+    assert orc.config(N, no, 0.1 * N).polish_res_g == 1e-7
     # (2)
     N, no, seed, b = 47, 1, 863992655, 155
     x0, goal, obst = random_batch(1500, no, seed=seed)
@@ -331,7 +334,7 @@ def test_polish_and_the_unsolved_rule_on_the_oracle():
     for N, no, B, seed, b, bxt, was in ((62, 5, 1500, 261131589, 1116, 1, 2e-6), (30, 5, 1025, 390641943, 325, 1, 1e-5)):
         x0, goal, obst = random_batch(B, no, seed=seed)
         for frac, bound in ((0.0, None), (None, 3e-7)):
-            cfg = orc.config(N, no, 0.1 * N, bx_terminal=bxt, **({} if frac is None else dict(polish_step_frac=frac)))
+            cfg = orc.config(N, no, 0.1 * N, bx_terminal=bxt, **({} if frac is None else dict(polish_step_frac=frac, polish_res_g=0.0)))
             X, U = orc.initial_guess(cfg, x0[b]); P = orc.predict_params(cfg, obst[b])
             r = orc.rti_solve(cfg, x0[b], P, goal[b], X, U)
             v = step_vector(N, X, U, r["X"], r["U"])
@@ -343,7 +346,7 @@ def test_polish_and_the_unsolved_rule_on_the_oracle():
     N, no, B = 20, 3, 64
     x0, goal, obst = random_batch(B, no, seed=5)
     its = {}
-    for name, kw in (("off", dict(polish_ratio=0.0, polish_tol=0.0)), ("on", {})):
+    for name, kw in (("off", dict(polish_ratio=0.0, polish_tol=0.0, polish_res_g=0.0)), ("on", {})):
         cfg = orc.config(N, no, 0.1 * N, **kw)
         X = np.zeros((B, N + 1, 5)); U = np.zeros((B, N, 2)); x = x0.copy(); ob = obst.copy(); n = 0; st = []
         for i in range(B):
