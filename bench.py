@@ -519,6 +519,8 @@ def roofline(loop, N, no, r):
         for rec in cp["kernels"]:
             if rec["kernel"] == kname:
                 sweep_frac = {"factor": rec["factor_sweep"]["model_over_measured"], "vector": rec["vector_sweep"]["model_over_measured"]}
+                if "dep_floor" in rec["factor_sweep"]:      # (round 6) the factor sweep's own dependency chain per stage over the measured cycles per stage
+                    sweep_frac["dep_floor"] = rec["factor_sweep"]["dep_floor"]
                 pmc_source["sweep_frac_file"] = "profiles/" + os.path.basename(cps[-1])
     except (OSError, KeyError, ValueError):
         pass
