@@ -414,7 +414,9 @@ __device__ __forceinline__ bool seg_any(bool w, int lane)
     return (b & m) != 0ull;
 }
 // after the step lengths are known: this lane's (stage's) step norm, its estimate against polish_tol, the segment's verdict for the next head
-template <int G>
+// CARRY: the trigger of indicator (c) -- some stage's last step longer than kStationarityStep -- is carried to the next head in S.long_step (one ballot per iteration);
+// a kernel that decides it where it asks (the branch-free form of rti_solve_kernel) leaves S.long_step at true
+template <int G, bool CARRY = true>
 __device__ __forceinline__ void ipm_polish_step(const KParams &p, IpmState &S, int lane, double alpha, const double dz[7], float &stepl)
 {
     // (float)max|dz| = max|(float)dz|: round-to-nearest is monotone, so the maximum is taken on the floats (v_max3_f32 with |.| modifiers: 3 instructions)
@@ -424,7 +426,8 @@ __device__ __forceinline__ void ipm_polish_step(const KParams &p, IpmState &S, i
     bool w, u;
     polish_wanted(sn, stepl, p.polish_tol, p.polish_tol_unsolved, p.polish_kappa, w, u);      // (polish_tol = +inf: indicator off)
     stepl = sn;
-    S.want_step = seg_any<G>(w, lane); S.unsolved = seg_any<G>(u, lane); S.long_step = seg_any<G>(sn > kStationarityStep, lane);
+    S.want_step = seg_any<G>(w, lane); S.unsolved = seg_any<G>(u, lane);
+    if constexpr (CARRY) S.long_step = seg_any<G>(sn > kStationarityStep, lane);
 }
 // A step that is not finite is not a step (MPC_NAN_NOTE): an overflow that reached z without passing through mu or sigma (the last iteration of a solve that
 // diverged under qp_fail_policy 1 takes alpha = 1 on an infinite direction, and the floors then wash the row state clean) ends as status 4, iterate untouched,
@@ -2685,6 +2688,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
     //   (60..104 B per lane in every arrangement tried: measured 17.7 against 17.2 ms per C5 control step), so that kernel keeps the branches.
     constexpr bool BRANCHFREE = NOBST < 10;
     if constexpr (BRANCHFREE) {
+    ipm.long_step = true;      // (not carried in this form: decided at the head, where the residual is asked for)
     for (it = 0;; it++) {
         // ---- complementarity measures ----
         double msum = 0.0, cmax = 0.0;
@@ -2716,7 +2720,14 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
         const double mu = msum * inv_items;
         const double lin = rhoPi * lin0;
         ipm_head(p, ipm, it, mu, lin, cmax);
-        if (__ballot(ipm.ask_g) != 0ull) ipm_head_g(p, ipm, it, stationarity());
+        // (this form decides the trigger of indicator (c) here, in cold code laid out behind the loop, instead of carrying it -- measured per kernel, one box, per control
+        // step against round 5's library: rti_solve_kernel<3, 21, 3> -0.5 % this way, +0.6 % carried; the ten-obstacle form and rti_split_kernel lose 1.5 % this way
+        // and carry it: profiles/r06_stationarity_placement.txt)
+        if (__builtin_expect(__ballot(ipm.ask_g) != 0ull, 0)) {
+            const bool asked = ipm.ask_g && seg_any<G>(stepl > kStationarityStep, lane);
+            const double res_g = __ballot(asked) != 0ull ? stationarity() : 0.0;
+            ipm_head_g(p, ipm, it, asked ? res_g : 0.0);
+        }
         if (__ballot(running) == 0ull) break;
         ipm.cprev = cmax;
         MPC_TICK(0);
@@ -2950,7 +2961,7 @@ __global__ __launch_bounds__(64) void rti_solve_kernel(const KParams p)
             if (p.trace && i == 0 && valid && running) p.trace[((size_t)inst * p.iter_max + it) * 4 + 2] = alpha;
 #endif
             ipm_step_check(ipm, it, alpha, alphad, smu);
-            ipm_polish_step<G>(p, ipm, lane, alpha, dz, stepl);
+            ipm_polish_step<G, false>(p, ipm, lane, alpha, dz, stepl);
             {   // An instance that has stopped keeps its step z (a select, not a step of length zero: what a converged instance computes while it idles
                 // beside a neighbour that still iterates is a Newton step from a state with slacks at their floor -- it may be Inf or NaN, and 0 * NaN
                 // is NaN).  Its row state is no longer read by anything and simply moves on, as do the rows that do not exist.
