@@ -69,7 +69,7 @@ while time.time() - t0 < budget and (replay is None or replay):
                         Xn = np.vstack([before["x0"][b][None], after["X"][b][:N]]); Un = np.vstack([after["u0"][b][None], after["U"][b][:N - 1]])
                         P = orc.predict_params(cfg, before["obst"][b])
                         a = adjudicate(orc, cfg, before["x0"][b], P, goal[b], before["X"][b], before["U"][b], Xn, Un, r["X"], r["U"])      # against the exact QP solution
-                        adjudicated.append(dict(N=N, n_obst=no, kernel=rec["kernel"], **a))
+                        adjudicated.append(dict(N=N, n_obst=no, kernel=rec["kernel"], seed=seed, B=B, alias=alias, step=k, inst=b, **a))      # (seed / step / instance: enough to replay it)
                         if not a["passed"]: why = f"iterate d={d:.2e} adjudication {a}"
                     else:
                         worst = max(worst, d)
