@@ -338,7 +338,8 @@ struct IpmState {            // per instance (segment-uniform)
     bool running = true;
     bool want_step = false;   // polish indicator (b) of the step just taken (ipm_polish_step) ...
     bool unsolved = false;    // ... and the same estimate against kPolishUnsolved x polish_tol: an end-game that is not a tail but a QP left unsolved
-    bool long_step = false;   // some stage's last step was longer than kStationarityStep: only then is indicator (c) worth its sweep
+    bool long_step = false;   // some stage's last step was longer than kStationarityStep: only then is indicator (c) worth its sweep (carried here by
+                              // ipm_polish_step<G, true>; the branch-free form of rti_solve_kernel keeps it at true and decides at its head instead)
     bool ask_g = false;       // the termination test holds and indicators (a), (b) are silent: the caller forms the stationarity residual and ipm_head_g decides (indicator (c))
     double cprev = INFINITY;  // c_max at the head of the previous iteration
 };
