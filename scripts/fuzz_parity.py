@@ -10,26 +10,29 @@ from mpc_gpu import _lib
 from oracle import oracle as orc
 from helpers import adjudicate, oracle_P, oracle_guess, random_batch
 
+# FUZZ_N="30,31,40,47,50,62": horizons to draw from; FUZZ_CFG="polish_step_frac=0.0,...": configuration overrides applied to BOTH sides (re-validation of a default)
+N_CHOICES = [int(x) for x in os.environ["FUZZ_N"].split(",")] if os.environ.get("FUZZ_N") else [2, 3, 5, 9, 10, 14, 15, 17, 19, 20, 21, 25, 30, 31, 32, 40, 47, 50, 62]
+CFG_OVER = {k: (float(v) if ("." in v or "e" in v) else int(v)) for k, v in (kv.split("=") for kv in filter(None, os.environ.get("FUZZ_CFG", "").split(",")))}
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
 BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
 t0 = time.time(); log = []; fails = []; adjudicated = []
 while time.time() - t0 < budget:
-    N = int(rng.choice([2, 3, 5, 9, 10, 14, 15, 17, 19, 20, 21, 25, 30, 31, 32, 40, 47, 50, 62]))
+    N = int(rng.choice(N_CHOICES))
     no = int(rng.integers(1, 11))
     B = int(rng.choice([1, 2, 3, 7, 33, 64, 65, 100, 257]))
     if N > 31: B = min(B, 65)
-    if BIG: B = int(rng.choice([1025, 3000, 4097, 8193, 12289, 20000])) if N <= 31 else 1500      # batches deep enough for instance scheduling and every packing rule
+    if BIG: B = int(rng.choice([1025, 3000, 4097, 8193, 12289, 20000])) if N <= 31 else int(os.environ.get("FUZZ_B_LONG", "1500"))      # batches deep enough for instance scheduling and every packing rule
     lps = int(rng.choice([0, 1, 2, 3])); lanes = int(rng.choice([0, 0, 16, 21, 32, 64])); waves = int(rng.choice([0, 1, 2]))
     soft = int(rng.random() > 0.15); bxt = int(rng.random() > 0.7)
     seed = int(rng.integers(1 << 30))
     x0, goal, obst = random_batch(B, no, seed=seed)
-    cfg = orc.config(N, no, 0.1 * N, soft_h=soft, bx_terminal=bxt)
+    cfg = orc.config(N, no, 0.1 * N, soft_h=soft, bx_terminal=bxt, **CFG_OVER)
     use_alpha = bool(soft and B <= 65 and rng.random() < 0.3)     # an explicit slack schedule (mpc_set_slack_schedule), some stages with zero weight
     alpha = rng.uniform(0.0, 3e4, (B, N + 1)) * (rng.random((B, N + 1)) > 0.15) if use_alpha else None
     rec = dict(N=N, n_obst=no, B=B, lps=lps, lanes=lanes, waves=waves, soft_h=soft, bx_terminal=bxt, seed=seed, explicit_slack_schedule=use_alpha)
     try:
-        with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B, soft_h=soft, bx_terminal=bxt) as s:
+        with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B, soft_h=soft, bx_terminal=bxt, **CFG_OVER) as s:
             L = _lib.lib()
             if lps: L.mpc_set_lanes_per_stage(s._h, lps)          # (an unsupported combination is rejected or ignored by the library: both are fine here)
             if lanes: L.mpc_set_lanes_per_instance(s._h, lanes)
