@@ -32,7 +32,7 @@ def work(job):
             q = orc.export_qp(base, x, P, goal[b], X, U)
             res, vs = {}, {}
             for t in tols:
-                cfg = orc.config(N, no, 0.1 * N, polish_ratio=t[0], polish_tol=t[1], polish_res_g=t[2] if len(t) > 2 else 0.0)
+                cfg = orc.config(N, no, 0.1 * N, polish_ratio=t[0], polish_tol=t[1], polish_res_g=t[2] if len(t) > 2 else 0.0, **(dict(polish_step_frac=t[3]) if len(t) > 3 else {}))
                 r = orc.rti_solve(cfg, x, P, goal[b], X, U)
                 res[t] = r
                 if r["status"] == 0:
@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--count", type=int, default=600)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--tols", default="0:0,1e-2:0,0:1e-6,1e-2:1e-6", help="variants polish_ratio:polish_tol[:polish_res_g]")
+    ap.add_argument("--tols", default="0:0,1e-2:0,0:1e-6,1e-2:1e-6", help="variants polish_ratio:polish_tol[:polish_res_g[:polish_step_frac]]")
     ap.add_argument("--procs", type=int, default=8)
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
