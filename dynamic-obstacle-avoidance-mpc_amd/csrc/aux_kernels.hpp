@@ -355,6 +355,41 @@ __global__ void plant_step_kernel(int batch, double dt, const double *__restrict
     for (int c = 0; c < 5; c++) xn[(size_t)t * 5 + c] = xo[c];
 }
 
+// The stationarity sweep of the polish on its own (tests only): the open-loop adjoint of a GIVEN per-stage gradient g[B][N+1][7] over the linearisation of a given
+// iterate, through rti_kernel.hpp::adjoint_inputs in the lane layouts of the solve kernels -- G lanes per instance with one lane per stage (G = 16, 21, 32, 64), or LPS
+// lanes per stage with one instance per wavefront (rti_split_kernel: the stage's first lane holds g, the others enter the suffix sums with zero).
+// ru[B][N] = max(|ru_t[0]|, |ru_t[1]|), ru_t = g_u,t + B_t' pi_{t+1}, pi_t = g_x,t + A_t' pi_{t+1}.
+template <int G, int LPS>
+__global__ __launch_bounds__(64) void adjoint_check_kernel(KParams p, const double *__restrict__ Xin, const double *__restrict__ Uin, const double *__restrict__ gin,
+                                                            double *__restrict__ ru)
+{
+    constexpr int IPW = LPS > 1 ? 1 : (G == 21 ? 3 : 64 / G);
+    const int lane = threadIdx.x, N = p.N;
+    const int slot = LPS > 1 ? 0 : (G == 21 ? seg21_slot(lane) : lane / G);
+    const int i = LPS > 1 ? lane / LPS : lane - slot * G;
+    const bool own = LPS > 1 ? (lane % LPS == 0) : true;
+    const int inst = blockIdx.x * IPW + slot;
+    const bool act = inst < p.batch && i <= N, has_u = inst < p.batch && i < N;
+    double xi[5] = {0, 0, 0, 0, 0}, ui[2] = {0, 0}, g[7] = {0, 0, 0, 0, 0, 0, 0};
+    StageLin S;
+    S.a02 = S.a03 = S.a04 = S.a12 = S.a13 = S.a14 = S.b00 = S.b01 = S.b10 = S.b11 = 0.0; S.dt = p.dt; S.h2 = p.h2;
+    if (act) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) xi[c] = Xin[((size_t)inst * (N + 1) + i) * 5 + c];
+#pragma unroll
+        for (int c = 0; c < 7; c++) g[c] = gin[((size_t)inst * (N + 1) + i) * 7 + c];
+    }
+    if (has_u) {
+        ui[0] = Uin[((size_t)inst * N + i) * 2]; ui[1] = Uin[((size_t)inst * N + i) * 2 + 1];
+        double xn[5], ae[6], be[4];
+        dyn_step<true>(xi, ui, p.dt, xn, ae, be);
+        S.a02 = ae[0]; S.a03 = ae[1]; S.a04 = ae[2]; S.a12 = ae[3]; S.a13 = ae[4]; S.a14 = ae[5];
+        S.b00 = be[0]; S.b01 = be[1]; S.b10 = be[2]; S.b11 = be[3];
+    }
+    const double r = adjoint_inputs<(LPS > 1 ? 64 : G)>(own && act, own && has_u, S, g, lane);
+    if (own && has_u) ru[(size_t)inst * N + i] = r;
+}
+
 // Dense dump of the linearisation of the iterate (tests only): same device functions the solve kernel uses.
 __global__ void linearize_kernel(KParams p, int n_obst, const double *__restrict__ Xin, const double *__restrict__ Uin,
                                  double *__restrict__ A, double *__restrict__ B, double *__restrict__ b, double *__restrict__ q,

@@ -649,6 +649,31 @@ int mpc_linearize_dev(mpc_handle *h, int batch, const double *d_x0, const double
     return MPC_OK;
 }
 
+int mpc_debug_adjoint_dev(mpc_handle *h, int batch, int lanes_per_instance, int lanes_per_stage, const double *d_X, const double *d_U, const double *d_g,
+                          double *d_ru, void *stream)
+{
+    int rc = check_batch(h, batch); if (rc) return rc;
+    if (batch == 0) return MPC_OK;
+    if (!d_X || !d_U || !d_g || !d_ru) return fail(MPC_ERR_ARG, "null device pointer");
+    const int N = h->cfg.N, G = lanes_per_instance, L = lanes_per_stage;
+    if (!(L == 1 || L == 2 || L == 3)) return fail(MPC_ERR_ARG, "lanes_per_stage must be 1, 2 or 3");
+    if (L > 1 ? (L * (N + 1) > 64) : !((G == 16 || G == 21 || G == 32 || G == 64) && N + 1 <= G))
+        return fail(MPC_ERR_ARG, "the horizon does not fit this lane layout");
+    HIPCHK(hipSetDevice(h->device));
+    mpc::KParams p = make_params(h->cfg, batch);
+    hipStream_t s = pick(h, stream);
+    const int ipw = L > 1 ? 1 : (G == 21 ? 3 : 64 / G);
+    const dim3 grid((batch + ipw - 1) / ipw), block(64);
+    if (L == 3) hipLaunchKernelGGL((mpc::adjoint_check_kernel<64, 3>), grid, block, 0, s, p, d_X, d_U, d_g, d_ru);
+    else if (L == 2) hipLaunchKernelGGL((mpc::adjoint_check_kernel<64, 2>), grid, block, 0, s, p, d_X, d_U, d_g, d_ru);
+    else if (G == 16) hipLaunchKernelGGL((mpc::adjoint_check_kernel<16, 1>), grid, block, 0, s, p, d_X, d_U, d_g, d_ru);
+    else if (G == 21) hipLaunchKernelGGL((mpc::adjoint_check_kernel<21, 1>), grid, block, 0, s, p, d_X, d_U, d_g, d_ru);
+    else if (G == 32) hipLaunchKernelGGL((mpc::adjoint_check_kernel<32, 1>), grid, block, 0, s, p, d_X, d_U, d_g, d_ru);
+    else hipLaunchKernelGGL((mpc::adjoint_check_kernel<64, 1>), grid, block, 0, s, p, d_X, d_U, d_g, d_ru);
+    HIPCHK(hipGetLastError());
+    return MPC_OK;
+}
+
 /* ------------------------------------------------- host-pointer API ------------------------------------------------- */
 
 int mpc_set_warmstart(mpc_handle *h, int batch, const double *X, const double *U)

@@ -73,6 +73,7 @@ SYMBOLS = {
     "mpc_plant_step_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     "mpc_obstacle_step_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _d, _d, _vp]),
     "mpc_linearize_dev": (C.c_int, [_vp, C.c_int] + [_vp] * 12),
+    "mpc_debug_adjoint_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int] + [_vp] * 5),
     "mpc_profile_enable": (C.c_int, [_vp, C.c_int]),
     "mpc_profile_read": (C.c_int, [_vp, C.POINTER(_d), C.POINTER(C.c_int)]),
     "mpc_set_accumulators": (C.c_int, [_vp, _vp, _vp]),
@@ -196,8 +197,15 @@ def lib():
             except ImportError:
                 pass
         L = C.CDLL(LIB_PATH)
+        L.mpc_abi_version.restype = C.c_int
+        diagnostic_older = bool(os.environ.get("MPC_GPU_LIB")) and L.mpc_abi_version() <= ABI_VERSION
         for name, (res, args) in SYMBOLS.items():
-            fn = getattr(L, name)      # AttributeError if the .so does not export a declared symbol
+            try:
+                fn = getattr(L, name)      # AttributeError if the .so does not export a declared symbol
+            except AttributeError:
+                if diagnostic_older:       # (an A/B run against an earlier build, MPC_GPU_LIB: entry points added since are simply absent there)
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         # (a diagnostic build supplied through MPC_GPU_LIB may be OLDER than the mirror -- A/B runs against last round's library: it reads and writes a prefix of

@@ -264,6 +264,10 @@ class BatchedMpc:
         _lib.check(_lib.lib().mpc_linearize_dev(self._h, batch, _ptr(x0), _ptr(P), _ptr(goal), _ptr(X), _ptr(U), _ptr(A), _ptr(B),
                                                 _ptr(b), _ptr(q), _ptr(hval), _ptr(dh), _ptr(stream)))
 
+    def debug_adjoint_dev(self, batch, lanes_per_instance, lanes_per_stage, X, U, g, ru, stream=None):
+        """the polish's stationarity sweep on its own (mpc_debug_adjoint_dev): ru[B][N] from a given gradient g[B][N+1][7] over the linearisation of (X, U)"""
+        _lib.check(_lib.lib().mpc_debug_adjoint_dev(self._h, batch, int(lanes_per_instance), int(lanes_per_stage), _ptr(X), _ptr(U), _ptr(g), _ptr(ru), _ptr(stream)))
+
     # ------------------------------------------------------------------ measurement
     def set_accumulators(self, iters_acc=None, status_acc=None):
         _lib.check(_lib.lib().mpc_set_accumulators(self._h, _ptr(iters_acc), _ptr(status_acc)))

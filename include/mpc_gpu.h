@@ -225,6 +225,13 @@ int mpc_linearize_dev(mpc_handle *h, int batch, const double *d_x0, const double
                       const double *d_X, const double *d_U,
                       double *d_A, double *d_B, double *d_b, double *d_q, double *d_hval, double *d_dh, void *stream);
 
+/* The stationarity sweep of the polish (mpc_config.polish_res_g) on its own, for parity tests of that stage: the open-loop adjoint of a given per-stage gradient
+ * g[B][N+1][7] (order u, x) over the linearisation of the iterate (X, U), in the lane layout of a solve kernel -- lanes_per_stage = 1 with lanes_per_instance 16, 21,
+ * 32 or 64 (N + 1 lanes must fit), or lanes_per_stage 2 (N <= 31) / 3 (N <= 20) with one instance per wavefront.  ru[B][N] = max-norm of the input block
+ * g_u,i + B_i' pi_{i+1} per stage, pi_i = g_x,i + A_i' pi_{i+1}.  (No reference counterpart: HPIPM forms res_g inside acados, robot_ocp_problem.py:126-132,195.) */
+int mpc_debug_adjoint_dev(mpc_handle *h, int batch, int lanes_per_instance, int lanes_per_stage, const double *d_X, const double *d_U, const double *d_g,
+                          double *d_ru, void *stream);
+
 /* ---- measurement: HIP events around solve-kernel launches on the launch stream ----
  * on = 0: off; on = k > 0: events around every k-th launch (k = 1: every launch).  A pair of event records between two back-to-back
  * launches costs the stream ~7 us (measured, scripts/gap_probe.py), so a throughput run samples (bench.py: every 7th launch). */

@@ -929,3 +929,41 @@ def test_stationarity_indicator_closes_a_tail_instance_on_the_gpu(env, lanes):
         res[name] = (float(np.abs(step_vector(N, X[b], U[b], Xg[b], Ug[b]) - vex).max()), int(g["iters"][b]), int(o["iters"][b]))
     assert res["off"][0] > 1e-6 and res["stationarity"][0] < 2e-7, res
     assert 1 <= res["stationarity"][1] - res["off"][1] <= 2 and abs(res["stationarity"][1] - res["stationarity"][2]) <= 1 and res["off"][1] == res["off"][2], res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,L,N", [(16, 1, 14), (16, 1, 5), (21, 1, 20), (21, 1, 17), (32, 1, 30), (32, 1, 20), (64, 1, 50), (64, 1, 62), (64, 1, 33),
+                                   (64, 2, 31), (64, 2, 25), (64, 3, 20), (64, 3, 10)])
+def test_stationarity_sweep_against_the_adjoint_recursion(built, G, L, N):
+    """The sweep behind polish indicator (c) on its own, through the C ABI (mpc_debug_adjoint_dev -> rti_kernel.hpp::adjoint_inputs): for RANDOM per-stage gradients
+    g and a random iterate, the kernels' three levels of suffix sums over the stage lanes against the open-loop adjoint recursion written out in numpy over the
+    oracle's linearisation, pi_N = g_x,N, pi_i = g_x,i + A_i' pi_{i+1}, ru_i = g_u,i + B_i' pi_{i+1} -- in every lane layout a solve kernel uses (16, 21, 32, 64 lanes per
+    instance with one lane per stage: whole DPP rows, and the three-instances-per-wavefront packing whose segments straddle rows; 2 and 3 lanes per stage with one
+    instance per wavefront), horizons that fill the layout and horizons that do not, a batch that ends in a partly filled wavefront.  1e-12 relative."""
+    import torch
+    import mpc_gpu
+    from oracle import oracle as orc
+    no, B = 3, 11
+    cfg = orc.config(N, no, 0.1 * N)
+    rng = np.random.default_rng(1000 + 100 * G + 10 * L + N)
+    X = rng.uniform(-7, 7, (B, N + 1, 5)); X[:, :, 2] = rng.uniform(-6, 6, (B, N + 1)); U = rng.uniform(-8, 8, (B, N, 2))
+    g = rng.standard_normal((B, N + 1, 7)) * rng.choice([1.0, 1e3, 1e6], (B, N + 1, 1))      # multipliers reach 1e6: so do the gradients the residual is made of
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ru = torch.full((B, N), -1.0, dtype=torch.float64, device=dev)
+    with mpc_gpu.BatchedMpc(N, no, 0.1 * N, max_batch=B) as s:
+        s.debug_adjoint_dev(B, G, L, t(X), t(U), t(g), ru, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for Gbad, Lbad in ((16 if N + 1 > 16 else 17, 1), (21 if N + 1 > 21 else 20, 1), (64, 3 if N > 20 else 5), (64, 2 if N > 31 else 4)):
+            with pytest.raises(mpc_gpu.MpcError):          # a layout the horizon does not fit, or one that does not exist, is refused
+                s.debug_adjoint_dev(B, Gbad, Lbad, t(X), t(U), t(g), ru)
+    ru = ru.cpu().numpy()
+    zero = np.zeros(5); P0 = np.zeros((N + 1, no, 2))
+    for b in range(B):
+        lin = orc.linearize(cfg, zero, P0, np.zeros(2), X[b], U[b])
+        pi = g[b, N, 2:].copy()
+        for i in range(N - 1, -1, -1):
+            r = g[b, i, :2] + lin["B"][i].T @ pi
+            scale = max(1.0, np.abs(g[b, i:]).max())
+            assert abs(ru[b, i] - np.abs(r).max()) <= 1e-12 * scale * (N - i + 1), (b, i, ru[b, i], np.abs(r).max())
+            pi = g[b, i, 2:] + lin["A"][i].T @ pi
