@@ -230,6 +230,28 @@ def test_bench_roofline_names_its_profile_and_withholds_stale_fields(capsys):
     assert bench.roofline(L(), 20, 3, run(us))["issue"] is None
 
 
+def test_cpu_baseline_of_the_bench_runs_and_reports_its_spread():
+    """bench.py::cpu_baseline on a small budget, in a child process (it switches the oracle module to its -O3 -march=native build, which must not become this
+    process's checker): thread sweep to the plateau, the plateau timed three times -- `value` is the median and lies inside `spread` --, one thread, and the
+    reference's call pattern; episodes roll over (more control steps than one episode holds) without the loop state running away."""
+    import json
+    import subprocess
+    code = (
+        "import sys, json; sys.path.insert(0, %r); import bench\n"
+        "from mpc_gpu.sharding import shard_slice\n"
+        "x0, goal, obst, *_ = bench.make_workload('c2', 1, 0, shard_slice)\n"
+        "r = bench.cpu_baseline(20, 3, x0[:16], goal[:16], obst[:16], budget_s=2.0, steady_s=1.0)\n"
+        "print(json.dumps({k: r[k] for k in ('value', 'cores', 'kind', 'spread', 'one_thread', 'python_call_pattern_one_thread', 'threads', 'sample')}))\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["kind"] == "port" and r["value"] > 100 and r["one_thread"] > 100 and r["python_call_pattern_one_thread"] > 10
+    assert r["spread"]["samples"] == 3 and r["spread"]["min"] <= r["value"] * 1.0001 and r["value"] <= r["spread"]["max"] * 1.0001
+    assert str(r["cores"]) in r["threads"] and "x 3 (median" in r["sample"]
+    steps = int(r["sample"].split(" scenarios x ")[1].split(" ")[0])
+    assert steps > 100, r["sample"]           # 16 scenarios at >= 2e3 solves/s for 1 s: more than one episode of 100 control steps
+
+
 def test_bench_dry_run_last_stdout_line_parses(built):
     import json
     for wl in ("c2", "c4"):

@@ -362,3 +362,25 @@ def test_polish_and_the_unsolved_rule_on_the_oracle():
                 X[i], U[i] = orc.shift(cfg, r["X"][i], r["U"][i])
         its[name] = (n, np.stack(st))
     assert np.array_equal(its["on"][1], its["off"][1]) and its["off"][0] <= its["on"][0] <= 1.015 * its["off"][0], (its["on"][0], its["off"][0])
+
+
+def test_batch_helpers_of_the_cpu_baseline_are_the_per_instance_functions():
+    """bench.py's cpu_baseline advances its closed loop with two batch calls (orc_predict_params_batch, orc_advance_batch) instead of ~6 Python -> C calls per scenario
+    and control step: bit for bit what the per-instance functions give (look-ahead; plant step, noise-free obstacle step, warm-start shift)."""
+    from oracle import oracle as orc
+    from helpers import random_batch
+    N, no, B = 20, 3, 9
+    cfg = orc.config(N, no, 2.0)
+    x0, goal, obst = random_batch(B, no, seed=11)
+    obst[0, 0] = [7.95, -7.9, 1.9, -1.7]                       # next to two walls: the reflections are part of both paths
+    rng = np.random.default_rng(3)
+    X = rng.uniform(-5, 5, (B, N + 1, 5)); U = rng.uniform(-8, 8, (B, N, 2)); u0 = rng.uniform(-8, 8, (B, 2))
+    P = orc.predict_params_batch(cfg, obst)
+    assert np.array_equal(P, np.stack([orc.predict_params(cfg, o) for o in obst]))
+    x1, o1, X1, U1 = x0.copy(), obst.copy(), X.copy(), U.copy()
+    orc.advance_batch(cfg, x1, u0, o1, X1, U1)
+    for b in range(B):
+        assert np.array_equal(x1[b], orc.dynamics(x0[b], u0[b], 0.1)[0])
+        assert np.array_equal(o1[b], np.array([orc.obstacle_step(cfg, o, 0.1) for o in obst[b]]))
+        Xs, Us = orc.shift(cfg, X[b], U[b])
+        assert np.array_equal(X1[b], Xs) and np.array_equal(U1[b], Us)
