@@ -47,6 +47,15 @@ static int one_config(int N, int no, int batch)
         int st = orc_rti_solve_alpha(&c, x0 + 5 * b, P + sP * b, goal + 2 * b, alpha, X + sX * b, U + sU * b, u0 + 2 * b, cost + b, &it, kkt);
         if (st != 0 && st != 2 && st != 4) bad++;
     }
+    /* the batch helpers of bench.py's cpu_baseline (look-ahead of a whole batch; plant step + obstacle step + warm-start shift in place), then one more batched
+     * solve from what they left: the long-step trigger and the stationarity residual of the polish are on by default (orc_last_res_g reads what was formed) */
+    orc_predict_params_batch(&c, batch, obst, P);
+    orc_advance_batch(&c, batch, x0, u0, obst, X, U);
+    orc_predict_params_batch(&c, batch, obst, P);
+    orc_rti_solve_batch(&c, batch, x0, P, goal, X, U, u0, cost, status, iters, 2);
+    for (int b = 0; b < batch; b++) if (status[b] != 0 && status[b] != 2 && status[b] != 4) bad++;
+    if (!(orc_last_res_g() >= 0.0) || orc_last_settled_it() < -1) bad++;
+    orc_set_investigation(0);
     /* linearisation products and the dense QP of instance 0 */
     {
         double *A = malloc(sizeof(double) * N * 25), *B = malloc(sizeof(double) * N * 10), *bb = malloc(sizeof(double) * N * 5);
