@@ -33,6 +33,8 @@ int main(void)
     if (mpc_reset_guess(NULL, 1, buf) != MPC_ERR_ARG) bad++;
     if (mpc_plant_step(NULL, 1, buf, buf, buf) != MPC_ERR_ARG) bad++;
     if (mpc_predict(NULL, 1, buf, buf) != MPC_ERR_ARG) bad++;
+    if (mpc_debug_adjoint_dev(NULL, 1, 64, 1, buf, buf, buf, buf, NULL) != MPC_ERR_ARG) bad++;
+    if (mpc_linearize_dev(NULL, 1, buf, buf, buf, buf, buf, buf, buf, buf, buf, buf, buf, NULL) != MPC_ERR_ARG) bad++;
     if (mpc_profile_enable(NULL, 1) != MPC_ERR_ARG) bad++;
     if (mpc_set_lanes_per_stage(NULL, 0) != MPC_ERR_ARG) bad++;
     if (mpc_set_waves_per_simd(NULL, 2) != MPC_ERR_ARG) bad++;
